@@ -1,0 +1,184 @@
+/*
+ * currennt_hip.h -- C ABI of libcurrennt_hip.so, the MI355X (gfx950) implementation of the
+ * CURRENNT LSTM training hot path (naxingyu/lstm-rnn, currennt_lib/src).
+ *
+ * The reference has no FFI layer: its seam is the virtual layers::Layer<TDevice> interface
+ * (layers/Layer.hpp:40-179, layers/TrainableLayer.hpp:84-155, layers/PostOutputLayer.hpp:80)
+ * plus the GEMM seam helpers::Matrix / helpers::cublas::multiplyMatrices
+ * (helpers/Matrix.hpp:48-49, helpers/cublas.hpp:30-38).  Every entry point below names the
+ * reference method it stands in for; a maintainer binds them from a `Hip` device policy next to
+ * `Cpu`/`Gpu` (Types.hpp:45-67) as shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: opaque handles, ints, floats, raw pointers; no C++ or torch types.
+ *   - every function returns 0 on success or a negative cn_status; the message is available
+ *     from cn_last_error() (the reference throws std::runtime_error(msg), e.g. Matrix.cu:209-210;
+ *     host wrappers turn a non-zero status back into an exception -> "FAILED: msg", exit code 2,
+ *     main.cpp:492-495).
+ *   - host arrays use the reference layouts: activations [t*PS + ps][unit]
+ *     (DataSet.cpp:359,376,383,406), flat weight vectors as in LstmLayer.hpp:36-55 and
+ *     FeedForwardLayer.cu:148,160.  Padded / packed / bf16 device copies are internal.
+ *   - one cn_ctx per GPU, used from one host thread at a time (the reference is single-threaded,
+ *     cublas.cu:33-43).  All work is enqueued on the ctx stream; only the functions marked
+ *     [sync] wait for the device.
+ */
+#ifndef CURRENNT_HIP_H
+#define CURRENNT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cn_ctx   cn_ctx;
+typedef struct cn_layer cn_layer;
+
+typedef enum cn_status {
+    CN_OK            =  0,
+    CN_ERR_BAD_ARG   = -1,   /* null handle, negative size, unknown enum                     */
+    CN_ERR_SHAPE     = -2,   /* size mismatch (reference: "Invalid matrix dimensions", ...)  */
+    CN_ERR_HIP       = -3,   /* a HIP runtime call failed                                    */
+    CN_ERR_STATE     = -4,   /* call order violated (e.g. forward before a fraction is loaded)*/
+    CN_ERR_NO_DEVICE = -5    /* no gfx950 device / code object cannot run here               */
+} cn_status;
+
+/* arithmetic mode of the GEMM operands (accumulation and all state are always fp32) */
+typedef enum cn_precision {
+    CN_PREC_F32  = 0,   /* fp32 operands on v_mfma_f32_*_f32: parity mode (real_t = float, Types.hpp:39) */
+    CN_PREC_BF16 = 1    /* bf16 operands on v_mfma_f32_*_bf16: throughput mode                           */
+} cn_precision;
+
+/* layer kinds = the type strings of LayerFactory.cu:52-87 that are on the hot path */
+typedef enum cn_layer_kind {
+    CN_LAYER_INPUT = 0,                   /* "input"                      InputLayer.cpp            */
+    CN_LAYER_LSTM,                        /* "lstm"                       LstmLayer.cu              */
+    CN_LAYER_BLSTM,                       /* "blstm"                      LstmLayer.cu              */
+    CN_LAYER_FF_TANH,                     /* "feedforward_tanh"           FeedForwardLayer.cu       */
+    CN_LAYER_FF_LOGISTIC,                 /* "feedforward_logistic"                                 */
+    CN_LAYER_FF_IDENTITY,                 /* "feedforward_identity"                                 */
+    CN_LAYER_SOFTMAX,                     /* "softmax"                    SoftmaxLayer.cu           */
+    CN_LAYER_SSE,                         /* "sse"                        SsePostOutputLayer.cu     */
+    CN_LAYER_MULTICLASS_CLASSIFICATION    /* "multiclass_classification"  MulticlassClassificationLayer.cu */
+} cn_layer_kind;
+
+/* which device vector cn_layer_read / cn_layer_device_ptr addresses */
+typedef enum cn_buffer {
+    CN_BUF_OUTPUTS = 0,        /* Layer::outputs()               [N][size]  Layer.hpp:132        */
+    CN_BUF_OUTPUT_ERRORS,      /* Layer::outputErrors()          [N][size]  Layer.hpp:153        */
+    CN_BUF_WEIGHTS,            /* TrainableLayer::weights()      flat       TrainableLayer.hpp:119*/
+    CN_BUF_WEIGHT_UPDATES,     /* TrainableLayer::weightUpdates() flat      TrainableLayer.hpp:133*/
+    CN_BUF_WEIGHT_DELTAS,      /* SteepestDescentOptimizer::m_weightDeltas  SteepestDescentOptimizer.cu:117-123 */
+    /* LSTM per-direction internals, [N][H] each (LstmLayer.hpp:88-100,170-233); `dir` selects fw/bw */
+    CN_BUF_LSTM_CELL_STATES,
+    CN_BUF_LSTM_NI_ACTS,
+    CN_BUF_LSTM_IG_ACTS,
+    CN_BUF_LSTM_FG_ACTS,
+    CN_BUF_LSTM_OG_ACTS,
+    CN_BUF_LSTM_NI_DELTAS,
+    CN_BUF_LSTM_IG_DELTAS,
+    CN_BUF_LSTM_FG_DELTAS,
+    CN_BUF_LSTM_OG_DELTAS,
+    CN_BUF_LSTM_TMP_OUTPUTS    /* per-direction block outputs y */
+} cn_buffer;
+
+/* one parallel-sequence mini batch = data_sets::DataSetFraction (DataSetFraction.hpp:50-60) */
+typedef struct cn_fraction {
+    int          max_seq_length;    /* T     = fraction.maxSeqLength()                               */
+    int          min_seq_length;    /* Tmin  = fraction.minSeqLength()                               */
+    int          num_sequences;     /* fraction.numSequences() (<= parallel_sequences)               */
+    int          input_pattern_size;/* fraction.inputPatternSize()                                   */
+    int          output_pattern_size;/* fraction.outputPatternSize()                                  */
+    const char  *pat_types;         /* [T*PS]            0 = PATTYPE_NONE  (Types.hpp:30-33)         */
+    const float *inputs;            /* [T*PS][inputSize]                                              */
+    const int   *target_classes;    /* [T*PS] or NULL    -1 on dummy slots (DataSet.cpp:336)         */
+    const float *targets;           /* [T*PS][outputSize] or NULL                                     */
+} cn_fraction;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Replaces the device selection of main.cpp:526-541 and the lazy cuBLAS handle of cublas.cu:33-43.
+ * `stream` is a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream) or NULL
+ * for a stream owned by the context. */
+int  cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **out);
+int  cn_ctx_destroy(cn_ctx *ctx);
+int  cn_ctx_synchronize(cn_ctx *ctx);                                   /* [sync] */
+/* message of the last failed call on this thread (ctx may be NULL for creation failures) */
+const char *cn_last_error(cn_ctx *ctx);
+/* "gfx950" etc. of the bound device; version string of the library */
+const char *cn_device_arch(cn_ctx *ctx);
+const char *cn_version(void);
+
+/* ---- layers (LayerFactory<TDevice>::createLayer, LayerFactory.hpp:49-56) -------------------- */
+
+/* `preceding` is NULL only for CN_LAYER_INPUT.  parallel_sequences / max_seq_length size every
+ * buffer once, as Layer.cpp:59-66 and LstmLayer.cu:553-574 do; they are taken from `preceding`
+ * for all other layers (pass 0).  `bias` is the JSON "bias" value (TrainableLayer.cu:57). */
+int  cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int size, float bias,
+                     int parallel_sequences, int max_seq_length, cn_layer **out);
+int  cn_layer_destroy(cn_layer *layer);
+
+int  cn_layer_size(const cn_layer *layer);
+int  cn_layer_kind_of(const cn_layer *layer);
+/* number of weights: size*(inputWeightsPerBlock*(P+1)+internalWeightsPerBlock), TrainableLayer.cu:101 */
+int  cn_layer_weight_count(const cn_layer *layer);
+
+/* Layer::loadSequences(fraction) for every layer of the stack: uploads patTypes once (the
+ * reference copies them per layer, Layer.cpp:140), inputs (InputLayer.cpp:49-60) and targets /
+ * target classes (PostOutputLayer.cpp:67-79, MulticlassClassificationLayer.cu:186-192).
+ * Error texts follow the reference ("Input layer size of X != data input pattern size of Y"). */
+int  cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
+
+/* Layer::computeForwardPass / computeBackwardPass (Layer.hpp:165-170).  Backward of a trainable
+ * layer consumes its outputErrors, writes the preceding trainable layer's outputErrors
+ * (LstmLayer.cu:990-1009, FeedForwardLayer.cu:188-198) and its own weightUpdates. */
+int  cn_layer_forward(cn_layer *layer);
+int  cn_layer_backward(cn_layer *layer);
+
+/* PostOutputLayer::calculateError() and, for multiclass_classification,
+ * countCorrectClassifications() (MulticlassClassificationLayer.cu:159-177,194-213).
+ * `correct` may be NULL; it is set to -1 for layers without a class count.        [sync] */
+int  cn_loss_eval(cn_layer *post_output, float *error, int *correct);
+
+/* ---- weights (TrainableLayer.cu:65-101,211-248) --------------------------------------------- */
+
+int  cn_layer_set_weights(cn_layer *layer, const float *host, int count);       /* flat reference layout */
+/* copy one reference-layout vector to the host; `dir` = 0 fw / 1 bw for LSTM internals.   [sync] */
+int  cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t count);
+/* overwrite Layer::outputErrors() from the host (tests of a single layer's backward pass) */
+int  cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t count);
+/* raw fp32 device pointer of a flat parameter vector (WEIGHTS / WEIGHT_UPDATES / WEIGHT_DELTAS),
+ * valid until the layer is destroyed; SteepestDescentOptimizer.cu:83-85 reads the same pointers */
+void *cn_layer_device_ptr(cn_layer *layer, cn_buffer which);
+
+/* All trainable layers of a context share one parameter arena [weights | weightUpdates | deltas];
+ * the weightUpdates part is what the data-parallel all-reduce sums.  The arena is
+ * laid out at the first call of this function / the first forward pass; creating a trainable layer
+ * afterwards fails with CN_ERR_STATE. */
+int  cn_ctx_param_arena(cn_ctx *ctx, void **weights, void **weight_updates, void **weight_deltas,
+                        size_t *count);
+
+/* Tell the library that the flat weights were modified through a raw device pointer (e.g. by an
+ * external optimizer); the packed copies are rebuilt before the next forward pass. */
+int  cn_ctx_weights_touched(cn_ctx *ctx);
+
+/* UpdateWeightFn (SteepestDescentOptimizer.cu:39-59): delta = momentum*delta - lr*update;
+ * w += delta; then refresh the packed device copies the kernels read. */
+int  cn_sgd_update(cn_layer *layer, float learning_rate, float momentum);
+/* the same for every trainable layer of the context in one launch (per-layer learning rates are
+ * not applied here; use cn_sgd_update per layer for those, TrainableLayer.cu:58) */
+int  cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Wrap hipEvents around the kernels of one class on the ctx stream and accumulate their device
+ * time; used by bench.py for the live roofline figure.  kernel_class: 0 = recurrent forward,
+ * 1 = recurrent backward, 2 = N-wide gate GEMMs, 3 = weight-gradient GEMMs, 4 = everything else. */
+int  cn_ctx_timing_enable(cn_ctx *ctx, int enable);
+int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, long *launches); /* [sync] */
+int  cn_ctx_timing_reset(cn_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURRENNT_HIP_H */

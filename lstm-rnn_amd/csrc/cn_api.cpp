@@ -1,0 +1,854 @@
+// C ABI of libcurrennt_hip.so (include/currennt_hip.h): contexts, layer objects, buffer ownership
+// and the per-layer kernel sequences.  Host-only code; all device work is in the .hip files.
+//
+// Layer call sequences follow the reference methods they replace:
+//   LSTM   forward  LstmLayer.cu:763-886    backward LstmLayer.cu:888-1051
+//   FF     forward  FeedForwardLayer.cu:143-170   backward :172-224
+//   softmax forward SoftmaxLayer.cu:250-315 backward :317-353
+//   post output     MulticlassClassificationLayer.cu:159-240, SsePostOutputLayer.cu:114-155
+#include "cn_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace cn;
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_last_error;
+
+struct cn_error : std::runtime_error {
+    int code;
+    cn_error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess)
+        throw cn_error(CN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_CHECK(x) hip_check((x), #x)
+
+template <typename F> int guarded(F &&f)
+{
+    try { f(); return CN_OK; }
+    catch (const cn_error &e) { g_last_error = e.what(); return e.code; }
+    catch (const std::exception &e) { g_last_error = e.what(); return CN_ERR_HIP; }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------
+struct cn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool f32 = true;
+    std::string arch;
+    std::vector<cn_layer *> layers;
+
+    // current fraction (Layer::loadSequences, Layer.cpp:134-141)
+    int PS = 0, maxT = 0, T = 0, Tmin = 0, N = 0, numSeqs = 0;
+    bool loaded = false;
+    char *d_pat = nullptr;
+    int *d_tcls = nullptr;
+    float *d_loss = nullptr;      // [2]
+
+    // parameter arena [weights | weightUpdates | weightDeltas]
+    bool finalized = false;
+    float *arena = nullptr;
+    size_t total = 0;
+
+    // timing
+    bool timing = false;
+    struct Span { hipEvent_t a, b; };
+    std::vector<Span> spans[KC_COUNT];
+    std::vector<hipEvent_t> free_events;
+    double acc_ms[KC_COUNT] = {0, 0, 0, 0, 0};
+    long acc_n[KC_COUNT] = {0, 0, 0, 0, 0};
+
+    size_t esz() const { return f32 ? 4 : 2; }
+};
+
+struct cn_layer {
+    cn_ctx *ctx = nullptr;
+    cn_layer_kind kind = CN_LAYER_INPUT;
+    cn_layer *prev = nullptr;
+    int size = 0;
+    float bias = 0.f;
+    int PS = 0, maxT = 0;
+    bool trainable = false, post = false, lstm = false, has_follower = false;
+
+    int dirs = 1, H = 0, Hp = 0;          // lstm geometry
+    int Lp = 0;                           // padded output width (row stride of out/err)
+    int P = 0, Pp = 0;                    // preceding layer size / padded width
+
+    // activations
+    void *out_op = nullptr;               // [maxN][Lp] operand copy of the outputs
+    float *out_f32 = nullptr;             // [maxN][Lp] fp32 outputs (ff/softmax; aliases out_op in f32 mode)
+    float *err = nullptr;                 // [maxN][Lp] outputErrors
+    float *stage_in = nullptr;            // input layer: [maxN][size] fp32 as loaded
+    float *targets = nullptr;             // sse: [maxN][size]
+
+    // lstm internals
+    float *acts = nullptr, *cell = nullptr;
+    void *delta_op = nullptr;
+
+    // parameters (flat reference layout, inside the ctx arena)
+    size_t woff = 0;
+    int nw = 0;
+    float *w = nullptr, *wu = nullptr, *wd = nullptr;
+    std::vector<float> pending_w;         // set_weights before the arena exists
+    bool dirty = true;                    // packed copies out of date
+
+    // packed copies
+    void *Win = nullptr, *WinT = nullptr, *Wrec = nullptr, *WrecT = nullptr;
+    float *bias_p = nullptr, *peep_p = nullptr;
+    float *grad_block = nullptr;          // dWin | dWrec | dbias | dpeep  (or dW | colsum), zeroed per backward
+    size_t grad_block_floats = 0;
+    float *dWin = nullptr, *dWrec = nullptr, *dbias = nullptr, *dpeep = nullptr;
+
+    std::vector<void *> owned;            // device allocations to free
+
+    size_t maxN() const { return (size_t)PS * maxT; }
+};
+
+namespace {
+
+void *dalloc(cn_layer *l, size_t bytes)
+{
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    HIP_CHECK(hipMalloc(&p, bytes));
+    HIP_CHECK(hipMemsetAsync(p, 0, bytes, l->ctx->stream));
+    l->owned.push_back(p);
+    return p;
+}
+
+// ---- timing ---------------------------------------------------------------------------------
+hipEvent_t get_event(cn_ctx *c)
+{
+    if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+    hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
+}
+struct Timed {
+    cn_ctx *c; int cls; hipEvent_t a = nullptr;
+    Timed(cn_ctx *ctx, int k) : c(ctx), cls(k)
+    {
+        if (c->timing) { a = get_event(c); hipEventRecord(a, c->stream); }
+    }
+    ~Timed()
+    {
+        if (a) { hipEvent_t b = get_event(c); hipEventRecord(b, c->stream); c->spans[cls].push_back({a, b}); }
+    }
+};
+void timing_collect(cn_ctx *c)
+{
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < KC_COUNT; ++k) {
+        for (auto &sp : c->spans[k]) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, sp.a, sp.b));
+            c->acc_ms[k] += ms; c->acc_n[k] += 1;
+            c->free_events.push_back(sp.a); c->free_events.push_back(sp.b);
+        }
+        c->spans[k].clear();
+    }
+}
+
+// ---- geometry -------------------------------------------------------------------------------
+int pad_units(int H) { return H > 512 ? round_up(H, 64) : round_up(H, 32); }
+
+LstmGeom lstm_geom(const cn_layer *l)
+{
+    LstmGeom g;
+    g.P = l->P; g.Pp = l->Pp; g.L = l->size; g.H = l->H; g.Hp = l->Hp; g.dirs = l->dirs;
+    g.prevH = l->prev->lstm ? l->prev->H : 0;
+    g.prevHp = l->prev->lstm ? l->prev->Hp : 0;
+    g.prevDirs = l->prev->lstm ? l->prev->dirs : 0;
+    return g;
+}
+FfGeom ff_geom(const cn_layer *l)
+{
+    FfGeom g;
+    g.P = l->P; g.Pp = l->Pp; g.L = l->size; g.Lp = l->Lp;
+    g.prevH = l->prev->lstm ? l->prev->H : 0;
+    g.prevHp = l->prev->lstm ? l->prev->Hp : 0;
+    g.prevDirs = l->prev->lstm ? l->prev->dirs : 0;
+    return g;
+}
+int ff_act(cn_layer_kind k)
+{
+    switch (k) {
+    case CN_LAYER_FF_TANH: return ACT_TANH;
+    case CN_LAYER_FF_LOGISTIC: return ACT_LOGISTIC;
+    default: return ACT_IDENTITY;
+    }
+}
+
+// ---- parameter arena ------------------------------------------------------------------------
+void finalize(cn_ctx *c)
+{
+    if (c->finalized) return;
+    size_t total = 0;
+    for (cn_layer *l : c->layers)
+        if (l->trainable) { l->woff = total; total += (size_t)round_up(l->nw, 4); }
+    c->total = total;
+    if (total) {
+        HIP_CHECK(hipMalloc((void **)&c->arena, 3 * total * sizeof(float)));
+        HIP_CHECK(hipMemsetAsync(c->arena, 0, 3 * total * sizeof(float), c->stream));
+    }
+    for (cn_layer *l : c->layers) {
+        if (!l->trainable) continue;
+        l->w = c->arena + l->woff;
+        l->wu = c->arena + total + l->woff;
+        l->wd = c->arena + 2 * total + l->woff;
+        if (!l->pending_w.empty()) {
+            HIP_CHECK(hipMemcpyAsync(l->w, l->pending_w.data(), l->pending_w.size() * sizeof(float),
+                                     hipMemcpyHostToDevice, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            l->pending_w.clear();
+        }
+        l->dirty = true;
+    }
+    c->finalized = true;
+}
+
+void repack(cn_layer *l)
+{
+    if (!l->dirty) return;
+    cn_ctx *c = l->ctx;
+    Timed tm(c, KC_OTHER);
+    if (l->lstm) launch_lstm_pack(c->stream, c->f32, lstm_geom(l), l->bias, l->w, l->Win, l->WinT, l->Wrec, l->WrecT, l->bias_p, l->peep_p);
+    else         launch_ff_pack(c->stream, c->f32, ff_geom(l), l->bias, l->w, l->Win, l->WinT, l->bias_p);
+    l->dirty = false;
+}
+
+void require_loaded(cn_ctx *c)
+{
+    if (!c->loaded) throw cn_error(CN_ERR_STATE, "no fraction loaded (call cn_fraction_load first)");
+}
+
+// ---- forward / backward sequences -----------------------------------------------------------
+void lstm_rec_args(cn_layer *l, LstmRec &r)
+{
+    cn_ctx *c = l->ctx;
+    r.H = l->H; r.Hp = l->Hp; r.dirs = l->dirs; r.PS = c->PS; r.T = c->T; r.Tmin = c->Tmin;
+    r.pat = c->d_pat;
+    r.acts = l->acts; r.cell = l->cell; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
+    r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
+    r.bias = l->bias;
+}
+
+void lstm_forward(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    const int R = l->dirs * 4 * l->Hp;
+    repack(l);
+    {   // K1: gate pre-activations of all frames, 4 gates x dirs packed into one N = R product
+        Timed tm(c, KC_GEMM_WIDE);
+        GemmNT g{};
+        g.A = l->prev->out_op; g.lda = l->Pp; g.B = l->Win; g.ldb = l->Pp;
+        g.C = l->acts; g.ldc = R; g.C2 = nullptr; g.ldc2 = 0; g.bias = l->bias_p; g.act = ACT_IDENTITY;
+        g.M = c->N; g.N = R; g.K = l->Pp;
+        launch_gemm_nt(c->stream, c->f32, g);
+    }
+    {   // K2+K3+K4: the whole time loop
+        Timed tm(c, KC_REC_FWD);
+        LstmRec r; lstm_rec_args(l, r);
+        launch_lstm_forward(c->stream, c->f32, r);
+    }
+}
+
+void lstm_backward(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    const int R = l->dirs * 4 * l->Hp, Hp = l->Hp, PS = c->PS, N = c->N;
+    const size_t e = c->esz();
+    repack(l);
+    {
+        Timed tm(c, KC_OTHER);
+        HIP_CHECK(hipMemsetAsync(l->grad_block, 0, l->grad_block_floats * sizeof(float), c->stream));
+    }
+    {   // K5+K6+K7 and the bias / peephole sums of K9
+        Timed tm(c, KC_REC_BWD);
+        LstmRec r; lstm_rec_args(l, r);
+        launch_lstm_backward(c->stream, c->f32, r);
+    }
+    if (l->prev->trainable) {   // K8 (LstmLayer.cu:990-1009): one K = R product instead of 4*dirs
+        Timed tm(c, KC_GEMM_WIDE);
+        GemmNT g{};
+        g.A = l->delta_op; g.lda = R; g.B = l->WinT; g.ldb = R;
+        g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
+        g.M = N; g.N = l->Pp; g.K = R;
+        launch_gemm_nt(c->stream, c->f32, g);
+    }
+    {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
+        Timed tm(c, KC_GEMM_GRAD);
+        GemmTN g{};
+        g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
+        g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
+        launch_gemm_tn(c->stream, c->f32, g);
+        // K9 recurrent weights: dWrec[(g,j)][i] = sum_t delta[t][(g,j)] y[prev(t)][i]
+        if (N > PS) {
+            for (int d = 0; d < l->dirs; ++d) {
+                GemmTN r{};
+                const char *dl = (const char *)l->delta_op + (size_t)d * 4 * Hp * e;
+                const char *y = (const char *)l->out_op + (size_t)d * Hp * e;
+                if (d == 0) { r.A = dl + (size_t)PS * R * e; r.B = y; }                       // skipFirstPattern, LstmLayer.cu:432-435
+                else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
+                r.lda = R; r.ldb = l->Lp;
+                r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
+                launch_gemm_tn(c->stream, c->f32, r);
+            }
+        }
+    }
+    {
+        Timed tm(c, KC_OTHER);
+        launch_lstm_unpack_grads(c->stream, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu);
+    }
+}
+
+void ff_forward(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    repack(l);
+    const bool softmax = l->kind == CN_LAYER_SOFTMAX;
+    {
+        Timed tm(c, KC_GEMM_WIDE);
+        GemmNT g{};
+        g.A = l->prev->out_op; g.lda = l->Pp; g.B = l->Win; g.ldb = l->Pp;
+        g.C = l->out_f32; g.ldc = l->Lp;
+        g.C2 = (!c->f32 && !softmax) ? l->out_op : nullptr; g.ldc2 = l->Lp;
+        g.bias = l->bias_p; g.act = ff_act(l->kind);
+        g.M = c->N; g.N = l->Lp; g.K = l->Pp;
+        launch_gemm_nt(c->stream, c->f32, g);
+    }
+    if (softmax) {
+        Timed tm(c, KC_OTHER);
+        launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp);
+        if (!c->f32 && l->has_follower) launch_pad_convert(c->stream, false, l->out_f32, c->N, l->Lp, l->out_op, l->Lp);
+    }
+}
+
+void ff_backward(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    const int N = c->N;
+    repack(l);
+    {
+        Timed tm(c, KC_OTHER);
+        if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, l->out_f32, l->err, c->d_pat, N, l->size, l->Lp);
+        launch_ff_delta(c->stream, c->f32, ff_act(l->kind), l->out_f32, l->err, l->delta_op, N, l->size, l->Lp);
+        HIP_CHECK(hipMemsetAsync(l->grad_block, 0, l->grad_block_floats * sizeof(float), c->stream));
+        launch_colsum(c->stream, l->err, N, l->Lp, l->dbias);
+    }
+    if (l->prev->trainable) {   // FeedForwardLayer.cu:188-198
+        Timed tm(c, KC_GEMM_WIDE);
+        GemmNT g{};
+        g.A = l->delta_op; g.lda = l->Lp; g.B = l->WinT; g.ldb = l->Lp;
+        g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
+        g.M = N; g.N = l->Pp; g.K = l->Lp;
+        launch_gemm_nt(c->stream, c->f32, g);
+    }
+    {   // FeedForwardLayer.cu:200-207
+        Timed tm(c, KC_GEMM_GRAD);
+        GemmTN g{};
+        g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
+        g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
+        launch_gemm_tn(c->stream, c->f32, g);
+    }
+    {
+        Timed tm(c, KC_OTHER);
+        launch_ff_unpack_grads(c->stream, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *cn_version(void) { return "currennt_hip 0.1 (gfx950)"; }
+
+const char *cn_last_error(cn_ctx *) { return g_last_error.c_str(); }
+
+const char *cn_device_arch(cn_ctx *ctx) { return ctx ? ctx->arch.c_str() : ""; }
+
+int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **out)
+{
+    if (!out) { g_last_error = "cn_ctx_create: out is NULL"; return CN_ERR_BAD_ARG; }
+    *out = nullptr;
+    if (precision != CN_PREC_F32 && precision != CN_PREC_BF16) { g_last_error = "cn_ctx_create: unknown precision"; return CN_ERR_BAD_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        g_last_error = "cn_ctx_create: no HIP device available (this library has no CPU fallback)";
+        return CN_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) { g_last_error = "cn_ctx_create: device id out of range"; return CN_ERR_BAD_ARG; }
+    cn_ctx *c = nullptr;
+    int rc = guarded([&] {
+        HIP_CHECK(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+        std::string arch = prop.gcnArchName;
+        if (arch.rfind("gfx950", 0) != 0)
+            throw cn_error(CN_ERR_NO_DEVICE, "cn_ctx_create: device is " + arch + ", this library is built for gfx950 only");
+        c = new cn_ctx;
+        c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
+        if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+        else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        HIP_CHECK(hipMalloc((void **)&c->d_loss, 2 * sizeof(float)));
+    });
+    if (rc != CN_OK) { delete c; return rc; }
+    *out = c;
+    return CN_OK;
+}
+
+int cn_ctx_destroy(cn_ctx *ctx)
+{
+    if (!ctx) return CN_OK;
+    return guarded([&] {
+        hipSetDevice(ctx->device);
+        hipStreamSynchronize(ctx->stream);
+        std::vector<cn_layer *> ls = ctx->layers;
+        for (cn_layer *l : ls) { for (void *p : l->owned) hipFree(p); delete l; }
+        for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+        for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
+        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena);
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        delete ctx;
+    });
+}
+
+int cn_ctx_synchronize(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_ctx_synchronize: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] { HIP_CHECK(hipStreamSynchronize(ctx->stream)); HIP_CHECK(hipGetLastError()); });
+}
+
+// ---------------------------------------------------------------------------------------------
+// layers
+// ---------------------------------------------------------------------------------------------
+int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int size, float bias,
+                    int parallel_sequences, int max_seq_length, cn_layer **out)
+{
+    if (!ctx || !out) { g_last_error = "cn_layer_create: NULL argument"; return CN_ERR_BAD_ARG; }
+    *out = nullptr;
+    cn_layer *l = nullptr;
+    int rc = guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (size <= 0) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: layer size must be positive");
+        if (kind == CN_LAYER_INPUT) {
+            if (preceding) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: the input layer has no preceding layer");
+            if (parallel_sequences <= 0 || max_seq_length <= 0)
+                throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: parallel_sequences and max_seq_length must be positive");
+            if (ctx->PS) throw cn_error(CN_ERR_STATE, "cn_layer_create: this context already has an input layer");
+        } else {
+            if (!preceding) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: preceding layer required");
+            if (preceding->ctx != ctx) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: preceding layer belongs to another context");
+            if (preceding->post) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: a post output layer must be the last layer");
+        }
+        l = new cn_layer;
+        l->ctx = ctx; l->kind = kind; l->prev = preceding; l->size = size; l->bias = bias;
+        l->PS = preceding ? preceding->PS : parallel_sequences;
+        l->maxT = preceding ? preceding->maxT : max_seq_length;
+        const size_t maxN = l->maxN(), e = ctx->esz();
+        if (preceding) { l->P = preceding->size; l->Pp = preceding->Lp; }
+
+        switch (kind) {
+        case CN_LAYER_INPUT: {
+            l->Lp = round_up(size, 32);
+            l->stage_in = (float *)dalloc(l, maxN * size * sizeof(float));
+            l->out_op = dalloc(l, maxN * l->Lp * e);
+            ctx->PS = l->PS; ctx->maxT = l->maxT;
+            HIP_CHECK(hipMalloc((void **)&ctx->d_pat, maxN));
+            HIP_CHECK(hipMalloc((void **)&ctx->d_tcls, maxN * sizeof(int)));
+            HIP_CHECK(hipMemsetAsync(ctx->d_pat, 0, maxN, ctx->stream));
+            break; }
+        case CN_LAYER_LSTM:
+        case CN_LAYER_BLSTM: {
+            if (ctx->finalized) throw cn_error(CN_ERR_STATE, "cn_layer_create: parameter arena already laid out");
+            l->lstm = true; l->trainable = true;
+            l->dirs = (kind == CN_LAYER_BLSTM) ? 2 : 1;
+            if (l->dirs == 2 && size % 2 != 0)
+                throw cn_error(CN_ERR_SHAPE, "Cannot create a bidirectional layer with an odd layer size");   // LstmLayer.cu:528-529
+            l->H = size / l->dirs; l->Hp = pad_units(l->H); l->Lp = l->dirs * l->Hp;
+            const size_t R = (size_t)l->dirs * 4 * l->Hp;
+            l->nw = size * (4 * (l->P + 1) + 4 * l->H + 3);                                            // LstmLayer.cu:525
+            l->out_op = dalloc(l, maxN * l->Lp * e);
+            l->err = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->acts = (float *)dalloc(l, maxN * R * sizeof(float));
+            l->cell = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->delta_op = dalloc(l, maxN * R * e);
+            l->Win = dalloc(l, R * l->Pp * e); l->WinT = dalloc(l, R * l->Pp * e);
+            l->Wrec = dalloc(l, R * l->Hp * e); l->WrecT = dalloc(l, R * l->Hp * e);
+            l->bias_p = (float *)dalloc(l, R * sizeof(float));
+            l->peep_p = (float *)dalloc(l, (size_t)l->dirs * 3 * l->Hp * sizeof(float));
+            l->grad_block_floats = R * l->Pp + R * l->Hp + R + (size_t)l->dirs * 3 * l->Hp;
+            l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
+            l->dWin = l->grad_block; l->dWrec = l->dWin + R * l->Pp; l->dbias = l->dWrec + R * l->Hp; l->dpeep = l->dbias + R;
+            break; }
+        case CN_LAYER_FF_TANH:
+        case CN_LAYER_FF_LOGISTIC:
+        case CN_LAYER_FF_IDENTITY:
+        case CN_LAYER_SOFTMAX: {
+            if (ctx->finalized) throw cn_error(CN_ERR_STATE, "cn_layer_create: parameter arena already laid out");
+            l->trainable = true;
+            l->Lp = round_up(size, 32);
+            l->nw = size * (l->P + 1);                                                                   // FeedForwardLayer.cu:130
+            l->out_f32 = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->out_op = ctx->f32 ? (void *)l->out_f32 : dalloc(l, maxN * l->Lp * e);
+            l->err = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->delta_op = ctx->f32 ? (void *)l->err : dalloc(l, maxN * l->Lp * e);
+            l->Win = dalloc(l, (size_t)l->Lp * l->Pp * e); l->WinT = dalloc(l, (size_t)l->Lp * l->Pp * e);
+            l->bias_p = (float *)dalloc(l, l->Lp * sizeof(float));
+            l->grad_block_floats = (size_t)l->Lp * l->Pp + l->Lp;
+            l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
+            l->dWin = l->grad_block; l->dbias = l->dWin + (size_t)l->Lp * l->Pp;
+            break; }
+        case CN_LAYER_SSE:
+        case CN_LAYER_MULTICLASS_CLASSIFICATION: {
+            if (!preceding->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: a post output layer needs a trainable preceding layer");
+            if (preceding->lstm) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: post output layers directly after an LSTM layer are not supported");
+            if (size != preceding->size)                                                                 // PostOutputLayer.cpp:58-59
+                throw cn_error(CN_ERR_SHAPE, "Size mismatch: " + std::to_string(size) + " vs. " + std::to_string(preceding->size));
+            if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && size == 1)                                  // MulticlassClassificationLayer.cu:146-147
+                throw cn_error(CN_ERR_SHAPE, "The multiclass classification post output layer cannot be used for an output layer size of 1");
+            l->post = true; l->Lp = preceding->Lp;
+            if (kind == CN_LAYER_SSE) l->targets = (float *)dalloc(l, maxN * size * sizeof(float));
+            break; }
+        default:
+            throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: unknown layer kind");
+        }
+        if (preceding && l->trainable) preceding->has_follower = true;
+        ctx->layers.push_back(l);
+    });
+    if (rc != CN_OK) { if (l) { for (void *p : l->owned) hipFree(p); delete l; } return rc; }
+    *out = l;
+    return CN_OK;
+}
+
+int cn_layer_destroy(cn_layer *layer)
+{
+    if (!layer) return CN_OK;
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (void *p : layer->owned) hipFree(p);
+        for (size_t i = 0; i < c->layers.size(); ++i)
+            if (c->layers[i] == layer) { c->layers.erase(c->layers.begin() + i); break; }
+        delete layer;
+    });
+}
+
+int cn_layer_size(const cn_layer *layer) { return layer ? layer->size : CN_ERR_BAD_ARG; }
+int cn_layer_kind_of(const cn_layer *layer) { return layer ? (int)layer->kind : CN_ERR_BAD_ARG; }
+int cn_layer_weight_count(const cn_layer *layer) { return layer ? layer->nw : CN_ERR_BAD_ARG; }
+
+// ---------------------------------------------------------------------------------------------
+// fraction
+// ---------------------------------------------------------------------------------------------
+int cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    if (!ctx || !input || !f) { g_last_error = "cn_fraction_load: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (input->kind != CN_LAYER_INPUT) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `input` is not an input layer");
+        if (f->input_pattern_size != input->size)                                                     // InputLayer.cpp:52-55
+            throw cn_error(CN_ERR_SHAPE, "Input layer size of " + std::to_string(input->size) +
+                           " != data input pattern size of " + std::to_string(f->input_pattern_size));
+        if (post_output) {
+            if (!post_output->post) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `post_output` is not a post output layer");
+            if (f->output_pattern_size != post_output->size)                                          // PostOutputLayer.cpp:70-73
+                throw cn_error(CN_ERR_SHAPE, "Output layer size of " + std::to_string(post_output->size) +
+                               " != data target pattern size of " + std::to_string(f->output_pattern_size));
+        }
+        const int T = f->max_seq_length;
+        if (T <= 0 || T > ctx->maxT) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: max_seq_length " + std::to_string(T) +
+                                                    " outside (0, " + std::to_string(ctx->maxT) + "]");
+        if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
+        if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
+        finalize(ctx);
+        const size_t N = (size_t)T * ctx->PS;
+        Timed tm(ctx, KC_OTHER);
+        HIP_CHECK(hipMemcpyAsync(ctx->d_pat, f->pat_types, N, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(input->stage_in, f->inputs, N * input->size * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if (post_output) {
+            if (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
+                if (!f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
+                HIP_CHECK(hipMemcpyAsync(ctx->d_tcls, f->target_classes, N * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            } else {
+                if (!f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
+                HIP_CHECK(hipMemcpyAsync(post_output->targets, f->targets, N * post_output->size * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+            }
+        }
+        launch_pad_convert(ctx->stream, ctx->f32, input->stage_in, (int)N, input->size, input->out_op, input->Lp);
+        ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->numSeqs = f->num_sequences;
+        ctx->loaded = true;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward / backward / loss
+// ---------------------------------------------------------------------------------------------
+int cn_layer_forward(cn_layer *layer)
+{
+    if (!layer) { g_last_error = "cn_layer_forward: layer is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(layer->ctx->device));
+        require_loaded(layer->ctx);
+        finalize(layer->ctx);
+        if (layer->lstm) lstm_forward(layer);
+        else if (layer->trainable) ff_forward(layer);
+        /* input and post output layers: no-op (InputLayer.cpp:62-65, SsePostOutputLayer.cu:134-137) */
+    });
+}
+
+int cn_layer_backward(cn_layer *layer)
+{
+    if (!layer) { g_last_error = "cn_layer_backward: layer is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        require_loaded(c);
+        finalize(c);
+        if (layer->lstm) lstm_backward(layer);
+        else if (layer->trainable) ff_backward(layer);
+        else if (layer->post) {
+            Timed tm(c, KC_OTHER);
+            cn_layer *o = layer->prev;
+            if (layer->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
+                launch_mcc_backward(c->stream, o->out_f32, c->d_tcls, c->N, layer->size, o->Lp, o->err);
+            else
+                launch_sse_backward(c->stream, o->out_f32, layer->targets, c->d_pat, c->N, layer->size, o->Lp, o->err);
+        }
+    });
+}
+
+int cn_loss_eval(cn_layer *post, float *error, int *correct)
+{
+    if (!post || !error) { g_last_error = "cn_loss_eval: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = post->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        if (!post->post) throw cn_error(CN_ERR_BAD_ARG, "cn_loss_eval: not a post output layer");
+        require_loaded(c);
+        cn_layer *o = post->prev;
+        {
+            Timed tm(c, KC_OTHER);
+            if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
+                launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss);
+            else
+                launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss);
+        }
+        float h[2];
+        HIP_CHECK(hipMemcpyAsync(h, c->d_loss, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        *error = h[0];
+        if (correct) {
+            int cc; memcpy(&cc, &h[1], sizeof(int));
+            *correct = (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) ? cc : -1;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights and buffers
+// ---------------------------------------------------------------------------------------------
+int cn_layer_set_weights(cn_layer *layer, const float *host, int count)
+{
+    if (!layer || !host) { g_last_error = "cn_layer_set_weights: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_set_weights: layer has no weights");
+        if (count != layer->nw)
+            throw cn_error(CN_ERR_SHAPE, "Invalid number of weights: " + std::to_string(count) + " given, " + std::to_string(layer->nw) + " expected");
+        if (!c->finalized) { layer->pending_w.assign(host, host + count); return; }
+        HIP_CHECK(hipMemcpyAsync(layer->w, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        layer->dirty = true;
+    });
+}
+
+int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t count)
+{
+    if (!layer || !host) { g_last_error = "cn_layer_write_output_errors: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        require_loaded(c);
+        if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_write_output_errors: layer has no outputErrors");
+        if (count != (size_t)c->N * layer->size) throw cn_error(CN_ERR_SHAPE, "cn_layer_write_output_errors: count != T*PS*size");
+        float *tmp = nullptr;
+        HIP_CHECK(hipMalloc((void **)&tmp, count * sizeof(float)));
+        HIP_CHECK(hipMemcpyAsync(tmp, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemsetAsync(layer->err, 0, (size_t)c->N * layer->Lp * sizeof(float), c->stream));
+        launch_pad_f32(c->stream, tmp, c->N, layer->size, layer->err, layer->Lp, layer->lstm ? layer->H : 0, layer->lstm ? layer->Hp : 0);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        hipFree(tmp);
+    });
+}
+
+int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t count)
+{
+    if (!layer || !host) { g_last_error = "cn_layer_read: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        finalize(c);
+        const size_t e = c->esz();
+        const bool opbf = !c->f32;
+        // flat parameter vectors
+        if (which == CN_BUF_WEIGHTS || which == CN_BUF_WEIGHT_UPDATES || which == CN_BUF_WEIGHT_DELTAS) {
+            if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no weights");
+            if (count != (size_t)layer->nw) throw cn_error(CN_ERR_SHAPE, "cn_layer_read: count != weight count");
+            const float *src = which == CN_BUF_WEIGHTS ? layer->w : (which == CN_BUF_WEIGHT_UPDATES ? layer->wu : layer->wd);
+            HIP_CHECK(hipMemcpyAsync(host, src, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+            return;
+        }
+        require_loaded(c);
+        const int N = c->N;
+        int width = layer->size;
+        if (which >= CN_BUF_LSTM_CELL_STATES) {
+            if (!layer->lstm) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: not an LSTM layer");
+            if (dir < 0 || dir >= layer->dirs) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: direction out of range");
+            width = layer->H;
+        }
+        if (count != (size_t)N * width) throw cn_error(CN_ERR_SHAPE, "cn_layer_read: count != T*PS*width");
+        float *tmp = nullptr;
+        HIP_CHECK(hipMalloc((void **)&tmp, count * sizeof(float)));
+        const int R = layer->dirs * 4 * layer->Hp, Hp = layer->Hp, H = layer->H;
+        switch (which) {
+        case CN_BUF_OUTPUTS:
+            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, N, layer->size, tmp, layer->size, 0);
+            else if (layer->lstm)
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, N, H, tmp, layer->size, d * H);
+            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, N, layer->size, tmp, layer->size, 0);
+            else throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputs");
+            break;
+        case CN_BUF_OUTPUT_ERRORS:
+            if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputErrors");
+            if (layer->lstm)
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, N, H, tmp, layer->size, d * H);
+            else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, N, layer->size, tmp, layer->size, 0);
+            break;
+        case CN_BUF_LSTM_CELL_STATES:
+            launch_unpad(c->stream, false, layer->cell, layer->Lp, dir * Hp, N, H, tmp, H, 0); break;
+        case CN_BUF_LSTM_TMP_OUTPUTS:
+            launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, dir * Hp, N, H, tmp, H, 0); break;
+        case CN_BUF_LSTM_NI_ACTS: case CN_BUF_LSTM_IG_ACTS: case CN_BUF_LSTM_FG_ACTS: case CN_BUF_LSTM_OG_ACTS:
+            launch_unpad(c->stream, false, layer->acts, R, (dir * 4 + (which - CN_BUF_LSTM_NI_ACTS)) * Hp, N, H, tmp, H, 0); break;
+        case CN_BUF_LSTM_NI_DELTAS: case CN_BUF_LSTM_IG_DELTAS: case CN_BUF_LSTM_FG_DELTAS: case CN_BUF_LSTM_OG_DELTAS:
+            launch_unpad(c->stream, opbf, layer->delta_op, R, (dir * 4 + (which - CN_BUF_LSTM_NI_DELTAS)) * Hp, N, H, tmp, H, 0); break;
+        default:
+            hipFree(tmp);
+            throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: unknown buffer");
+        }
+        (void)e;
+        HIP_CHECK(hipMemcpyAsync(host, tmp, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        hipFree(tmp);
+    });
+}
+
+void *cn_layer_device_ptr(cn_layer *layer, cn_buffer which)
+{
+    if (!layer || !layer->trainable) return nullptr;
+    if (guarded([&] { HIP_CHECK(hipSetDevice(layer->ctx->device)); finalize(layer->ctx); }) != CN_OK) return nullptr;
+    switch (which) {
+    case CN_BUF_WEIGHTS: return layer->w;
+    case CN_BUF_WEIGHT_UPDATES: return layer->wu;
+    case CN_BUF_WEIGHT_DELTAS: return layer->wd;
+    default: return nullptr;
+    }
+}
+
+int cn_ctx_param_arena(cn_ctx *ctx, void **weights, void **weight_updates, void **weight_deltas, size_t *count)
+{
+    if (!ctx) { g_last_error = "cn_ctx_param_arena: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        finalize(ctx);
+        if (weights) *weights = ctx->arena;
+        if (weight_updates) *weight_updates = ctx->arena + ctx->total;
+        if (weight_deltas) *weight_deltas = ctx->arena + 2 * ctx->total;
+        if (count) *count = ctx->total;
+    });
+}
+
+int cn_ctx_weights_touched(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_ctx_weights_touched: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
+    return CN_OK;
+}
+
+int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
+{
+    if (!layer) { g_last_error = "cn_sgd_update: layer is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_sgd_update: layer has no weights");
+        finalize(c);
+        Timed tm(c, KC_OTHER);
+        launch_sgd(c->stream, layer->w, layer->wu, layer->wd, (size_t)layer->nw, learning_rate, momentum);
+        layer->dirty = true;
+    });
+}
+
+int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
+{
+    if (!ctx) { g_last_error = "cn_sgd_update_all: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        finalize(ctx);
+        Timed tm(ctx, KC_OTHER);
+        launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum);
+        for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------------------------
+int cn_ctx_timing_enable(cn_ctx *ctx, int enable)
+{
+    if (!ctx) { g_last_error = "cn_ctx_timing_enable: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); timing_collect(ctx); ctx->timing = enable != 0; });
+}
+int cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, long *launches)
+{
+    if (!ctx || kernel_class < 0 || kernel_class >= KC_COUNT) { g_last_error = "cn_ctx_timing_read: bad argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        timing_collect(ctx);
+        if (total_ms) *total_ms = ctx->acc_ms[kernel_class];
+        if (launches) *launches = ctx->acc_n[kernel_class];
+    });
+}
+int cn_ctx_timing_reset(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_ctx_timing_reset: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        timing_collect(ctx);
+        for (int k = 0; k < KC_COUNT; ++k) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }
+    });
+}
+
+}  // extern "C"

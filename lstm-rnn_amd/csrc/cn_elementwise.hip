@@ -1,0 +1,475 @@
+// Bandwidth-bound helper kernels around the GEMMs and the recurrent kernels: weight packing,
+// gradient unpacking, softmax / loss rows, optimizer step, layout conversion.  gfx950 only.
+//
+// Reference functors restated here (currennt_lib/src):
+//   layers/FeedForwardLayer.cu:69-80   ComputeDeltaFn            -> ff_delta_kernel
+//   layers/FeedForwardLayer.cu:82-102  ComputeBiasWeightUpdateFn -> colsum_kernel
+//   layers/SoftmaxLayer.cu:45-160      offset/exp/sum/normalise  -> softmax_fwd_kernel (one pass)
+//   layers/SoftmaxLayer.cu:162-219     error offset / errors     -> softmax_bwd_kernel (one pass)
+//   layers/MulticlassClassificationLayer.cu:48-135               -> mcc_rows_kernel, mcc_backward_kernel
+//   layers/SsePostOutputLayer.cu:39-88                           -> sse_rows_kernel, sse_backward_kernel
+//   optimizers/SteepestDescentOptimizer.cu:39-59 UpdateWeightFn  -> sgd_kernel
+#include "cn_internal.h"
+
+#include <float.h>
+
+namespace cn {
+
+#define NL_MIN 1.1754944e-038f
+#define NL_MAX 3.4028235e+038f
+#define NL_EXPLIMIT 88.722839f
+#define NL_LOGZERO (-1e30f)
+
+template <bool F32> __device__ __forceinline__ void st_op(void *base, long idx, float v)
+{
+    if constexpr (F32) ((float *)base)[idx] = v; else ((__bf16 *)base)[idx] = (__bf16)v;
+}
+
+// reference feature index of a padded column of the preceding layer's output, -1 for padding.
+// An LSTM layer stores direction d at columns [d*Hp, d*Hp+H); every other layer is dense.
+__device__ __forceinline__ int unpad_col(int pc, int P, int prevH, int prevHp, int prevDirs)
+{
+    if (prevH == 0) return pc < P ? pc : -1;
+    int dd = pc / prevHp, jj = pc % prevHp;
+    return (dd < prevDirs && jj < prevH) ? dd * prevH + jj : -1;
+}
+__device__ __forceinline__ int pad_col(int i, int prevH, int prevHp)
+{
+    if (prevH == 0) return i;
+    return (i / prevH) * prevHp + (i % prevH);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LSTM weight packing (flat layout: LstmLayer.hpp:36-55, LstmLayer.cu:535-541,583-596)
+// ---------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *Win, void *WinT,
+                                 void *Wrec, void *WrecT, float *bias_p, float *peep_p)
+{
+    const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp, dirs = g.dirs;
+    const long R = (long)dirs * 4 * Hp;                 // packed gate rows
+    const long nIn = R * Pp, nRec = (long)dirs * 4 * Hp * Hp, nB = (long)dirs * 4 * Hp, nPe = (long)dirs * 3 * Hp;
+    const long total = nIn + nRec + nB + nPe;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < nIn) {
+            const int r = idx / Pp, pc = idx % Pp;
+            const int d = r / (4 * Hp), gg = (r / Hp) % 4, j = r % Hp;
+            const int i = unpad_col(pc, P, g.prevH, g.prevHp, g.prevDirs);
+            float v = 0.f;
+            if (j < H && i >= 0) v = w[(long)gg * L * P + (long)d * H * P + (long)j * P + i];
+            st_op<F32>(Win, (long)r * Pp + pc, v);
+            st_op<F32>(WinT, (long)pc * R + r, v);
+        } else if (idx < nIn + nRec) {
+            const long k = idx - nIn;
+            const int d = k / (4L * Hp * Hp), rem = k % (4L * Hp * Hp);
+            const int gg = rem / (Hp * Hp), j = (rem / Hp) % Hp, i = rem % Hp;
+            float v = 0.f;
+            if (j < H && i < H)
+                v = w[4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i];
+            st_op<F32>(Wrec, ((long)d * 4 * Hp + gg * Hp + j) * Hp + i, v);
+            st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + gg * Hp + j, v);
+        } else if (idx < nIn + nRec + nB) {
+            const int k = idx - nIn - nRec;
+            const int d = k / (4 * Hp), gg = (k / Hp) % 4, j = k % Hp;
+            bias_p[k] = (j < H) ? bias * w[4L * L * P + gg * L + d * H + j] : 0.f;   // LstmLayer.cu:97-100
+        } else {
+            const int k = idx - nIn - nRec - nB;
+            const int d = k / (3 * Hp), pp = (k / Hp) % 3, j = k % Hp;
+            peep_p[k] = (j < H) ? w[4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j] : 0.f;
+        }
+    }
+}
+
+void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, const float *w,
+                      void *Win, void *WinT, void *Wrec, void *WrecT, float *bias_p, float *peep_p)
+{
+    long total = (long)g.dirs * 4 * g.Hp * (g.Pp + g.Hp + 1) + (long)g.dirs * 3 * g.Hp;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    if (f32) hipLaunchKernelGGL(lstm_pack_kernel<true>, dim3(blocks), dim3(256), 0, s, g, bias, w, Win, WinT, Wrec, WrecT, bias_p, peep_p);
+    else     hipLaunchKernelGGL(lstm_pack_kernel<false>, dim3(blocks), dim3(256), 0, s, g, bias, w, Win, WinT, Wrec, WrecT, bias_p, peep_p);
+}
+
+// packed fp32 gradients -> flat weightUpdates (same layout as the weights, LstmLayer.cu:577-581)
+__global__ void lstm_unpack_kernel(LstmGeom g, const float *dWin, const float *dWrec, const float *dbias,
+                                   const float *dpeep, float *wu)
+{
+    const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp;
+    const long nIn = 4L * L * P, nB = 4L * L, nRec = 4L * L * H, nPe = 3L * L;
+    const long total = nIn + nB + nRec + nPe;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        float v;
+        if (idx < nIn) {
+            const int gg = idx / ((long)L * P), rem = idx % ((long)L * P);
+            const int blk = rem / P, i = rem % P, d = blk / H, j = blk % H;
+            v = dWin[((long)(d * 4 + gg) * Hp + j) * Pp + pad_col(i, g.prevH, g.prevHp)];
+        } else if (idx < nIn + nB) {
+            const int k = idx - nIn, gg = k / L, blk = k % L, d = blk / H, j = blk % H;
+            v = dbias[(d * 4 + gg) * Hp + j];
+        } else if (idx < nIn + nB + nRec) {
+            const long k = idx - nIn - nB;
+            const int gg = k / ((long)L * H), rem = k % ((long)L * H);
+            const int blk = rem / H, i = rem % H, d = blk / H, j = blk % H;
+            v = dWrec[((long)d * 4 * Hp + gg * Hp + j) * Hp + i];
+        } else {
+            const int k = idx - nIn - nB - nRec, pp = k / L, blk = k % L, d = blk / H, j = blk % H;
+            v = dpeep[(d * 3 + pp) * Hp + j];
+        }
+        wu[idx] = v;
+    }
+}
+
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, const float *dWin, const float *dWrec,
+                              const float *dbias, const float *dpeep, float *wu)
+{
+    long total = (long)g.L * (4 * (g.P + 1) + 4 * g.H + 3);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, s, g, dWin, dWrec, dbias, dpeep, wu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// feed-forward weight packing (flat layout: [j][i] P x L column-major then L bias weights,
+// FeedForwardLayer.cu:148,160)
+// ---------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ void ff_pack_kernel(FfGeom g, float bias, const float *w, void *W, void *WT, float *bias_p)
+{
+    const long nW = (long)g.Lp * g.Pp, total = nW + g.Lp;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < nW) {
+            const int j = idx / g.Pp, pc = idx % g.Pp;
+            const int i = unpad_col(pc, g.P, g.prevH, g.prevHp, g.prevDirs);
+            float v = (j < g.L && i >= 0) ? w[(long)j * g.P + i] : 0.f;
+            st_op<F32>(W, (long)j * g.Pp + pc, v);
+            st_op<F32>(WT, (long)pc * g.Lp + j, v);
+        } else {
+            const int j = idx - nW;
+            bias_p[j] = (j < g.L) ? bias * w[(long)g.L * g.P + j] : 0.f;            // FeedForwardLayer.cu:59
+        }
+    }
+}
+void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p)
+{
+    long total = (long)g.Lp * g.Pp + g.Lp;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    if (f32) hipLaunchKernelGGL(ff_pack_kernel<true>, dim3(blocks), dim3(256), 0, s, g, bias, w, W, WT, bias_p);
+    else     hipLaunchKernelGGL(ff_pack_kernel<false>, dim3(blocks), dim3(256), 0, s, g, bias, w, W, WT, bias_p);
+}
+
+__global__ void ff_unpack_kernel(FfGeom g, float bias, const float *dW, const float *colsum, float *wu)
+{
+    const long nW = (long)g.L * g.P, total = nW + g.L;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (idx < nW) {
+            const int j = idx / g.P, i = idx % g.P;
+            wu[idx] = dW[(long)j * g.Pp + pad_col(i, g.prevH, g.prevHp)];
+        } else {
+            wu[idx] = bias * colsum[idx - nW];                                     // FeedForwardLayer.cu:94-100
+        }
+    }
+}
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, const float *dW, const float *colsum, float *wu)
+{
+    long total = (long)g.L * (g.P + 1);
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ff_unpack_kernel, dim3(blocks), dim3(256), 0, s, g, bias, dW, colsum, wu);
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion
+// ---------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ void pad_convert_kernel(const float *src, int N, int P, void *dst, int Pp)
+{
+    const long total = (long)N * Pp;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / Pp; const int c = idx % Pp;
+        st_op<F32>(dst, idx, c < P ? src[n * P + c] : 0.f);
+    }
+}
+void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P, void *dst, int Pp)
+{
+    long total = (long)N * Pp; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (f32) hipLaunchKernelGGL(pad_convert_kernel<true>, dim3(blocks), dim3(256), 0, s, src, N, P, dst, Pp);
+    else     hipLaunchKernelGGL(pad_convert_kernel<false>, dim3(blocks), dim3(256), 0, s, src, N, P, dst, Pp);
+}
+
+template <bool BF16>
+__global__ void unpad_kernel(const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0)
+{
+    const long total = (long)N * L;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / L; const int j = idx % L;
+        float v;
+        if constexpr (BF16) v = (float)((const __bf16 *)src)[n * ld + col0 + j];
+        else v = ((const float *)src)[n * ld + col0 + j];
+        dst[n * ldd + dcol0 + j] = v;
+    }
+}
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0)
+{
+    long total = (long)N * L; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (src_is_bf16) hipLaunchKernelGGL(unpad_kernel<true>, dim3(blocks), dim3(256), 0, s, src, ld, col0, N, L, dst, ldd, dcol0);
+    else             hipLaunchKernelGGL(unpad_kernel<false>, dim3(blocks), dim3(256), 0, s, src, ld, col0, N, L, dst, ldd, dcol0);
+}
+
+__global__ void pad_f32_kernel(const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp)
+{
+    const long total = (long)N * L;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / L; const int j = idx % L;
+        dst[n * ld + pad_col(j, prevH, prevHp)] = src[idx];
+    }
+}
+void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp)
+{
+    long total = (long)N * L; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pad_f32_kernel, dim3(blocks), dim3(256), 0, s, src, N, L, dst, ld, prevH, prevHp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// feed-forward delta and bias gradient
+// ---------------------------------------------------------------------------------------------
+template <bool F32>
+__global__ void ff_delta_kernel(int act, const float *y, float *err, void *delta_op, int N, int L, int Lp)
+{
+    const long total = (long)N * Lp;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = idx % Lp;
+        float dl = 0.f;
+        if (j < L) {
+            const float yy = y[idx], e = err[idx];
+            float dv = 1.0f;                                         // Identity.cuh:38-41
+            if (act == ACT_TANH) dv = 1.0f - yy * yy;                // Tanh.cuh:38-41
+            else if (act == ACT_LOGISTIC) dv = yy * (1.0f - yy);     // Logistic.cuh:46-49
+            dl = dv * e;
+        }
+        err[idx] = dl;
+        st_op<F32>(delta_op, idx, dl);
+    }
+}
+void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *err, void *delta_op, int N, int L, int Lp)
+{
+    long total = (long)N * Lp; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    if (f32) hipLaunchKernelGGL(ff_delta_kernel<true>, dim3(blocks), dim3(256), 0, s, act, y, err, delta_op, N, L, Lp);
+    else     hipLaunchKernelGGL(ff_delta_kernel<false>, dim3(blocks), dim3(256), 0, s, act, y, err, delta_op, N, L, Lp);
+}
+
+// colsum[j] += sum_n err[n][j]; block = 256 threads = 8 row lanes x 32 columns, rows strided over the grid
+__global__ void colsum_kernel(const float *err, int N, int Lp, float *colsum)
+{
+    __shared__ float part[8][33];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    for (int c0 = 0; c0 < Lp; c0 += 32) {
+        float sacc = 0.f;
+        for (long n = (long)blockIdx.x * 8 + ry; n < N; n += (long)gridDim.x * 8) sacc += err[n * Lp + c0 + cx];
+        part[ry][cx] = sacc;
+        __syncthreads();
+        if (ry == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t += part[r][cx];
+            atomicAdd(&colsum[c0 + cx], t);
+        }
+        __syncthreads();
+    }
+}
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum)
+{
+    if (N <= 0) return;
+    int blocks = (N + 63) / 64; if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, err, N, Lp, colsum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax rows: one 64-lane wave per pattern
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float safe_exp(float x)      // helpers/safeExp.cuh:31-40
+{
+    if (x <= NL_LOGZERO) return 0.f;
+    if (x >= NL_EXPLIMIT) return NL_MAX;
+    return expf(x);
+}
+
+__global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int Lp)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    if (pat[row] == 0) return;                           // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+    float *r = y + row * Lp;
+    float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
+    for (int j = lane; j < L; j += 64) { float v = r[j]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
+    mx = wave_max(mx); mn = wave_min(mn);
+    const float offset = 0.5f * (mn + mx);               // :74
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) { float x = safe_exp(r[j] - offset); r[j] = x; sum += x; }
+    sum = wave_sum(sum);
+    for (int j = lane; j < L; j += 64) r[j] = r[j] / sum; // :152
+}
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp)
+{
+    if (N <= 0) return;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp);
+}
+
+__global__ void softmax_bwd_kernel(const float *y, float *err, const char *pat, int N, int L, int Lp)
+{
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= N) return;
+    if (pat[row] == 0) return;                           // SoftmaxLayer.cu:175-176
+    const float *yr = y + row * Lp; float *er = err + row * Lp;
+    float off = 0.f;
+    for (int j = lane; j < L; j += 64) off += yr[j] * er[j];   // :183-185
+    off = wave_sum(off);
+    for (int j = lane; j < L; j += 64) er[j] = yr[j] * (er[j] - off);  // :214
+}
+void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp)
+{
+    if (N <= 0) return;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, err, pat, N, L, Lp);
+}
+
+// ---------------------------------------------------------------------------------------------
+// post output layers.  loss2[0] = error (float), loss2[1] = #correct (int bits), both accumulated
+// with one atomic per workgroup after a fixed-order in-block reduction.
+// ---------------------------------------------------------------------------------------------
+__global__ void mcc_rows_kernel(const float *y, const int *tcls, int N, int L, int Lp, float *loss2)
+{
+    __shared__ float sl[4]; __shared__ int sc[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float lsum = 0.f; int csum = 0;
+    for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
+        const int tc = tcls[row];
+        if (tc < 0) continue;                                     // MulticlassClassificationLayer.cu:61-62
+        const float *r = y + row * Lp;
+        // CountCorrectClassificationsFn :89-99: first strictly greater value wins, start (0, class 0)
+        float best = 0.f; int bi = 0;
+        for (int j = lane; j < L; j += 64) { float v = r[j]; if (v > best) { best = v; bi = j; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (best <= 0.f) bi = 0;
+        if (lane == 0) {
+            lsum += logf(fmaxf(NL_MIN, r[tc]));                   // :65-66
+            csum += (bi == tc) ? 1 : 0;
+        }
+    }
+    if (lane == 0) { sl[wv] = lsum; sc[wv] = csum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = (sl[0] + sl[1]) + (sl[2] + sl[3]);
+        int c = sc[0] + sc[1] + sc[2] + sc[3];
+        atomicAdd(&loss2[0], -t);                                 // calculateError returns -sum, :212
+        atomicAdd((int *)&loss2[1], c);
+    }
+}
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2)
+{
+    hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+    if (N <= 0) return;
+    int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mcc_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, loss2);
+}
+
+__global__ void mcc_backward_kernel(const float *y, const int *tcls, int N, int L, int Lp, float *err)
+{
+    const long total = (long)N * Lp;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / Lp; const int j = idx % Lp;
+        float v = 0.f;                                            // fill_n 0, :227
+        if (j < L && tcls[n] == j) v = -(1.0f / fmaxf(NL_MIN, y[idx]));   // :128-130
+        err[idx] = v;
+    }
+}
+void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err)
+{
+    long total = (long)N * Lp; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(mcc_backward_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, err);
+}
+
+__global__ void sse_rows_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2)
+{
+    __shared__ float sl[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float lsum = 0.f;
+    for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
+        if (pat[row] == 0) continue;                              // SsePostOutputLayer.cu:53-54
+        float a = 0.f;
+        for (int j = lane; j < L; j += 64) { float df = tgt[row * L + j] - y[row * Lp + j]; a += df * df; }
+        lsum += wave_sum(a);
+    }
+    if (lane == 0) sl[wv] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&loss2[0], 0.5f * ((sl[0] + sl[1]) + (sl[2] + sl[3])));   // :121
+}
+void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2)
+{
+    hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+    if (N <= 0) return;
+    int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sse_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, loss2);
+}
+
+__global__ void sse_backward_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
+{
+    const long total = (long)N * Lp;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long n = idx / Lp; const int j = idx % Lp;
+        float v = 0.f;
+        if (j < L && pat[n] != 0) v = y[idx] - tgt[n * L + j];    // SsePostOutputLayer.cu:79-86
+        err[idx] = v;
+    }
+}
+void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
+{
+    long total = (long)N * Lp; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sse_backward_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer step
+// ---------------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float *w, const float *wu, float *wd, size_t n, float lr, float mom)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        // separate multiplies and adds (no FMA contraction) so that equal gradients give bit-equal weights
+        const float dl = __fsub_rn(__fmul_rn(mom, wd[i]), __fmul_rn(lr, wu[i]));   // SteepestDescentOptimizer.cu:51
+        wd[i] = dl;
+        w[i] = __fadd_rn(w[i], dl);                               // :55
+    }
+}
+void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom)
+{
+    if (n == 0) return;
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, s, w, wu, wd, n, lr, mom);
+}
+
+}  // namespace cn

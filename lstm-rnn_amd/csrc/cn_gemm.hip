@@ -1,0 +1,327 @@
+// MFMA GEMM kernels for the N-wide gate products and the weight-gradient products.
+//
+// Replaces helpers::Matrix<TDevice>::assignProduct/addProduct (helpers/Matrix.cu:218-349, Cpu
+// functors :41-183) and helpers::cublas::multiplyMatrices (helpers/cublas.cu:52-84) at the call
+// sites LstmLayer.cu:774-785 (K1), :996-1006 (K8), the GEMM parts of ComputeWeightUpdateFn
+// :289-512 (K9), and FeedForwardLayer.cu:148-152,190-197,202-206 (K10,K13,K14).
+//
+// gfx950 only.  Two kernels:
+//   gemm_nt : C[m][n]  = sum_k A[m][k] B[n][k]   both operands K-contiguous (activations x packed
+//             weights).  128x128 tile, 4 waves of 64x64 (2x2 v_mfma 32x32), 128 bytes of K per
+//             LDS row (+16 pad -> conflict-free ds_read_b128), register-staged double buffering.
+//   gemm_tn : C[m][n] += sum_k A[k][m] B[k][n]   the reduction runs over frames (K = T*PS), so the
+//             operands arrive K-strided; tiles are kept K-major in LDS and the bf16 fragments are
+//             read with ds_read_b64_tr_b16 (hardware transpose), fp32 ones with ds_read_b32.
+//             Split-K over frames, fp32 atomics into the pre-zeroed gradient.
+// Operand type: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32).
+#include "cn_internal.h"
+
+namespace cn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ float act_apply(int act, float x)
+{
+    // activation_functions/Logistic.cuh:33-44, Tanh.cuh:33-36 (tanh(x) = 2*logistic(2x) - 1)
+    if (act == ACT_IDENTITY) return x;
+    float z = (act == ACT_TANH) ? 2.0f * x : x;
+    float s;
+    if (z < 88.722839f) s = (z > -88.722839f) ? 1.0f / (1.0f + __expf(-z)) : 0.0f;
+    else s = 1.0f;
+    return (act == ACT_TANH) ? 2.0f * s - 1.0f : s;
+}
+
+// one K-group (32 bytes of K per row: 16 bf16 or 8 fp32) of a 32x32 tile product
+template <bool F32>
+__device__ __forceinline__ void mma32(f32x16 &acc, const u32x4 &a, const u32x4 &b)
+{
+    if constexpr (F32) {
+        // K order inside the group is permuted identically for A and B (lane half h holds
+        // k = 4h..4h+3), which leaves the dot product unchanged.
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[i]),
+                                                       __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_nt
+// ---------------------------------------------------------------------------------------------
+constexpr int NT_BM = 128, NT_BN = 128, NT_ROWB = 128, NT_PITCH = 144;
+constexpr int NT_TILE_BYTES = NT_BM * NT_PITCH;           // one operand tile
+constexpr int NT_LDS_BYTES = 4 * NT_TILE_BYTES;           // (A,B) x 2 buffers = 73728
+
+template <bool F32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int nwg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ELT = F32 ? 4 : 2;
+    constexpr int KB = NT_ROWB / ELT;          // k elements per tile row
+    constexpr int CH = 16 / ELT;               // k elements per 16-byte chunk
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
+    // run of tiles so the N-tiles of one A panel hit the same L2 (bijective remap).
+    int bid = blockIdx.x;
+    {
+        int q = nwg / 8, r = nwg % 8, x = bid % 8;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+
+    const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
+    const int nk = (p.K + KB - 1) / KB;
+
+    u32x4 ra[4], rb[4];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = tid + 256 * j, row = c >> 3, kc = c & 7;
+            int k = kt * KB + kc * CH;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            ra[j] = z; rb[j] = z;
+            if (k < p.K) {
+                if (m0 + row < p.M) ra[j] = *(const u32x4 *)(Ab + ((long)(m0 + row) * p.lda + k) * ELT);
+                if (n0 + row < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)(n0 + row) * p.ldb + k) * ELT);
+            }
+        }
+    };
+    auto lwrite = [&](int buf) {
+        char *sa = smem + buf * 2 * NT_TILE_BYTES, *sb = sa + NT_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = tid + 256 * j, row = c >> 3, kc = c & 7;
+            *(u32x4 *)(sa + row * NT_PITCH + kc * 16) = ra[j];
+            *(u32x4 *)(sb + row * NT_PITCH + kc * 16) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char *sa = smem + (kt & 1) * 2 * NT_TILE_BYTES, *sb = sa + NT_TILE_BYTES;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+                b[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma32<F32>(acc[i][j], a[i], b[j]);
+        }
+        if (kt + 1 < nk) lwrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= p.M) continue;
+                float v = act_apply(p.act, acc[i][j][r] + bv);
+                if (p.C) p.C[(long)m * p.ldc + n] = v;
+                if (p.C2) {
+                    if constexpr (F32) ((float *)p.C2)[(long)m * p.ldc2 + n] = v;
+                    else ((__bf16 *)p.C2)[(long)m * p.ldc2 + n] = (__bf16)v;
+                }
+            }
+        }
+    }
+}
+
+void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
+{
+    if (g.M <= 0 || g.N <= 0) return;
+    int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
+    int nwg = tiles_m * tiles_n;
+    if (f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
+    else     hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_tn
+// ---------------------------------------------------------------------------------------------
+constexpr int TN_BM = 128, TN_BN = 128, TN_BK = 32;
+template <bool F32> struct TnGeom {
+    static constexpr int ELT = F32 ? 4 : 2;
+    static constexpr int PITCH = TN_BM * ELT + 64;         // bf16: 320 B, f32: 576 B
+    static constexpr int TILE = TN_BK * PITCH;
+    static constexpr int LDS = 4 * TILE;                   // (A,B) x 2 buffers
+    static constexpr int CPR = TN_BM * ELT / 16;           // 16-byte chunks per tile row (16 / 32)
+    static constexpr int NLD = TN_BK * CPR / 256;          // chunks per thread per operand (2 / 4)
+};
+
+template <bool F32>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int ntiles, int kchunk)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = TnGeom<F32>;
+    constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD;
+    constexpr int CH = 16 / ELT;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const int m0 = (tile / tiles_n) * TN_BM, n0 = (tile % tiles_n) * TN_BN;
+    const int kbeg = split * kchunk;
+    const int kend = min(p.K, kbeg + kchunk);
+    if (kbeg >= kend) return;
+    const int nk = (kend - kbeg + TN_BK - 1) / TN_BK;
+
+    const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
+    u32x4 ra[NLD], rb[NLD];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
+            int k = kbeg + kt * TN_BK + kr;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            ra[j] = z; rb[j] = z;
+            if (k < kend) {
+                if (m0 + cc * CH < p.M) ra[j] = *(const u32x4 *)(Ab + ((long)k * p.lda + m0 + cc * CH) * ELT);
+                if (n0 + cc * CH < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)k * p.ldb + n0 + cc * CH) * ELT);
+            }
+        }
+    };
+    auto lwrite = [&](int buf) {
+        char *sa = smem + buf * 2 * TILE, *sb = sa + TILE;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
+            *(u32x4 *)(sa + kr * PITCH + cc * 16) = ra[j];
+            *(u32x4 *)(sb + kr * PITCH + cc * 16) = rb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char *sa = smem + (kt & 1) * 2 * TILE, *sb = sa + TILE;
+        if constexpr (F32) {
+            // v_mfma_f32_32x32x2_f32: lane (r,h) holds A[m=r][k=2s+h] / B[k=2s+h][n=r]
+#pragma unroll 4
+            for (int s2 = 0; s2 < TN_BK / 2; ++s2) {
+                float a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = *(const float *)(sa + (2 * s2 + fh) * PITCH + (wm * 64 + i * 32 + fr) * 4);
+                    b[i] = *(const float *)(sb + (2 * s2 + fh) * PITCH + (wn * 64 + i * 32 + fr) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(m) block, lane 4q+p supplies the
+            // address of row q, columns 4p..4p+3, lane i receives column i of the 4 rows.
+            const int g16 = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
+#pragma unroll
+            for (int ks = 0; ks < TN_BK / 16; ++ks) {
+                bf16x8 a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        int k = ks * 16 + 8 * (g16 >> 1) + 4 * jj + q;
+                        int ma = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                        int nb = wn * 64 + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                        s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3))) *)(sa + k * PITCH + ma * 2));
+                        s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (s16x4 __attribute__((address_space(3))) *)(sb + k * PITCH + nb * 2));
+                        bf16x4 ta = __builtin_bit_cast(bf16x4, va), tb = __builtin_bit_cast(bf16x4, vb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[i][4 * jj + e] = ta[e]; b[i][4 * jj + e] = tb[e]; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) lwrite((kt + 1) & 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fr;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (m >= p.M) continue;
+                atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
+            }
+        }
+    }
+}
+
+void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
+{
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+    int tiles_m = (g.M + TN_BM - 1) / TN_BM, tiles_n = (g.N + TN_BN - 1) / TN_BN;
+    int ntiles = tiles_m * tiles_n;
+    // enough K splits to fill the 256 CUs a few times over, each at least 4 K-tiles deep
+    int want = (1024 + ntiles - 1) / ntiles;
+    int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
+    int splits = want < maxsplit ? want : maxsplit;
+    if (splits < 1) splits = 1;
+    int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
+    splits = (g.K + kchunk - 1) / kchunk;
+    if (f32) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(ntiles * splits), dim3(256), TnGeom<true>::LDS, s, g, tiles_n, ntiles, kchunk);
+    else     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(ntiles * splits), dim3(256), TnGeom<false>::LDS, s, g, tiles_n, ntiles, kchunk);
+}
+
+}  // namespace cn

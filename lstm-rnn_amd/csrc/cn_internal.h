@@ -1,0 +1,99 @@
+// Internal declarations shared by the translation units of libcurrennt_hip.so.
+// Nothing in here is part of the ABI (include/currennt_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/currennt_hip.h"
+
+namespace cn {
+
+// ---- activation ids used by kernels --------------------------------------------------------
+enum Act { ACT_TANH = 0, ACT_LOGISTIC = 1, ACT_IDENTITY = 2 };
+
+// kernel classes for cn_ctx_timing_*
+enum KClass { KC_REC_FWD = 0, KC_REC_BWD = 1, KC_GEMM_WIDE = 2, KC_GEMM_GRAD = 3, KC_OTHER = 4, KC_COUNT = 5 };
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- GEMM ------------------------------------------------------------------------------------
+// All matrices are row-major; "op" element type is float (CN_PREC_F32) or bf16 (CN_PREC_BF16).
+struct GemmNT {            // C[m][n] = sum_k A[m][k] * B[n][k]   (+ bias[n]) -> act -> C / C2
+    const void *A; long lda;      // [M][K] op
+    const void *B; long ldb;      // [N][K] op
+    float *C; long ldc;           // [M][N] fp32 (nullable)
+    void *C2; long ldc2;          // [M][N] op copy (nullable)
+    const float *bias;            // [N] fp32 added before the activation (nullable)
+    int act;                      // Act
+    int M, N, K;                  // K multiple of 8 (bf16) / 4 (f32); N multiple of 32
+};
+struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), fp32 atomics (split-K)
+    const void *A; long lda;      // [K][M] op
+    const void *B; long ldb;      // [K][N] op
+    float *C; long ldc;           // [M][N] fp32, pre-zeroed
+    int M, N, K;                  // M, N multiples of 32
+};
+void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g);
+void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g);
+
+// ---- recurrent LSTM kernels --------------------------------------------------------------------
+struct LstmRec {
+    int H, Hp, dirs, PS, T, Tmin;
+    const char *pat;              // [T*PS]
+    // forward
+    float *acts;                  // [N][dirs][4][Hp] fp32: pre-activations in, n/i/f/o activations out
+    float *cell;                  // [N][dirs][Hp]    fp32
+    void  *y_op;                  // [N][dirs*Hp]     op  (layer output, GEMM operand)
+    const void *Wrec;             // [dirs][4*Hp][Hp] op  (k = source unit contiguous)
+    const float *peep;            // [dirs][3][Hp]
+    // backward
+    const float *err;             // [N][dirs*Hp] fp32 outputErrors of this layer
+    void  *delta_op;              // [N][dirs][4][Hp] op
+    const void *WrecT;            // [dirs][Hp][4*Hp] op  (k = (gate, target unit) contiguous)
+    float *dbias;                 // [dirs][4][Hp] fp32 accumulators (pre-zeroed)
+    float *dpeep;                 // [dirs][3][Hp]
+    float bias;                   // JSON bias value (scales the bias gradient)
+};
+void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
+void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
+
+// ---- element-wise / packing kernels -----------------------------------------------------------
+struct LstmGeom { int P, Pp, L, H, Hp, dirs; int prevH, prevHp, prevDirs; /* prevH=0: identity column map */ };
+
+// flat fp32 reference weights -> packed op copies + fp32 bias/peephole vectors
+void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, const float *w,
+                      void *Win, void *WinT, void *Wrec, void *WrecT, float *bias_p, float *peep_p);
+// packed fp32 gradients -> flat reference layout
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, const float *dWin, const float *dWrec,
+                              const float *dbias, const float *dpeep, float *wu);
+struct FfGeom { int P, Pp, L, Lp; int prevH, prevHp, prevDirs; };
+void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w,
+                    void *W, void *WT, float *bias_p);
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, const float *dW, const float *colsum, float *wu);
+
+// inputs [N][P] fp32 (reference layout) -> [N][Pp] op, zero padded
+void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P, void *dst, int Pp);
+// delta = act'(y) * err (in place on err, all N slots: FeedForwardLayer.cu:72-79), op copy for the GEMMs
+void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *err, void *delta_op, int N, int L, int Lp);
+// column sums of delta over the N slots (FeedForwardLayer.cu:82-102): colsum[j] += sum_n err[n][j]
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum);
+// softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp);
+// e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
+void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
+// multiclass_classification: loss/#correct reduction and error injection
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/);
+void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
+// sse
+void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2);
+void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err);
+// UpdateWeightFn over a flat range
+void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);
+// gather a padded row-major fp32/op matrix into the reference layout [N][L]
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0);
+// scatter host-provided [N][L] fp32 into a padded fp32 matrix (tests)
+void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp);
+
+}  // namespace cn

@@ -1,0 +1,452 @@
+// Persistent recurrent LSTM kernels: the whole time loop of one layer pass in ONE launch.
+//
+// Replaces the per-timestep launch storm of LstmLayer<TDevice>::computeForwardPass
+// (LstmLayer.cu:812-829 fw, :847-864 bw: 4 x addProduct + ComputeBlockOutputFn :47-138 per step)
+// and computeBackwardPass (:936-951, :970-985: 4 x addProduct + ComputeBlockErrorsFn :190-287 per
+// step), plus ResortOutputsFn/ResortOutputErrorsFn (:140-188) and the bias / peephole parts of
+// ComputeWeightUpdateFn (:289-512).
+//
+// MI355X design:
+//   * parallel sequences never interact inside a layer pass, so the PS sequences are cut into
+//     groups of 16 (one MFMA M-tile) and every (direction, sequence group) pair is one workgroup
+//     that walks all T steps on its own: no inter-workgroup communication, no grid barrier.
+//   * the four gates are packed into one tile row: wave w owns hidden units [16w, 16w+16) and
+//     the 4 gate tiles of those units, so after the MFMAs every lane holds n/i/f/o of one unit
+//     for 4 sequences and the cell update needs no cross-lane traffic.  Gate pre-activations from
+//     the N-wide input GEMM (bias already added) enter as the MFMA C operand.
+//   * W_rec fragments stay in registers for the whole pass when 4*Hp*Hp operands fit one CU's
+//     register file (Hp <= 128), otherwise they are streamed from L2 every step.
+//   * y[t] (forward) / the four deltas (backward) are exchanged between the waves of the workgroup
+//     through a double-buffered LDS tile in MFMA A-operand order; cell state, forget-gate carry and
+//     the peephole/bias gradient sums never leave registers.
+//   * fw/bw halves are written straight into the interleaved [N][2*Hp] layer output.
+#include "cn_internal.h"
+
+namespace cn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define EXP_LIMIT 88.722839f   // helpers/NumericLimits.cuh:41
+
+// Logistic::fn (Logistic.cuh:33-44); the explicit clamps reproduce the reference's exact 0 / 1.
+template <bool F32>
+__device__ __forceinline__ float logistic(float x)
+{
+    float r;
+    if constexpr (F32) r = 1.0f / (1.0f + expf(-x));
+    else r = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    r = (x >= EXP_LIMIT) ? 1.0f : r;
+    r = (x <= -EXP_LIMIT) ? 0.0f : r;
+    return r;
+}
+// Tanh::fn = Maxmin1::fn(2x) = 2*Logistic::fn(2x) - 1 (Tanh.cuh:33-36, Maxmin1.cuh:33-36)
+template <bool F32>
+__device__ __forceinline__ float tanh_ref(float x) { return 2.0f * logistic<F32>(2.0f * x) - 1.0f; }
+__device__ __forceinline__ float clip1(float e) { return e < -1.0f ? -1.0f : (e > 1.0f ? 1.0f : e); }   // limitedError.cuh:31-34
+
+// one 64-byte K chunk of a 16x16 tile product: 32 bf16 (one MFMA) or 16 fp32 (four MFMAs; the K order
+// inside the chunk is permuted identically for A and B)
+template <bool F32>
+__device__ __forceinline__ void mma16(f32x4 &acc, const u32x4 &a, const u32x4 &b)
+{
+    if constexpr (F32) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]),
+                                                       __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                      __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+}
+
+template <bool F32> __device__ __forceinline__ void st_op(void *base, long idx, float v)
+{
+    if constexpr (F32) ((float *)base)[idx] = v; else ((__bf16 *)base)[idx] = (__bf16)v;
+}
+
+// workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
+// stay in flight across it (a __syncthreads() would drain vmcnt every step)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---------------------------------------------------------------------------------------------
+// forward: a[t] = G[t] + Wrec^T y[prev(t)]; ComputeBlockOutputFn
+// ---------------------------------------------------------------------------------------------
+// HP  : padded units per direction when the W_rec fragments are register resident, 0 = stream W_rec
+// UG  : unit groups (of 16) per wave
+template <bool F32, int HP, int UG>
+__global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ELT = F32 ? 4 : 2;
+    constexpr bool RES = HP != 0;
+    const int Hp = RES ? HP : p.Hp;
+    const int pitch = Hp * ELT + 16;                 // LDS row pitch of the y tile (bytes)
+    const int KC = Hp * ELT / 64;                    // 64-byte K chunks
+    constexpr int KCR = RES ? HP * ELT / 64 : 1;
+    const int nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 16;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * Hp;           // acts row stride (floats)
+    const long crow = (long)dirs * Hp;               // cell / y row stride (elements)
+
+    // zero both y tiles (y[prev] of the first processed step is 0)
+    for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    int unit[UG];
+    float pi[UG], pf[UG], po[UG];
+    u32x4 wreg[UG][4][KCR];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * Hp * Hp * ELT;
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+        unit[u] = 16 * (wave + u * nw) + c;
+        pi[u] = p.peep[(d * 3 + 0) * Hp + unit[u]];
+        pf[u] = p.peep[(d * 3 + 1) * Hp + unit[u]];
+        po[u] = p.peep[(d * 3 + 2) * Hp + unit[u]];
+        if constexpr (RES) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int kc = 0; kc < KCR; ++kc)
+                    wreg[u][g][kc] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+        }
+    }
+
+    float cst[UG][4];
+    float pre[UG][4][4];
+    char pt[4];
+#pragma unroll
+    for (int u = 0; u < UG; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cst[u][r] = 0.f;
+
+    auto prefetch = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s0 + 4 * q + r;
+            const bool valid = s < PS;
+            const long n = (long)t * PS + s;
+            pt[r] = valid ? p.pat[n] : 0;
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pre[u][g][r] = valid ? p.acts[n * arow + (d * 4 + g) * Hp + unit[u]] : 0.f;
+        }
+    };
+
+    prefetch(d ? T - 1 : 0);
+    lds_barrier();
+
+    for (int it = 0; it < T; ++it) {
+        const int t = d ? T - 1 - it : it;
+        const char *ycur = smem + (it & 1) * 16 * pitch;
+        char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
+
+        f32x4 acc[UG][4];
+        char ptc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ptc[r] = pt[r];
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[u][g][r] = pre[u][g][r];
+
+        if (it + 1 < T) prefetch(d ? t - 1 : t + 1);
+
+        // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
+        if constexpr (RES) {
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) {
+                const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+                for (int u = 0; u < UG; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mma16<F32>(acc[u][g], a, wreg[u][g][kc]);
+            }
+        } else {
+            for (int kc = 0; kc < KC; ++kc) {
+                const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    u32x4 b[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        b[g] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mma16<F32>(acc[u][g], a, b[g]);
+                }
+            }
+        }
+
+        // cell update: C/D map of the 16x16 MFMA: col = lane&15 (unit), row = 4*(lane>>4)+reg (sequence)
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + 4 * q + r;
+                const bool valid = s < PS;
+                const bool dummy = !valid || (check && ptc[r] == 0);
+                const long n = (long)t * PS + s;
+                const float cp = cst[u][r];
+                // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
+                const float ni = tanh_ref<F32>(acc[u][0][r]);
+                const float ig = logistic<F32>(acc[u][1][r] + cp * pi[u]);
+                const float fg = logistic<F32>(acc[u][2][r] + cp * pf[u]);
+                const float cs = ni * ig + cp * fg;
+                const float og = logistic<F32>(acc[u][3][r] + cs * po[u]);
+                const float y = tanh_ref<F32>(cs) * og;
+                const float yo = dummy ? 0.f : y;
+                const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
+                cst[u][r] = co;
+                if constexpr (F32) *(float *)(ynxt + (4 * q + r) * pitch + unit[u] * 4) = yo;
+                else *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit[u] * 2) = (__bf16)yo;
+                if (valid) {
+                    if (!dummy) {
+                        float *ap = p.acts + n * arow + (long)d * 4 * Hp + unit[u];
+                        ap[0] = ni; ap[Hp] = ig; ap[2 * Hp] = fg; ap[3 * Hp] = og;
+                    }
+                    p.cell[n * crow + d * Hp + unit[u]] = co;
+                    st_op<F32>(p.y_op, n * crow + d * Hp + unit[u], yo);
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: e[t] = err[t] + Wrec delta[next(t)]; ComputeBlockErrorsFn; bias/peephole gradient sums
+// ---------------------------------------------------------------------------------------------
+template <bool F32, int HP, int UG>
+__global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ELT = F32 ? 4 : 2;
+    constexpr bool RES = HP != 0;
+    const int Hp = RES ? HP : p.Hp;
+    const int pitch = 4 * Hp * ELT + 16;             // LDS row pitch of the delta tile
+    const int KC = 4 * Hp * ELT / 64;
+    constexpr int KCR = RES ? 4 * HP * ELT / 64 : 1;
+    const int nw = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 16;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * Hp;
+    const long crow = (long)dirs * Hp;
+
+    for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    int unit[UG];
+    float pi[UG], pf[UG], po[UG];
+    u32x4 wreg[UG][KCR];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * Hp * Hp * ELT;
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+        unit[u] = 16 * (wave + u * nw) + c;
+        pi[u] = p.peep[(d * 3 + 0) * Hp + unit[u]];
+        pf[u] = p.peep[(d * 3 + 1) * Hp + unit[u]];
+        po[u] = p.peep[(d * 3 + 2) * Hp + unit[u]];
+        if constexpr (RES) {
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc)
+                wreg[u][kc] = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
+        }
+    }
+
+    // carried across steps (values of the step processed just before = next(t) in time)
+    float fgn[UG][4], ecn[UG][4], dign[UG][4], dfgn[UG][4], ccur[UG][4];
+    // gradient sums: bias (4 gates) and peepholes (i, f, o)
+    float sb[UG][4], spi[UG], spf[UG], spo[UG];
+    // prefetched operands of the next step
+    float pe[UG][4], pa[UG][4][4], pcp[UG][4];
+    char pt[4];
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+        spi[u] = spf[u] = spo[u] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { fgn[u][r] = ecn[u][r] = dign[u][r] = dfgn[u][r] = 0.f; sb[u][r] = 0.f; }
+    }
+
+    // processing order is the reverse of the forward pass of this direction
+    const int tfirst = d ? 0 : T - 1;
+    auto prefetch = [&](int t) {
+        const int tprev = d ? t + 1 : t - 1;          // prev(t) in the forward processing order
+        const bool hasprev = tprev >= 0 && tprev < T; // lastCall, LstmLayer.cu:947,981
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s0 + 4 * q + r;
+            const bool valid = s < PS;
+            const long n = (long)t * PS + s;
+            pt[r] = valid ? p.pat[n] : 0;
+#pragma unroll
+            for (int u = 0; u < UG; ++u) {
+                pe[u][r] = valid ? p.err[n * crow + d * Hp + unit[u]] : 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pa[u][g][r] = valid ? p.acts[n * arow + (d * 4 + g) * Hp + unit[u]] : 0.f;
+                pcp[u][r] = (valid && hasprev) ? p.cell[((long)tprev * PS + s) * crow + d * Hp + unit[u]] : 0.f;
+            }
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int s = s0 + 4 * q + r;
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+            ccur[u][r] = (s < PS) ? p.cell[((long)tfirst * PS + s) * crow + d * Hp + unit[u]] : 0.f;
+    }
+    prefetch(tfirst);
+    lds_barrier();
+
+    for (int it = 0; it < T; ++it) {
+        const int t = d ? it : T - 1 - it;
+        const char *dcur = smem + (it & 1) * 16 * pitch;
+        char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const bool check = t >= p.Tmin;
+
+        f32x4 acc[UG];
+        float a_[UG][4][4], cp_[UG][4];
+        char ptc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ptc[r] = pt[r];
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[u][r] = pe[u][r];
+                cp_[u][r] = pcp[u][r];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a_[u][g][r] = pa[u][g][r];
+            }
+        if (it + 1 < T) prefetch(d ? t + 1 : t - 1);
+
+        // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
+        if constexpr (RES) {
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) {
+                const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+                for (int u = 0; u < UG; ++u) mma16<F32>(acc[u], a, wreg[u][kc]);
+            }
+        } else {
+            for (int kc = 0; kc < KC; ++kc) {
+                const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+                for (int u = 0; u < UG; ++u) {
+                    const u32x4 b = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
+                    mma16<F32>(acc[u], a, b);
+                }
+            }
+        }
+
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + 4 * q + r;
+                const bool valid = s < PS;
+                const bool dummy = !valid || (check && ptc[r] == 0);
+                const long n = (long)t * PS + s;
+                // ComputeBlockErrorsFn, LstmLayer.cu:236-285
+                const float e = acc[u][r];
+                const float ni = a_[u][0][r], ig = a_[u][1][r], fg = a_[u][2][r], og = a_[u][3][r];
+                const float cs = ccur[u][r], cp = cp_[u][r];
+                const float th = tanh_ref<F32>(cs);
+                float dog = og * (1.0f - og) * th * e;
+                float ec = og * (1.0f - th * th) * e + po[u] * dog;
+                ec += fgn[u][r] * ecn[u][r] + pi[u] * dign[u][r] + pf[u] * dfgn[u][r];   // zero carry at firstCall
+                float dni = ig * (1.0f - ni * ni) * ec;
+                float dfg = fg * (1.0f - fg) * cp * ec;                                     // cp = 0 at lastCall
+                float dig = ig * (1.0f - ig) * ni * ec;
+                dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
+                if (dummy) { dni = dig = dfg = dog = 0.f; ec = 0.f; }                      // :224-234
+                fgn[u][r] = dummy ? 0.f : fg;
+                ecn[u][r] = ec; dign[u][r] = dig; dfgn[u][r] = dfg;
+                ccur[u][r] = cp;
+                // gradient sums (ComputeWeightUpdateFn bias / peephole cases, :392-408, :440-475)
+                sb[u][0] += dni; sb[u][1] += dig; sb[u][2] += dfg; sb[u][3] += dog;
+                spi[u] += cp * dig; spf[u] += cp * dfg; spo[u] += cs * dog;
+                const float dl[4] = {dni, dig, dfg, dog};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (F32) *(float *)(dnxt + (4 * q + r) * pitch + (g * Hp + unit[u]) * 4) = dl[g];
+                    else *(__bf16 *)(dnxt + (4 * q + r) * pitch + (g * Hp + unit[u]) * 2) = (__bf16)dl[g];
+                    if (valid) st_op<F32>(p.delta_op, n * arow + (d * 4 + g) * Hp + unit[u], dl[g]);
+                }
+            }
+        }
+        lds_barrier();
+    }
+
+    // fold the 4 sequence quads of each unit column, then one atomic per (gate, unit) and workgroup
+#pragma unroll
+    for (int u = 0; u < UG; ++u) {
+        float v[7] = {sb[u][0], sb[u][1], sb[u][2], sb[u][3], spi[u], spf[u], spo[u]};
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            v[i] += __shfl_xor(v[i], 16);
+            v[i] += __shfl_xor(v[i], 32);
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * 4 + g) * Hp + unit[u]], p.bias * v[g]);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * Hp + unit[u]], v[4 + g]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <bool F32, bool BWD, int HP, int UG>
+static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
+{
+    const int ELT = F32 ? 4 : 2;
+    const int nsg = (p.PS + 15) / 16;
+    const int pitch = (BWD ? 4 : 1) * p.Hp * ELT + 16;
+    const size_t lds = 2 * 16 * (size_t)pitch;
+    auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG> : lstm_fwd_kernel<F32, HP, UG>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds, s, p);
+}
+
+template <bool F32, bool BWD>
+static void launch_rec(hipStream_t s, const LstmRec &p)
+{
+    const int groups = p.Hp / 16;
+    switch (p.Hp) {
+    case 32:  launch_one<F32, BWD, 32, 1>(s, p, 2); return;
+    case 64:  launch_one<F32, BWD, 64, 1>(s, p, 4); return;
+    case 96:  launch_one<F32, BWD, 96, 1>(s, p, 6); return;
+    case 128: launch_one<F32, BWD, 128, 1>(s, p, 8); return;
+    default: break;
+    }
+    if (groups <= 16)      launch_one<F32, BWD, 0, 1>(s, p, groups);
+    else if (groups <= 32) launch_one<F32, BWD, 0, 2>(s, p, (groups + 1) / 2);
+    else                   launch_one<F32, BWD, 0, 4>(s, p, (groups + 3) / 4);
+}
+
+void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
+{
+    if (f32) launch_rec<true, false>(s, p); else launch_rec<false, false>(s, p);
+}
+void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p)
+{
+    if (f32) launch_rec<true, true>(s, p); else launch_rec<false, true>(s, p);
+}
+
+}  // namespace cn

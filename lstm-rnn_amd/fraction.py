@@ -1,0 +1,64 @@
+"""Fraction packer: host-side mirror of data_sets::DataSet::_makeFractionTask
+(currennt_lib/src/data_sets/DataSet.cpp:300-414) for in-memory sequences.
+
+A fraction is `parallel_sequences` sequences interleaved time-major: slot (t, i) of sequence i
+sits at pattern index t*PS + i; slots past a sequence's end (and columns of missing sequences) are
+PATTYPE_NONE with zero inputs and target class -1.
+"""
+import numpy as np
+
+PATTYPE_NONE, PATTYPE_FIRST, PATTYPE_NORMAL, PATTYPE_LAST = 0, 1, 2, 3
+
+
+def make_fraction(inputs, targets, parallel_sequences, classification=True, output_size=None):
+    """inputs: list of [len_i][P] float arrays; targets: list of [len_i] int arrays (classification)
+    or [len_i][L] float arrays.  Returns the dict layout used by NeuralNetwork.load_sequences."""
+    PS = int(parallel_sequences)
+    if not inputs or len(inputs) > PS:
+        raise ValueError("need 1..parallel_sequences sequences")
+    lengths = [int(x.shape[0]) for x in inputs]
+    T, Tmin = max(lengths), min(lengths)                       # DataSet.cpp:316-319
+    P = int(inputs[0].shape[1])
+    x = np.zeros((T, PS, P), np.float32)                       # :330
+    pat = np.full((T, PS), PATTYPE_NONE, np.int8)              # :331
+    frac = {"T": T, "Tmin": Tmin, "PS": PS, "numSeqs": len(inputs), "seqLengths": lengths}
+    if classification:
+        tc = np.full((T, PS), -1, np.int32)                    # :333-334
+    else:
+        L = int(output_size if output_size is not None else targets[0].shape[1])
+        tg = np.zeros((T, PS, L), np.float32)
+    for i, (xi, ti, n) in enumerate(zip(inputs, targets, lengths)):
+        x[:n, i, :] = xi                                       # :346-366 (no context splicing)
+        if classification:
+            tc[:n, i] = ti                                     # :372-380 (output lag 0)
+        else:
+            tg[:n, i, :] = ti                                  # :383-397
+        pat[:n, i] = PATTYPE_NORMAL                            # :400-409
+        pat[0, i] = PATTYPE_FIRST
+        if n > 1:
+            pat[n - 1, i] = PATTYPE_LAST
+    frac["inputs"] = x.reshape(T * PS, P)
+    frac["patTypes"] = pat.reshape(T * PS)
+    if classification:
+        frac["targetClasses"] = tc.reshape(T * PS)
+    else:
+        frac["targets"] = tg.reshape(T * PS, -1)
+    return frac
+
+
+def make_fractions(inputs, targets, parallel_sequences, sort_by_length=False, **kw):
+    """Cut a list of sequences into consecutive fractions (DataSet.cpp:632-668); optionally sort
+    ascending by length first as the training set does (DataSet.cpp:603-605)."""
+    order = list(range(len(inputs)))
+    if sort_by_length:
+        order.sort(key=lambda i: inputs[i].shape[0])
+    out = []
+    for a in range(0, len(order), parallel_sequences):
+        idx = order[a:a + parallel_sequences]
+        out.append(make_fraction([inputs[i] for i in idx], [targets[i] for i in idx],
+                                 parallel_sequences, **kw))
+    return out
+
+
+def real_frames(frac):
+    return int((np.asarray(frac["patTypes"]) != PATTYPE_NONE).sum())

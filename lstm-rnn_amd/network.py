@@ -1,0 +1,269 @@
+"""Host-side mirror of NeuralNetwork<TDevice> / Layer<TDevice> over the C ABI.
+
+Method names and call order follow currennt_lib/src/NeuralNetwork.cpp:37-130 (construction from
+the "layers"/"weights" JSON sections), :161-190 (loadSequences / computeForwardPass /
+computeBackwardPass / calculateError), :237-262 (getOutputs) and
+optimizers/SteepestDescentOptimizer.cu:67-94 (_updateWeights).  All arithmetic happens in
+libcurrennt_hip.so; nothing here touches the CPU oracle.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+
+_TRAINABLE = ("lstm", "blstm", "softmax", "feedforward_tanh", "feedforward_logistic",
+              "feedforward_identity")
+_POST = ("sse", "multiclass_classification")
+
+
+class Layer:
+    """One layer handle (layers/Layer.hpp:40-179, TrainableLayer.hpp:84-155)."""
+
+    def __init__(self, net, desc, prev):
+        self.net, self.desc, self.prev = net, desc, prev
+        if "name" not in desc:
+            raise RuntimeError("Missing value 'name' in layer description")           # Layer.cpp:52-53
+        if "size" not in desc:
+            raise RuntimeError("Missing value 'size' in layer '%s'" % desc["name"])   # Layer.cpp:56-57
+        self.name, self.type, self.size = desc["name"], desc["type"], int(desc["size"])
+        if self.type not in B.LAYER_KINDS:
+            raise RuntimeError("Unknown layer type '%s'" % self.type)                  # LayerFactory.cu:86
+        self.trainable = self.type in _TRAINABLE
+        self.post = self.type in _POST
+        if self.trainable and "bias" not in desc:
+            raise RuntimeError("Missing value 'bias' in layer '%s'" % self.name)       # TrainableLayer.cu:61-62
+        self.bias = float(desc.get("bias", 0.0))
+        self.learning_rate = float(desc.get("learningRate", -1.0))                     # TrainableLayer.cu:58
+        h = C.c_void_p()
+        L = net.lib
+        B.check(L.cn_layer_create(net.ctx, B.LAYER_KINDS[self.type], prev.handle if prev else None,
+                                  self.size, self.bias,
+                                  net.parallel_sequences if prev is None else 0,
+                                  net.max_seq_length if prev is None else 0, C.byref(h)), net.ctx)
+        self.handle = h
+        self.weight_count = L.cn_layer_weight_count(h) if self.trainable else 0
+        if self.type in ("lstm", "blstm"):
+            self.dirs = 2 if self.type == "blstm" else 1
+            self.H = self.size // self.dirs
+
+    # -- buffers in reference layout -----------------------------------------------------------
+    def _read(self, which, count, direction=0):
+        out = np.empty(count, np.float32)
+        B.check(self.net.lib.cn_layer_read(self.handle, B.BUF[which], direction,
+                                           out.ctypes.data_as(C.c_void_p), count), self.net.ctx)
+        return out
+
+    def outputs(self):
+        return self._read("outputs", self.net.N * self.size).reshape(self.net.T, self.net.PS, self.size)
+
+    def output_errors(self):
+        return self._read("outputErrors", self.net.N * self.size).reshape(self.net.T, self.net.PS, self.size)
+
+    def weights(self):
+        return self._read("weights", self.weight_count)
+
+    def weight_updates(self):
+        return self._read("weightUpdates", self.weight_count)
+
+    def internal(self, which, direction=0):
+        """LSTM per-direction internal vector by its reference name (LstmLayer.hpp:88-100)."""
+        return self._read(which, self.net.N * self.H, direction).reshape(self.net.T, self.net.PS, self.H)
+
+    def set_weights(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        B.check(self.net.lib.cn_layer_set_weights(self.handle, flat.ctypes.data_as(C.c_void_p), flat.size),
+                self.net.ctx)
+
+    def write_output_errors(self, err):
+        err = np.ascontiguousarray(err, np.float32).reshape(-1)
+        B.check(self.net.lib.cn_layer_write_output_errors(self.handle, err.ctypes.data_as(C.c_void_p), err.size),
+                self.net.ctx)
+
+
+class NeuralNetwork:
+    def __init__(self, layers, weights=None, parallel_sequences=1, max_seq_length=1,
+                 precision=B.PREC_F32, device=0, stream=None, seed=None):
+        self.lib = B.load_library()
+        self.parallel_sequences, self.max_seq_length = int(parallel_sequences), int(max_seq_length)
+        self.PS = self.parallel_sequences
+        self.precision = precision
+        ctx = C.c_void_p()
+        B.check(self.lib.cn_ctx_create(device, precision, stream, C.byref(ctx)))
+        self.ctx = ctx
+        self.layers = []
+        self.T = self.Tmin = self.N = 0
+        try:
+            names = set()
+            prev = None
+            for desc in layers:                                                        # NeuralNetwork.cpp:60-95
+                lay = Layer(self, desc, prev)
+                if lay.name in names:
+                    raise RuntimeError("Different layers have the same name '%s'" % lay.name)   # :85-86
+                names.add(lay.name)
+                self.layers.append(lay)
+                prev = lay
+            if len(self.layers) < 3:
+                raise RuntimeError("Not enough layers defined")                        # :98-99
+            if self.layers[0].type != "input":
+                raise RuntimeError("The first layer is not an input layer")            # :102-105 (paraphrased)
+            if not self.layers[-1].post:
+                raise RuntimeError("The last layer is not a post output layer")        # :116-117
+            rng = np.random.RandomState(seed) if seed is not None else None
+            for lay in self.layers:
+                if not lay.trainable:
+                    continue
+                if weights is not None and lay.name in weights:                        # TrainableLayer.cu:68-101
+                    w = weights[lay.name]
+                    for key in ("input", "bias", "internal"):
+                        if key not in w:
+                            raise RuntimeError("Missing array 'weights/%s/%s'" % (lay.name, key))
+                    flat = np.concatenate([np.asarray(w["input"], np.float32).reshape(-1),
+                                           np.asarray(w["bias"], np.float32).reshape(-1),
+                                           np.asarray(w["internal"], np.float32).reshape(-1)])
+                    if flat.size != lay.weight_count:
+                        raise RuntimeError("Invalid number of weights for layer '%s'" % lay.name)
+                elif rng is not None:
+                    # uniform [-0.1, 0.1] like Configuration.cpp:186-187; the reference draws from
+                    # boost::mt19937, which is not reproducible here
+                    flat = rng.uniform(-0.1, 0.1, lay.weight_count).astype(np.float32)
+                else:
+                    raise RuntimeError("no weights given for layer '%s' and no seed" % lay.name)
+                lay.set_weights(flat)
+        except Exception:
+            self.close()
+            raise
+
+    # -- life cycle ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.cn_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- NeuralNetwork API ---------------------------------------------------------------------
+    def input_layer(self):
+        return self.layers[0]
+
+    def post_output_layer(self):
+        return self.layers[-1]
+
+    def output_layer(self):
+        return self.layers[-2]
+
+    def trainable_layers(self):
+        return [l for l in self.layers if l.trainable]
+
+    def layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise KeyError(name)
+
+    def load_sequences(self, frac):                                                    # NeuralNetwork.cpp:161-166
+        x = np.ascontiguousarray(frac["inputs"], np.float32)
+        pat = np.ascontiguousarray(frac["patTypes"], np.int8)
+        f = B.Fraction()
+        f.max_seq_length, f.min_seq_length = int(frac["T"]), int(frac["Tmin"])
+        f.num_sequences = int(frac.get("numSeqs", self.PS))
+        f.input_pattern_size = int(x.shape[-1])
+        keep = [x, pat]
+        f.pat_types = pat.ctypes.data_as(C.c_void_p)
+        f.inputs = x.ctypes.data_as(C.c_void_p)
+        post = self.layers[-1]
+        if "targetClasses" in frac and frac["targetClasses"] is not None:
+            tc = np.ascontiguousarray(frac["targetClasses"], np.int32)
+            keep.append(tc)
+            f.target_classes = tc.ctypes.data_as(C.c_void_p)
+            f.output_pattern_size = int(frac.get("outputPatternSize", post.size))
+        if "targets" in frac and frac["targets"] is not None:
+            tg = np.ascontiguousarray(frac["targets"], np.float32)
+            keep.append(tg)
+            f.targets = tg.ctypes.data_as(C.c_void_p)
+            f.output_pattern_size = int(tg.shape[-1])
+        B.check(self.lib.cn_fraction_load(self.ctx, self.layers[0].handle, post.handle, C.byref(f)), self.ctx)
+        B.check(self.lib.cn_ctx_synchronize(self.ctx), self.ctx)     # host arrays may go away after return
+        self.T, self.Tmin = f.max_seq_length, f.min_seq_length
+        self.N = self.T * self.PS
+
+    def compute_forward_pass(self):                                                    # NeuralNetwork.cpp:168-173
+        for lay in self.layers:
+            B.check(self.lib.cn_layer_forward(lay.handle), self.ctx)
+
+    def compute_backward_pass(self):                                                   # NeuralNetwork.cpp:175-184
+        for lay in reversed(self.layers):
+            B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
+
+    def _loss(self):
+        err, cor = C.c_float(), C.c_int()
+        B.check(self.lib.cn_loss_eval(self.layers[-1].handle, C.byref(err), C.byref(cor)), self.ctx)
+        return float(err.value), int(cor.value)
+
+    def calculate_error(self):                                                         # NeuralNetwork.cpp:186-190
+        return self._loss()[0]
+
+    def count_correct_classifications(self):
+        return self._loss()[1]
+
+    def error_and_correct(self):
+        return self._loss()
+
+    def update_weights(self, learning_rate, momentum):                                 # SteepestDescentOptimizer.cu:67-94
+        for lay in self.trainable_layers():
+            lr = lay.learning_rate if lay.learning_rate >= 0.0 else learning_rate
+            B.check(self.lib.cn_sgd_update(lay.handle, lr, momentum), self.ctx)
+
+    def update_weights_fused(self, learning_rate, momentum):
+        B.check(self.lib.cn_sgd_update_all(self.ctx, learning_rate, momentum), self.ctx)
+
+    def outputs(self):
+        """Output layer activations [T][PS][C] (NeuralNetwork.cpp:237-262 de-interleaves per sequence)."""
+        return self.output_layer().outputs()
+
+    def synchronize(self):
+        B.check(self.lib.cn_ctx_synchronize(self.ctx), self.ctx)
+
+    def param_arena(self):
+        """(weights_ptr, weight_updates_ptr, weight_deltas_ptr, count) raw device pointers."""
+        w, g, d, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        B.check(self.lib.cn_ctx_param_arena(self.ctx, C.byref(w), C.byref(g), C.byref(d), C.byref(n)), self.ctx)
+        return w.value, g.value, d.value, n.value
+
+    def export_weights(self):
+        """The "weights" JSON section (TrainableLayer.cu:211-248: input / bias / internal)."""
+        out = {}
+        for lay in self.trainable_layers():
+            w = lay.weights()
+            P, L = lay.prev.size, lay.size
+            per_in = 4 if lay.type in ("lstm", "blstm") else 1
+            n_in, n_b = L * per_in * P, L * per_in
+            out[lay.name] = {"input": w[:n_in].tolist(), "bias": w[n_in:n_in + n_b].tolist(),
+                             "internal": w[n_in + n_b:].tolist()}
+        return out
+
+    # -- timing ---------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        B.check(self.lib.cn_ctx_timing_enable(self.ctx, 1 if on else 0), self.ctx)
+
+    def timing_reset(self):
+        B.check(self.lib.cn_ctx_timing_reset(self.ctx), self.ctx)
+
+    def timing_read(self):
+        names = ["rec_fwd", "rec_bwd", "gemm_wide", "gemm_grad", "other"]
+        out = {}
+        for k, nm in enumerate(names):
+            ms, n = C.c_double(), C.c_long()
+            B.check(self.lib.cn_ctx_timing_read(self.ctx, k, C.byref(ms), C.byref(n)), self.ctx)
+            out[nm] = (ms.value, n.value)
+        return out

@@ -1,0 +1,239 @@
+"""ctypes front end of the CPU oracle -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module (see the header of currennt_oracle.c).  `OracleNetwork` drives the C
+restatement layer by layer in the call order of the reference:
+
+  NeuralNetwork::loadSequences / computeForwardPass / calculateError /
+  computeBackwardPass            (currennt_lib/src/NeuralNetwork.cpp:161-190)
+  Optimizer::_processDataSet     (currennt_lib/src/optimizers/Optimizer.cu:37-104)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcurrennt_oracle.so")
+_lib = None
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+
+ACT = {"feedforward_tanh": 0, "feedforward_logistic": 1, "feedforward_identity": 2}
+
+
+def build():
+    """Compile oracle/libcurrennt_oracle.so with gcc (seconds)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libcurrennt_oracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src = os.path.join(_HERE, "currennt_oracle.c")
+    if (not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    ci, cf, vp = C.c_int, C.c_float, C.c_void_p
+    L.orc_matmul.argtypes = [ci, f32p, f32p, ci, ci, f32p, ci, ci, ci]
+    L.orc_lstm_weight_count.argtypes = [ci, ci, ci]
+    L.orc_lstm_weight_count.restype = ci
+    L.orc_lstm_internal_count.restype = ci
+    L.orc_lstm_forward.argtypes = [ci, ci, ci, cf, ci, ci, ci, ci, i8p, f32p, f32p, f32p, f32p]
+    L.orc_lstm_backward.argtypes = [ci, ci, ci, cf, ci, ci, ci, ci, i8p, f32p, f32p,
+                                    f32p, vp, f32p, f32p]
+    L.orc_ff_weight_count.argtypes = [ci, ci]
+    L.orc_ff_weight_count.restype = ci
+    L.orc_ff_forward.argtypes = [ci, ci, ci, cf, ci, f32p, f32p, f32p]
+    L.orc_ff_backward.argtypes = [ci, ci, ci, cf, ci, f32p, f32p, f32p, f32p, vp, f32p]
+    L.orc_softmax_forward.argtypes = [ci, ci, cf, ci, i8p, f32p, f32p, f32p, f32p]
+    L.orc_softmax_backward.argtypes = [ci, ci, cf, ci, i8p, f32p, f32p, f32p, f32p, vp, f32p, f32p]
+    L.orc_mcc_error.argtypes = [ci, ci, i32p, f32p]
+    L.orc_mcc_error.restype = cf
+    L.orc_mcc_correct.argtypes = [ci, ci, i32p, f32p]
+    L.orc_mcc_correct.restype = ci
+    L.orc_mcc_backward.argtypes = [ci, ci, i32p, f32p, f32p]
+    L.orc_sse_error.argtypes = [ci, ci, i8p, f32p, f32p]
+    L.orc_sse_error.restype = cf
+    L.orc_sse_backward.argtypes = [ci, ci, i8p, f32p, f32p, f32p]
+    L.orc_sgd_update.argtypes = [ci, cf, cf, f32p, f32p, f32p]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+INTERNAL_NAMES = ["tmpOutputs", "tmpOutputErrors", "cellStates", "cellStateErrors",
+                  "niActs", "igActs", "fgActs", "ogActs",
+                  "niDeltas", "igDeltas", "fgDeltas", "ogDeltas"]
+
+
+class _Layer:
+    def __init__(self, desc, prev, PS, maxT, weights):
+        self.desc = desc
+        self.name = desc["name"]
+        self.type = desc["type"]
+        self.size = int(desc["size"])
+        self.prev = prev
+        self.PS, self.maxT = PS, maxT
+        self.bias = float(desc.get("bias", 0.0))
+        self.trainable = self.type in ("lstm", "blstm", "softmax") or self.type in ACT
+        self.post = self.type in ("multiclass_classification", "sse")
+        n = PS * maxT * self.size
+        # PostOutputLayer writes into the preceding layer's outputErrors (PostOutputLayer.cpp:43-47)
+        self.outputs = np.zeros(n, np.float32) if not self.post else None
+        self.outputErrors = np.zeros(n, np.float32) if not self.post else None
+        self.weights = self.weightUpdates = None
+        if self.trainable:
+            P = prev.size
+            if self.type in ("lstm", "blstm"):
+                self.bidir = self.type == "blstm"
+                if self.bidir and self.size % 2:
+                    raise RuntimeError("Cannot create a bidirectional layer with an odd layer size")
+                nw = lib().orc_lstm_weight_count(P, self.size, int(self.bidir))
+                dirs = 2 if self.bidir else 1
+                self.H = self.size // dirs
+                self.bufs = np.zeros(dirs * 12 * PS * maxT * self.H, np.float32)
+            else:
+                nw = lib().orc_ff_weight_count(P, self.size)
+                self.patTmp = np.zeros(PS * maxT, np.float32)
+            w = weights.get(self.name) if weights else None
+            if w is None:
+                raise RuntimeError("oracle networks need explicit weights (SURVEY Q13)")
+            flat = np.concatenate([np.asarray(w["input"], np.float32),
+                                   np.asarray(w["bias"], np.float32),
+                                   np.asarray(w["internal"], np.float32)])
+            if flat.size != nw:
+                raise RuntimeError("Invalid number of weights for layer '%s'" % self.name)
+            self.weights = np.ascontiguousarray(flat)
+            self.weightUpdates = np.zeros(nw, np.float32)
+
+    def internal(self, which, d=0):
+        """LSTM per-direction internal vector by reference name (LstmLayer.hpp:88-100)."""
+        per = self.PS * self.maxT * self.H
+        b = INTERNAL_NAMES.index(which)
+        return self.bufs[(d * 12 + b) * per:(d * 12 + b + 1) * per]
+
+
+class OracleNetwork:
+    """Layer stack driven like NeuralNetwork.cpp:37-130,161-190."""
+
+    def __init__(self, layers, weights, parallel_sequences, max_seq_length):
+        self.PS, self.maxT = parallel_sequences, max_seq_length
+        self.layers = []
+        prev = None
+        for desc in layers:
+            lay = _Layer(desc, prev, self.PS, self.maxT, weights)
+            self.layers.append(lay)
+            prev = lay
+        if self.layers[0].type != "input":
+            raise RuntimeError("The first layer is not an input layer")
+        if not self.layers[-1].post:
+            raise RuntimeError("The last layer is not a post output layer")
+
+    # -- NeuralNetwork::loadSequences (NeuralNetwork.cpp:161-166)
+    def load_sequences(self, frac):
+        if frac["inputs"].shape[-1] != self.layers[0].size:
+            raise RuntimeError("Input layer size of %d != data input pattern size of %d"
+                               % (self.layers[0].size, frac["inputs"].shape[-1]))
+        self.T, self.Tmin = int(frac["T"]), int(frac["Tmin"])
+        self.N = self.T * self.PS
+        self.patTypes = np.ascontiguousarray(frac["patTypes"], np.int8)
+        x = np.ascontiguousarray(frac["inputs"], np.float32).reshape(-1)
+        self.layers[0].outputs[:x.size] = x
+        post = self.layers[-1]
+        if post.type == "multiclass_classification":
+            self.targetClasses = np.ascontiguousarray(frac["targetClasses"], np.int32)
+        else:
+            self.targets = np.ascontiguousarray(frac["targets"], np.float32).reshape(-1)
+
+    # -- NeuralNetwork::computeForwardPass (NeuralNetwork.cpp:168-173)
+    def compute_forward_pass(self):
+        L = lib()
+        for lay in self.layers[1:-1]:
+            P, x = lay.prev.size, lay.prev.outputs
+            if lay.type in ("lstm", "blstm"):
+                L.orc_lstm_forward(P, lay.size, int(lay.bidir), lay.bias, self.PS, self.maxT,
+                                   self.T, self.Tmin, self.patTypes, lay.weights, x,
+                                   lay.outputs, lay.bufs)
+            elif lay.type == "softmax":
+                L.orc_softmax_forward(P, lay.size, lay.bias, self.N, self.patTypes,
+                                      lay.weights, x, lay.outputs, lay.patTmp)
+            else:
+                L.orc_ff_forward(ACT[lay.type], P, lay.size, lay.bias, self.N,
+                                 lay.weights, x, lay.outputs)
+
+    # -- PostOutputLayer::calculateError
+    def calculate_error(self):
+        L = lib()
+        post, out = self.layers[-1], self.layers[-2]
+        if post.type == "multiclass_classification":
+            return float(L.orc_mcc_error(post.size, self.N, self.targetClasses, out.outputs))
+        return float(L.orc_sse_error(post.size, self.N, self.patTypes, self.targets, out.outputs))
+
+    def count_correct_classifications(self):
+        post, out = self.layers[-1], self.layers[-2]
+        return int(lib().orc_mcc_correct(post.size, self.N, self.targetClasses, out.outputs))
+
+    # -- NeuralNetwork::computeBackwardPass (NeuralNetwork.cpp:175-184), reverse order
+    def compute_backward_pass(self):
+        L = lib()
+        post, out = self.layers[-1], self.layers[-2]
+        if post.type == "multiclass_classification":
+            L.orc_mcc_backward(post.size, self.N, self.targetClasses, out.outputs, out.outputErrors)
+        else:
+            L.orc_sse_backward(post.size, self.N, self.patTypes, self.targets,
+                               out.outputs, out.outputErrors)
+        for lay in reversed(self.layers[1:-1]):
+            P, x = lay.prev.size, lay.prev.outputs
+            # only a trainable preceding layer receives errors (LstmLayer.cu:991-992)
+            prev_err = lay.prev.outputErrors if lay.prev.trainable else None
+            if lay.type in ("lstm", "blstm"):
+                L.orc_lstm_backward(P, lay.size, int(lay.bidir), lay.bias, self.PS, self.maxT,
+                                    self.T, self.Tmin, self.patTypes, lay.weights, x,
+                                    lay.outputErrors, _ptr(prev_err), lay.weightUpdates, lay.bufs)
+            elif lay.type == "softmax":
+                L.orc_softmax_backward(P, lay.size, lay.bias, self.N, self.patTypes, lay.weights,
+                                       x, lay.outputs, lay.outputErrors, _ptr(prev_err),
+                                       lay.weightUpdates, lay.patTmp)
+            else:
+                L.orc_ff_backward(ACT[lay.type], P, lay.size, lay.bias, self.N, lay.weights,
+                                  x, lay.outputs, lay.outputErrors, _ptr(prev_err),
+                                  lay.weightUpdates)
+
+    # -- SteepestDescentOptimizer::_updateWeights (SteepestDescentOptimizer.cu:67-94)
+    def update_weights(self, learning_rate, momentum, deltas=None):
+        if deltas is None:
+            deltas = getattr(self, "_deltas", None)
+            if deltas is None:
+                deltas = self._deltas = {l.name: np.zeros_like(l.weights)
+                                         for l in self.layers if l.trainable}
+        for lay in self.layers:
+            if not lay.trainable:
+                continue
+            lr = learning_rate
+            if float(lay.desc.get("learningRate", -1.0)) >= 0.0:
+                lr = float(lay.desc["learningRate"])
+            lib().orc_sgd_update(lay.weights.size, lr, momentum, lay.weights,
+                                 lay.weightUpdates, deltas[lay.name])
+
+    def trainable_layers(self):
+        return [l for l in self.layers if l.trainable]
+
+    def layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise KeyError(name)
+
+    def outputs(self):
+        """Output layer activations [T][PS][C] of the current fraction."""
+        out = self.layers[-2]
+        return out.outputs[:self.N * out.size].reshape(self.T, self.PS, out.size)

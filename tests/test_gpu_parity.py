@@ -1,0 +1,193 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, fp32 mode.  Tolerances are stated per assertion; BASELINE.json asks for frame-posterior
+max-abs error < 1e-4 against the CPU reference."""
+import numpy as np
+import pytest
+
+from helpers import load_kat0, net_desc, random_sequences, random_weights, real_mask
+
+pytestmark = pytest.mark.gpu
+
+POSTERIOR_TOL = 1e-4      # BASELINE.json north_star
+
+
+def run_both(pkg, orc, layers, weights, frac, PS, precision=0, lr=None):
+    ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    ref.load_sequences(frac)
+    ref.compute_forward_pass()
+    e_ref = ref.calculate_error()
+    c_ref = ref.count_correct_classifications() if layers[-1]["type"] == "multiclass_classification" else -1
+    ref.compute_backward_pass()
+    net = pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=precision)
+    net.load_sequences(frac)
+    net.compute_forward_pass()
+    e, c = net.error_and_correct()
+    net.compute_backward_pass()
+    return ref, net, (e_ref, c_ref), (e, c)
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def check_network(pkg, orc, layers, weights, frac, PS, grad_tol=2e-4):
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS)
+    try:
+        real = real_mask(frac)
+        C = layers[-1]["size"]
+        y = net.outputs().reshape(-1, C)[real]
+        yr = ref.outputs().reshape(-1, C)[real]
+        assert np.abs(y - yr).max() < POSTERIOR_TOL
+        assert abs(e - e_ref) <= 1e-4 * max(1.0, abs(e_ref))
+        assert c == c_ref
+        for lay in net.trainable_layers():
+            rl = ref.layer(lay.name)
+            g, gr = lay.weight_updates(), rl.weightUpdates
+            assert rel_err(g, gr) < grad_tol, (lay.name, rel_err(g, gr))
+            if lay.prev.trainable:
+                pe = lay.prev.output_errors().reshape(-1, lay.prev.size)[real]
+                per = rl.prev.outputErrors[:net.N * lay.prev.size].reshape(-1, lay.prev.size)[real]
+                assert rel_err(pe, per) < grad_tol, (lay.name, "prev errors")
+        return ref, net
+    except Exception:
+        net.close()
+        raise
+
+
+@pytest.mark.parametrize("kind,size", [("lstm", 12), ("blstm", 10), ("blstm", 40), ("lstm", 128)])
+def test_single_lstm_layer_internals(pkg, orc, kind, size):
+    """Every LSTM internal vector of LstmLayer.hpp:88-100 on real slots, ragged lengths {20,17,9}."""
+    rng = np.random.RandomState(11)
+    P, C, PS = 7, 5, 3
+    layers = net_desc(P, [(kind, size)], C)
+    weights = random_weights(layers, rng, 0.4)
+    xs, ts = random_sequences(rng, [20, 17, 9], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    with net:
+        lay, rl = net.layers[1], ref.layers[1]
+        real = real_mask(frac)
+        for d in range(lay.dirs):
+            for name in ("cellStates", "niActs", "igActs", "fgActs", "ogActs", "tmpOutputs",
+                         "niDeltas", "igDeltas", "fgDeltas", "ogDeltas"):
+                a = lay.internal(name, d).reshape(-1, lay.H)[real]
+                b = rl.internal(name, d)[:net.N * lay.H].reshape(-1, lay.H)[real]
+                assert np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(b).max()), (name, d, np.abs(a - b).max())
+        # bw direction zeroes the cell state of dummy slots (LstmLayer.cu:81-82); outputs of dummies are 0
+        out = lay.outputs().reshape(-1, lay.size)[~real]
+        assert np.all(out == 0)
+
+
+def test_kat0_network(pkg, orc):
+    """The reference's tests/test1 network (blstm/feedforward_tanh stack) on real CHiME frames."""
+    layers, weights, xs, ts = load_kat0()
+    frac = pkg.make_fraction(xs, ts, 10)
+    ref, net = check_network(pkg, orc, layers, weights, frac, 10)
+    with net:
+        e, c = net.error_and_correct()
+        assert abs(e - 5293.397461) < 0.05 and c == 126
+
+
+def test_timit_like_stack_3xblstm(pkg, orc):
+    """39 -> 3 x blstm -> softmax 183 (reading A uses size 250; a 3 x 50 stand-in keeps the oracle fast)."""
+    rng = np.random.RandomState(5)
+    P, C, PS = 39, 183, 6
+    layers = net_desc(P, [("blstm", 50), ("blstm", 50), ("blstm", 50)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, [31, 30, 28, 25, 25, 12], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    net.close()
+
+
+def test_full_width_blstm250(pkg, orc):
+    """One blstm of size 250 (H = 125 -> padded to 128: the register-resident kernel) + softmax 183."""
+    rng = np.random.RandomState(6)
+    P, C, PS = 39, 183, 20
+    layers = net_desc(P, [("blstm", 250)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, list(rng.randint(20, 41, PS)), P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    net.close()
+
+
+def test_streaming_kernel_blstm320(pkg, orc):
+    """H = 160 per direction does not fit the register-resident kernel: W_rec is streamed."""
+    rng = np.random.RandomState(8)
+    P, C, PS = 13, 9, 5
+    layers = net_desc(P, [("blstm", 320)], C)
+    weights = random_weights(layers, rng, 0.08)
+    xs, ts = random_sequences(rng, [12, 12, 10, 7, 3], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    net.close()
+
+
+def test_partial_fraction_and_sse(pkg, orc):
+    """Fewer sequences than parallel_sequences (missing columns stay PATTYPE_NONE, DataSet.cpp:339-341)
+    and the SSE post output layer on a feedforward_identity output."""
+    rng = np.random.RandomState(9)
+    P, L, PS = 6, 4, 4
+    layers = net_desc(P, [("lstm", 8), ("feedforward_logistic", 6)], L, post="sse")
+    weights = random_weights(layers, rng, 0.5)
+    xs, ts = random_sequences(rng, [9, 5], P, L=L)
+    frac = pkg.make_fraction(xs, ts, PS, classification=False)
+    ref, net, (e_ref, _), (e, _) = run_both(pkg, orc, layers, weights, frac, PS)
+    with net:
+        real = real_mask(frac)
+        assert abs(e - e_ref) <= 1e-5 * max(1.0, abs(e_ref))
+        y = net.outputs().reshape(-1, L)[real]
+        yr = ref.outputs().reshape(-1, L)[real]
+        assert np.abs(y - yr).max() < 1e-5
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 2e-4, lay.name
+
+
+def test_sgd_momentum_steps(pkg, orc):
+    """Three fractions of stochastic training: post-update weights track the oracle (Q10)."""
+    rng = np.random.RandomState(10)
+    P, C, PS = 5, 4, 3
+    layers = net_desc(P, [("blstm", 12)], C)
+    weights = random_weights(layers, rng, 0.3)
+    ref = orc.OracleNetwork(layers, weights, PS, 12)
+    with pkg.NeuralNetwork(layers, weights, PS, 12) as net:
+        for step in range(3):
+            xs, ts = random_sequences(rng, [12, 8, 5], P, C=C)
+            frac = pkg.make_fraction(xs, ts, PS)
+            for n in (ref, net):
+                n.load_sequences(frac); n.compute_forward_pass(); n.compute_backward_pass()
+            ref.update_weights(1e-2, 0.9); net.update_weights(1e-2, 0.9)
+            for lay in net.trainable_layers():
+                assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
+
+
+def test_bf16_mode_close(pkg, orc):
+    """Throughput mode (bf16 MFMA operands, fp32 accumulate/state): not a parity mode; posteriors
+    stay within 3e-2 of the fp32 oracle on a 2-layer stack and the loss within 1 %."""
+    rng = np.random.RandomState(12)
+    P, C, PS = 39, 20, 8
+    layers = net_desc(P, [("blstm", 64), ("blstm", 64)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, [30] * PS, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net, (e_ref, _), (e, _) = run_both(pkg, orc, layers, weights, frac, PS, precision=1)
+    with net:
+        assert np.abs(net.outputs() - ref.outputs()).max() < 3e-2
+        assert abs(e - e_ref) < 1e-2 * e_ref
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 5e-2, lay.name
+
+
+def test_error_texts(pkg):
+    """Shape errors carry the reference's messages (InputLayer.cpp:52-55, LstmLayer.cu:528-529)."""
+    rng = np.random.RandomState(1)
+    layers = net_desc(5, [("blstm", 8)], 3)
+    weights = random_weights(layers, rng)
+    with pkg.NeuralNetwork(layers, weights, 2, 4) as net:
+        xs, ts = random_sequences(rng, [4, 3], 6, C=3)
+        with pytest.raises(pkg.CurrenntHipError, match="Input layer size of 5 != data input pattern size of 6"):
+            net.load_sequences(pkg.make_fraction(xs, ts, 2))
+    bad = net_desc(5, [("blstm", 7)], 3)
+    with pytest.raises(pkg.CurrenntHipError, match="Cannot create a bidirectional layer with an odd layer size"):
+        pkg.NeuralNetwork(bad, None, 2, 4, seed=1)
