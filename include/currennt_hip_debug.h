@@ -1,0 +1,26 @@
+/*
+ * currennt_hip_debug.h -- kernel-level test hooks of libcurrennt_hip.so.
+ *
+ * Not part of the drop-in boundary: these run one GEMM kernel on host-provided fp32 matrices (converted to
+ * the context's operand type on the device) so the tests can check the MFMA kernels in isolation against
+ * the oracle's helpers::Matrix restatement (helpers/Matrix.cu:41-183).
+ */
+#ifndef CURRENNT_HIP_DEBUG_H
+#define CURRENNT_HIP_DEBUG_H
+
+#include "currennt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* C[M][N] = act(A[M][K] * B[N][K]^T + bias[N]);  K % 8 == 0, N % 32 == 0;  act: 0 tanh, 1 logistic, 2 identity */
+int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K,
+                   const float *bias, int act);
+/* C[M][N] = A[K][M]^T * B[K][N];  M % 32 == 0, N % 32 == 0 */
+int cn_dbg_gemm_tn(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,6 +30,8 @@ EXPORTS = [
     "cn_loss_eval", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
+    # include/currennt_hip_debug.h
+    "cn_dbg_gemm_nt", "cn_dbg_gemm_tn",
 ]
 
 
@@ -100,6 +102,8 @@ def load_library():
     L.cn_ctx_timing_enable.argtypes = [vp, ci]
     L.cn_ctx_timing_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.cn_ctx_timing_reset.argtypes = [vp]
+    L.cn_dbg_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci]
+    L.cn_dbg_gemm_tn.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     _LIB = L
     return L
 

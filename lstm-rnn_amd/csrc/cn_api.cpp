@@ -7,6 +7,7 @@
 //   softmax forward SoftmaxLayer.cu:250-315 backward :317-353
 //   post output     MulticlassClassificationLayer.cu:159-240, SsePostOutputLayer.cu:114-155
 #include "cn_internal.h"
+#include "../../include/currennt_hip_debug.h"
 
 #include <cstdio>
 #include <cstring>
@@ -848,6 +849,59 @@ int cn_ctx_timing_reset(cn_ctx *ctx)
         HIP_CHECK(hipSetDevice(ctx->device));
         timing_collect(ctx);
         for (int k = 0; k < KC_COUNT; ++k) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel-level test hooks (include/currennt_hip_debug.h)
+// ---------------------------------------------------------------------------------------------
+int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K, const float *bias, int act)
+{
+    if (!ctx || !A || !B || !C) { g_last_error = "cn_dbg_gemm_nt: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (K % 8 || N % 32) throw cn_error(CN_ERR_SHAPE, "cn_dbg_gemm_nt: K must be a multiple of 8 and N of 32");
+        const size_t e = ctx->esz();
+        float *dA, *dB, *dC, *dbias = nullptr; void *oA, *oB;
+        HIP_CHECK(hipMalloc((void **)&dA, (size_t)M * K * 4)); HIP_CHECK(hipMalloc((void **)&dB, (size_t)N * K * 4));
+        HIP_CHECK(hipMalloc((void **)&dC, (size_t)M * N * 4));
+        HIP_CHECK(hipMalloc(&oA, (size_t)M * K * e)); HIP_CHECK(hipMalloc(&oB, (size_t)N * K * e));
+        HIP_CHECK(hipMemcpyAsync(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(dB, B, (size_t)N * K * 4, hipMemcpyHostToDevice, ctx->stream));
+        if (bias) { HIP_CHECK(hipMalloc((void **)&dbias, (size_t)N * 4)); HIP_CHECK(hipMemcpyAsync(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream)); }
+        launch_pad_convert(ctx->stream, ctx->f32, dA, M, K, oA, K);
+        launch_pad_convert(ctx->stream, ctx->f32, dB, N, K, oB, K);
+        GemmNT g{}; g.A = oA; g.lda = K; g.B = oB; g.ldb = K; g.C = dC; g.ldc = N; g.bias = dbias; g.act = act; g.M = M; g.N = N; g.K = K;
+        launch_gemm_nt(ctx->stream, ctx->f32, g);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(oA); hipFree(oB); hipFree(dbias);
+    });
+}
+
+int cn_dbg_gemm_tn(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K)
+{
+    if (!ctx || !A || !B || !C) { g_last_error = "cn_dbg_gemm_tn: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        if (M % 32 || N % 32) throw cn_error(CN_ERR_SHAPE, "cn_dbg_gemm_tn: M and N must be multiples of 32");
+        const size_t e = ctx->esz();
+        float *dA, *dB, *dC; void *oA, *oB;
+        HIP_CHECK(hipMalloc((void **)&dA, (size_t)M * K * 4)); HIP_CHECK(hipMalloc((void **)&dB, (size_t)N * K * 4));
+        HIP_CHECK(hipMalloc((void **)&dC, (size_t)M * N * 4));
+        HIP_CHECK(hipMalloc(&oA, (size_t)M * K * e)); HIP_CHECK(hipMalloc(&oB, (size_t)N * K * e));
+        HIP_CHECK(hipMemcpyAsync(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(dB, B, (size_t)N * K * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemsetAsync(dC, 0, (size_t)M * N * 4, ctx->stream));
+        launch_pad_convert(ctx->stream, ctx->f32, dA, K, M, oA, M);
+        launch_pad_convert(ctx->stream, ctx->f32, dB, K, N, oB, N);
+        GemmTN g{}; g.A = oA; g.lda = M; g.B = oB; g.ldb = N; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        launch_gemm_tn(ctx->stream, ctx->f32, g);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(oA); hipFree(oB);
     });
 }
 

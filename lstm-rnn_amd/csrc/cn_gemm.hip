@@ -43,10 +43,11 @@ __device__ __forceinline__ void mma32(f32x16 &acc, const u32x4 &a, const u32x4 &
     if constexpr (F32) {
         // K order inside the group is permuted identically for A and B (lane half h holds
         // k = 4h..4h+3), which leaves the dot product unchanged.
+        // (bit_cast the whole vector: a bit_cast of a single ext_vector element picks element 0)
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[i]),
-                                                       __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[i], acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
@@ -168,6 +169,12 @@ void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
     if (g.M <= 0 || g.N <= 0) return;
     int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
     int nwg = tiles_m * tiles_n;
+    static bool attr_set = false;
+    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr_set = true;
+    }
     if (f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
     else     hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
 }
@@ -320,6 +327,12 @@ void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
     if (splits < 1) splits = 1;
     int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
     splits = (g.K + kchunk - 1) / kchunk;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TnGeom<true>::LDS);
+        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TnGeom<false>::LDS);
+        attr_set = true;
+    }
     if (f32) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(ntiles * splits), dim3(256), TnGeom<true>::LDS, s, g, tiles_n, ntiles, kchunk);
     else     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(ntiles * splits), dim3(256), TnGeom<false>::LDS, s, g, tiles_n, ntiles, kchunk);
 }

@@ -52,10 +52,11 @@ template <bool F32>
 __device__ __forceinline__ void mma16(f32x4 &acc, const u32x4 &a, const u32x4 &b)
 {
     if constexpr (F32) {
+        // (bit_cast the whole vector: a bit_cast of a single ext_vector element picks element 0)
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a[i]),
-                                                       __builtin_bit_cast(float, b[i]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[i], acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                       __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
