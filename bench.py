@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""bench.py -- train frames/sec of the CURRENNT LSTM hot path on MI355X.
+
+Metric (BASELINE.json): train frames/sec (node), 3x250 BLSTM 39->183, at 1/2/4/8 MI355X.
+A step = one fraction (parallel_sequences sequences) through
+    load (resident in HBM) -> forward -> loss -> backward (all weight gradients) -> [all-reduce] -> SGD update
+i.e. Optimizer::_processDataSet's loop body with --stochastic semantics (Optimizer.cu:46-97).
+
+One process per GPU (torch.distributed / RCCL when launched with --nproc-per-node N); the PS
+sequences of a fraction are independent, so ranks take disjoint sequences (weak scaling: PS per GPU
+is fixed) and meet only in one all-reduce(SUM) of the flat weightUpdates arena.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+# SURVEY.md section 8(d) workloads.  "size" is the CURRENNT JSON size (units of both directions).
+WORKLOADS = {
+    # reading A: the repo's own TIMIT recipe uses "size": 250 = 125 units per direction
+    "timit_3x250_blstm_H125": dict(P=39, hidden=[("blstm", 250)] * 3, C=183),
+    # reading B: Graves ASRU'13 literal, 250 units per direction = CURRENNT "size": 500
+    "timit_3x500_blstm_H250": dict(P=39, hidden=[("blstm", 500)] * 3, C=183),
+    # BASELINE.json configs[0] topology
+    "timit_1x128_lstm": dict(P=39, hidden=[("lstm", 128)], C=183),
+}
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
+
+
+def net_desc(P, hidden, C):
+    layers = [{"name": "input", "type": "input", "size": P}]
+    for i, (t, s) in enumerate(hidden):
+        layers.append({"name": "%s_%d" % (t, i + 1), "type": t, "size": s, "bias": 1.0})
+    layers.append({"name": "output", "type": "softmax", "size": C, "bias": 1.0})
+    layers.append({"name": "postoutput", "type": "multiclass_classification", "size": C})
+    return layers
+
+
+def make_weights(layers, seed):
+    """uniform [-0.1, 0.1] (Configuration.cpp:186-187) from a seeded generator, flat layout split like the JSON."""
+    rng = np.random.RandomState(seed)
+    out, prev = {}, None
+    for d in layers:
+        t, L = d["type"], d["size"]
+        if t in ("lstm", "blstm"):
+            P, H = prev["size"], L // (2 if t == "blstm" else 1)
+            out[d["name"]] = {"input": rng.uniform(-.1, .1, 4 * L * P).astype(np.float32),
+                              "bias": rng.uniform(-.1, .1, 4 * L).astype(np.float32),
+                              "internal": rng.uniform(-.1, .1, 4 * L * H + 3 * L).astype(np.float32)}
+        elif t == "softmax":
+            out[d["name"]] = {"input": rng.uniform(-.1, .1, L * prev["size"]).astype(np.float32),
+                              "bias": rng.uniform(-.1, .1, L).astype(np.float32), "internal": np.zeros(0, np.float32)}
+        prev = d
+    return out
+
+
+def synth_fraction(pkg, rng, PS, P, C, tmin, tmax):
+    """i.i.d. N(0,1) features, uniform targets, lengths U[tmin,tmax] sorted ascending (DataSet.cpp:603-605)."""
+    lens = np.sort(rng.randint(tmin, tmax + 1, PS))
+    xs = [rng.randn(n, P).astype(np.float32) for n in lens]
+    ts = [rng.randint(0, C, n).astype(np.int32) for n in lens]
+    return pkg.make_fraction(xs, ts, PS)
+
+
+def flops_per_frame(P, hidden, C):
+    """F_lstm = dirs*8H*[(P+H)*2 + H + (first?0:P)], softmax 6*C*P."""
+    total, first, prev = 0.0, True, P
+    for t, size in hidden:
+        dirs = 2 if t == "blstm" else 1
+        H = size // dirs
+        total += dirs * 8 * H * ((prev + H) * 2 + H + (0 if first else prev))
+        first, prev = False, size
+    return total + 6 * C * prev
+
+
+def rec_algorithmic(hidden):
+    """per real frame: HBM bytes of the fused cell kernels (44 B fwd / 64 B bwd per unit-frame,
+    SURVEY 8(a) rows a3/a6) and recurrent MFMA flops (2*4*H*H per direction, fwd and bwd each)."""
+    units = sum(s for _, s in hidden)
+    fl = sum((2 if t == "blstm" else 1) * 8 * (s // (2 if t == "blstm" else 1)) ** 2 for t, s in hidden)
+    return 44.0 * units, 64.0 * units, fl
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="timit_3x250_blstm_H125", choices=sorted(WORKLOADS))
+    ap.add_argument("--parallel-sequences", type=int, default=50, help="per GPU (examples/*/config.cfg: 50)")
+    ap.add_argument("--tmin", type=int, default=250)
+    ap.add_argument("--tmax", type=int, default=350)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--momentum", type=float, default=0.9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-pass", action="store_true")
+    ap.add_argument("--also", default="", help="comma list of extra workloads measured and reported under 'also'")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = ge.load_package()
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev)
+    prec = pkg.PREC_BF16 if args.precision == "bf16" else pkg.PREC_F32
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def run_workload(name, steps, warmup, roofline_pass):
+        wl = WORKLOADS[name]
+        P, C, hidden, PS = wl["P"], wl["C"], wl["hidden"], args.parallel_sequences
+        layers = net_desc(P, hidden, C)
+        weights = make_weights(layers, 1234)                       # identical replicas on every rank
+        rng = np.random.RandomState(1234 + rank)                   # seed = 1234 + rank
+        nfrac = 4
+        fracs = [synth_fraction(pkg, rng, PS, P, C, args.tmin, args.tmax) for _ in range(nfrac)]
+        net = pkg.NeuralNetwork(layers, weights, PS, args.tmax, precision=prec, device=local_rank,
+                                stream=stream.cuda_stream)
+        # fractions resident in HBM (torch owns the device memory)
+        dfr, keep = [], []
+        for f in fracs:
+            x = torch.from_numpy(f["inputs"]).to(dev)
+            pt = torch.from_numpy(f["patTypes"]).to(dev)
+            tc = torch.from_numpy(f["targetClasses"]).to(dev)
+            keep += [x, pt, tc]
+            dfr.append({"T": f["T"], "Tmin": f["Tmin"], "numSeqs": f["numSeqs"], "inputPatternSize": P,
+                        "outputPatternSize": C, "inputs": x.data_ptr(), "patTypes": pt.data_ptr(),
+                        "targetClasses": tc.data_ptr(), "frames": pkg.fraction.real_frames(f)})
+        wptr, gptr, dptr, count = net.param_arena()
+        grads = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device=dev) if world > 1 else None
+
+        def step(i):
+            f = dfr[i % nfrac]
+            net.load_sequences_resident(f)
+            net.compute_forward_pass()
+            net.loss_accumulate()
+            net.compute_backward_pass()
+            if world > 1:
+                dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+            net.update_weights_fused(args.lr, args.momentum)
+            return f["frames"]
+
+        for i in range(warmup):
+            step(i)
+        barrier()
+        t0 = time.perf_counter()
+        frames = 0
+        for i in range(steps):
+            frames += step(warmup + i)
+        barrier()
+        dt = time.perf_counter() - t0
+        err_sum, correct = net.loss_read()
+        res = {"frames": frames, "seconds": dt, "error_sum": err_sum, "weights": int(count)}
+        if roofline_pass:
+            # second pass of the same steps with hipEvents around every kernel class, on the ctx stream
+            net.timing_enable(True); net.timing_reset()
+            fr2 = 0
+            for i in range(steps):
+                fr2 += step(warmup + i)
+            net.synchronize()
+            res["timing"] = net.timing_read(); res["timing_frames"] = fr2
+            net.timing_enable(False)
+        net.close()
+        del keep
+        return res, wl
+
+    res, wl = run_workload(args.workload, args.steps, args.warmup, not args.no_roofline_pass)
+    t = torch.tensor([res["seconds"], float(res["frames"])], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        seconds, frames = float(tmax[0]), float(tsum[1])
+    else:
+        seconds, frames = res["seconds"], float(res["frames"])
+    value = frames / seconds
+
+    also = {}
+    for name in [a for a in args.also.split(",") if a]:
+        r2, _ = run_workload(name, args.steps, args.warmup, False)
+        t2 = torch.tensor([r2["seconds"], float(r2["frames"])], dtype=torch.float64, device=dev)
+        if world > 1:
+            a = t2.clone(); dist.all_reduce(a, op=dist.ReduceOp.MAX)
+            b = t2.clone(); dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            also[name] = float(b[1]) / float(a[0])
+        else:
+            also[name] = r2["frames"] / r2["seconds"]
+
+    if rank == 0:
+        out = {
+            "metric": "train frames/sec (node), 3x250 BLSTM 39->183", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * seconds / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": args.workload, "topology": "39 -> " + " -> ".join("%s%d" % h for h in wl["hidden"]) + " -> softmax183",
+                       "parallel_sequences_per_gpu": args.parallel_sequences, "seq_len": "U[%d,%d]" % (args.tmin, args.tmax),
+                       "weights": res["weights"], "update": "stochastic momentum SGD every fraction",
+                       "parallelism": "dp%d over sequences" % world},
+        }
+        if "timing" in res:
+            tm, fr = res["timing"], res["timing_frames"]
+            b_fwd, b_bwd, fl_rec = rec_algorithmic(wl["hidden"])
+            nl_f, nl_b = max(1, tm["rec_fwd"][1]), max(1, tm["rec_bwd"][1])
+            dom = "lstm_bwd_kernel" if tm["rec_bwd"][0] >= tm["rec_fwd"][0] else "lstm_fwd_kernel"
+            ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if dom == "lstm_bwd_kernel" else (tm["rec_fwd"][0], nl_f, b_fwd)
+            nlayers = len(wl["hidden"])
+            frames_per_launch = fr / (nl / 1.0) * 1.0            # every launch sees one fraction, one layer
+            bytes_per_launch = bpf / nlayers * frames_per_launch
+            avg_s = ms / nl * 1e-3
+            ach = bytes_per_launch / avg_s / 1e9
+            total_ms = sum(v[0] for v in tm.values())
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                               "avg_launch_ms": ms / nl, "launches": nl,
+                               "note": "latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
+                                       "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items())}
+            fpf = flops_per_frame(wl["P"], wl["hidden"], wl["C"])
+            gemm_ms = tm["gemm_wide"][0] + tm["gemm_grad"][0]
+            rec_ms = tm["rec_fwd"][0] + tm["rec_bwd"][0]
+            gemm_fl = (fpf - fl_rec * 2) * fr
+            out["roofline_mfma"] = {"gate_gemms_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None,
+                                    "recurrent_tflops": fl_rec * 2 * fr / (rec_ms * 1e-3) / 1e12 if rec_ms else None,
+                                    "whole_step_tflops": fpf * value / 1e12, "peak": PEAK_MFMA_TFLOPS[args.precision],
+                                    "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
+        if also:
+            out["also"] = {k: {"value": v, "unit": "frames/s"} for k, v in also.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, wl, args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pkg, wl, args):
+    """The oracle (scalar fp32 restatement of the reference's Cpu path, 1 thread like its Thrust-host build)
+    timed on a bounded sample of the same workload: one fraction of 16 sequences."""
+    orc = ge.load_oracle()
+    PS = 16
+    layers = net_desc(wl["P"], wl["hidden"], wl["C"])
+    weights = make_weights(layers, 1234)
+    rng = np.random.RandomState(99)
+    # keep the sample near 10-20 s of CPU work: ~5k frames of reading A
+    tlo, thi = (args.tmin, args.tmax) if sum(s for _, s in wl["hidden"]) <= 750 else (60, 90)
+    frac = synth_fraction(pkg, rng, PS, wl["P"], wl["C"], tlo, thi)
+    net = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    t0 = time.perf_counter()
+    net.load_sequences(frac); net.compute_forward_pass(); net.calculate_error(); net.count_correct_classifications()
+    net.compute_backward_pass(); net.update_weights(args.lr, args.momentum)
+    dt = time.perf_counter() - t0
+    frames = pkg.fraction.real_frames(frac)
+    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "1 fraction, %d sequences U[%d,%d] (%d frames), same topology, fp32, %.1f s" % (PS, tlo, thi, frames, dt)}
+
+
+if __name__ == "__main__":
+    main()

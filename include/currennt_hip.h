@@ -129,6 +129,11 @@ int  cn_layer_weight_count(const cn_layer *layer);
  * Error texts follow the reference ("Input layer size of X != data input pattern size of Y"). */
 int  cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
 
+/* The same with every pointer of `fraction` addressing DEVICE memory of the context's GPU (inputs already
+ * resident in HBM: a prefetching data loader uploads fraction k+1 while fraction k trains).  Copies are
+ * device-to-device on the ctx stream; nothing synchronises. */
+int  cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
+
 /* Layer::computeForwardPass / computeBackwardPass (Layer.hpp:165-170).  Backward of a trainable
  * layer consumes its outputErrors, writes the preceding trainable layer's outputErrors
  * (LstmLayer.cu:990-1009, FeedForwardLayer.cu:188-198) and its own weightUpdates. */
@@ -139,6 +144,12 @@ int  cn_layer_backward(cn_layer *layer);
  * countCorrectClassifications() (MulticlassClassificationLayer.cu:159-177,194-213).
  * `correct` may be NULL; it is set to -1 for layers without a class count.        [sync] */
 int  cn_loss_eval(cn_layer *post_output, float *error, int *correct);
+
+/* Asynchronous form for the training loop: add this fraction's error / #correct to device-side
+ * accumulators (Optimizer.cu:46-55 sums them per epoch on the host, two blocking D2H copies per
+ * fraction) and read the sums once with cn_loss_read ([sync]; `reset` != 0 clears them). */
+int  cn_loss_accumulate(cn_layer *post_output);
+int  cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset);
 
 /* ---- weights (TrainableLayer.cu:65-101,211-248) --------------------------------------------- */
 

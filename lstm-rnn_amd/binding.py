@@ -26,8 +26,8 @@ BUF = {
 EXPORTS = [
     "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_last_error", "cn_device_arch",
     "cn_version", "cn_layer_create", "cn_layer_destroy", "cn_layer_size", "cn_layer_kind_of",
-    "cn_layer_weight_count", "cn_fraction_load", "cn_layer_forward", "cn_layer_backward",
-    "cn_loss_eval", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors",
+    "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_layer_forward",
+    "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
     # include/currennt_hip_debug.h
@@ -87,6 +87,9 @@ def load_library():
     L.cn_layer_kind_of.argtypes = [vp]
     L.cn_layer_weight_count.argtypes = [vp]
     L.cn_fraction_load.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
+    L.cn_fraction_load_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
+    L.cn_loss_accumulate.argtypes = [vp]
+    L.cn_loss_read.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_long), ci]
     L.cn_layer_forward.argtypes = [vp]
     L.cn_layer_backward.argtypes = [vp]
     L.cn_loss_eval.argtypes = [vp, C.POINTER(cf), C.POINTER(ci)]

@@ -61,7 +61,8 @@ struct cn_ctx {
     bool loaded = false;
     char *d_pat = nullptr;
     int *d_tcls = nullptr;
-    float *d_loss = nullptr;      // [2]
+    float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
+    float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
 
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
@@ -409,7 +410,9 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-        HIP_CHECK(hipMalloc((void **)&c->d_loss, 2 * sizeof(float)));
+        HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
+        HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
+        c->d_loss_acc = c->d_loss + 2;
     });
     if (rc != CN_OK) { delete c; return rc; }
     *out = c;
@@ -561,9 +564,10 @@ int cn_layer_weight_count(const cn_layer *layer) { return layer ? layer->nw : CN
 // ---------------------------------------------------------------------------------------------
 // fraction
 // ---------------------------------------------------------------------------------------------
-int cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f, bool resident)
 {
     if (!ctx || !input || !f) { g_last_error = "cn_fraction_load: NULL argument"; return CN_ERR_BAD_ARG; }
+    const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     return guarded([&] {
         HIP_CHECK(hipSetDevice(ctx->device));
         if (input->kind != CN_LAYER_INPUT) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `input` is not an input layer");
@@ -584,21 +588,30 @@ int cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const 
         finalize(ctx);
         const size_t N = (size_t)T * ctx->PS;
         Timed tm(ctx, KC_OTHER);
-        HIP_CHECK(hipMemcpyAsync(ctx->d_pat, f->pat_types, N, hipMemcpyHostToDevice, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(input->stage_in, f->inputs, N * input->size * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ctx->d_pat, f->pat_types, N, kind, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(input->stage_in, f->inputs, N * input->size * sizeof(float), kind, ctx->stream));
         if (post_output) {
             if (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
                 if (!f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
-                HIP_CHECK(hipMemcpyAsync(ctx->d_tcls, f->target_classes, N * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(ctx->d_tcls, f->target_classes, N * sizeof(int), kind, ctx->stream));
             } else {
                 if (!f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
-                HIP_CHECK(hipMemcpyAsync(post_output->targets, f->targets, N * post_output->size * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+                HIP_CHECK(hipMemcpyAsync(post_output->targets, f->targets, N * post_output->size * sizeof(float), kind, ctx->stream));
             }
         }
         launch_pad_convert(ctx->stream, ctx->f32, input->stage_in, (int)N, input->size, input->out_op, input->Lp);
         ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->numSeqs = f->num_sequences;
         ctx->loaded = true;
     });
+}
+
+int cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    return fraction_load(ctx, input, post_output, f, false);
+}
+int cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    return fraction_load(ctx, input, post_output, f, true);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -650,9 +663,9 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
         {
             Timed tm(c, KC_OTHER);
             if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-                launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss);
+                launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
             else
-                launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss);
+                launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss, true);
         }
         float h[2];
         HIP_CHECK(hipMemcpyAsync(h, c->d_loss, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -662,6 +675,37 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
             int cc; memcpy(&cc, &h[1], sizeof(int));
             *correct = (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) ? cc : -1;
         }
+    });
+}
+
+int cn_loss_accumulate(cn_layer *post)
+{
+    if (!post) { g_last_error = "cn_loss_accumulate: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = post->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        if (!post->post) throw cn_error(CN_ERR_BAD_ARG, "cn_loss_accumulate: not a post output layer");
+        require_loaded(c);
+        cn_layer *o = post->prev;
+        Timed tm(c, KC_OTHER);
+        if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
+            launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
+        else
+            launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss_acc, false);
+    });
+}
+
+int cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
+{
+    if (!ctx) { g_last_error = "cn_loss_read: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        float h[2];
+        HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        if (reset) HIP_CHECK(hipMemsetAsync(ctx->d_loss_acc, 0, sizeof(h), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (error_sum) *error_sum = h[0];
+        if (correct_sum) { int cc; memcpy(&cc, &h[1], sizeof(int)); *correct_sum = cc; }
     });
 }
 

@@ -388,9 +388,9 @@ __global__ void mcc_rows_kernel(const float *y, const int *tcls, int N, int L, i
         atomicAdd((int *)&loss2[1], c);
     }
 }
-void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2)
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2, bool reset)
 {
-    hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+    if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
     if (N <= 0) return;
     int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(mcc_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, loss2);
@@ -428,9 +428,9 @@ __global__ void sse_rows_kernel(const float *y, const float *tgt, const char *pa
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&loss2[0], 0.5f * ((sl[0] + sl[1]) + (sl[2] + sl[3])));   // :121
 }
-void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2)
+void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2, bool reset)
 {
-    hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+    if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
     if (N <= 0) return;
     int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(sse_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, loss2);

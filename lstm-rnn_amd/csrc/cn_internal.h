@@ -84,10 +84,10 @@ void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, 
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
 // multiclass_classification: loss/#correct reduction and error injection
-void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/);
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/, bool reset);
 void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
 // sse
-void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2);
+void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2, bool reset);
 void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err);
 // UpdateWeightFn over a flat range
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);

@@ -197,6 +197,30 @@ class NeuralNetwork:
         self.T, self.Tmin = f.max_seq_length, f.min_seq_length
         self.N = self.T * self.PS
 
+    def load_sequences_resident(self, dfrac):
+        """Like load_sequences, but `dfrac` holds DEVICE pointers (ints) for inputs / patTypes /
+        targetClasses / targets: the fraction is already resident in HBM."""
+        f = B.Fraction()
+        f.max_seq_length, f.min_seq_length = int(dfrac["T"]), int(dfrac["Tmin"])
+        f.num_sequences = int(dfrac.get("numSeqs", self.PS))
+        f.input_pattern_size = int(dfrac["inputPatternSize"])
+        f.output_pattern_size = int(dfrac.get("outputPatternSize", self.layers[-1].size))
+        f.pat_types, f.inputs = dfrac["patTypes"], dfrac["inputs"]
+        f.target_classes, f.targets = dfrac.get("targetClasses"), dfrac.get("targets")
+        B.check(self.lib.cn_fraction_load_resident(self.ctx, self.layers[0].handle, self.layers[-1].handle,
+                                                   C.byref(f)), self.ctx)
+        self.T, self.Tmin = f.max_seq_length, f.min_seq_length
+        self.N = self.T * self.PS
+
+    def loss_accumulate(self):
+        """Add this fraction's error / #correct to the device-side epoch sums (no host sync)."""
+        B.check(self.lib.cn_loss_accumulate(self.layers[-1].handle), self.ctx)
+
+    def loss_read(self, reset=True):
+        err, cor = C.c_float(), C.c_long()
+        B.check(self.lib.cn_loss_read(self.ctx, C.byref(err), C.byref(cor), 1 if reset else 0), self.ctx)
+        return float(err.value), int(cor.value)
+
     def compute_forward_pass(self):                                                    # NeuralNetwork.cpp:168-173
         for lay in self.layers:
             B.check(self.lib.cn_layer_forward(lay.handle), self.ctx)
