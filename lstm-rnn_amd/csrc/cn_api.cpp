@@ -10,6 +10,7 @@
 #include "../../include/currennt_hip_debug.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -71,6 +72,7 @@ struct cn_ctx {
 
     // timing
     bool timing = false;
+    int rpl_override = 0;
     struct Span { hipEvent_t a, b; };
     std::vector<Span> spans[KC_COUNT];
     std::vector<hipEvent_t> free_events;
@@ -248,6 +250,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.acts = l->acts; r.cell = l->cell; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
+    r.rpl_override = c->rpl_override;
 }
 
 void lstm_forward(cn_layer *l)
@@ -410,6 +413,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
@@ -779,26 +783,26 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
         const int R = layer->dirs * 4 * layer->Hp, Hp = layer->Hp, H = layer->H;
         switch (which) {
         case CN_BUF_OUTPUTS:
-            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, N, layer->size, tmp, layer->size, 0);
+            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, 1, N, layer->size, tmp, layer->size, 0);
             else if (layer->lstm)
-                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, N, H, tmp, layer->size, d * H);
-            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, N, layer->size, tmp, layer->size, 0);
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H);
+            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0);
             else throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputs");
             break;
         case CN_BUF_OUTPUT_ERRORS:
             if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputErrors");
             if (layer->lstm)
-                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, N, H, tmp, layer->size, d * H);
-            else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, N, layer->size, tmp, layer->size, 0);
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H);
+            else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0);
             break;
         case CN_BUF_LSTM_CELL_STATES:
-            launch_unpad(c->stream, false, layer->cell, layer->Lp, dir * Hp, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, false, layer->cell, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0); break;
         case CN_BUF_LSTM_TMP_OUTPUTS:
-            launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, dir * Hp, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0); break;
         case CN_BUF_LSTM_NI_ACTS: case CN_BUF_LSTM_IG_ACTS: case CN_BUF_LSTM_FG_ACTS: case CN_BUF_LSTM_OG_ACTS:
-            launch_unpad(c->stream, false, layer->acts, R, (dir * 4 + (which - CN_BUF_LSTM_NI_ACTS)) * Hp, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, false, layer->acts, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_ACTS), 4, N, H, tmp, H, 0); break;
         case CN_BUF_LSTM_NI_DELTAS: case CN_BUF_LSTM_IG_DELTAS: case CN_BUF_LSTM_FG_DELTAS: case CN_BUF_LSTM_OG_DELTAS:
-            launch_unpad(c->stream, opbf, layer->delta_op, R, (dir * 4 + (which - CN_BUF_LSTM_NI_DELTAS)) * Hp, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, opbf, layer->delta_op, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_DELTAS), 4, N, H, tmp, H, 0); break;
         default:
             hipFree(tmp);
             throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: unknown buffer");

@@ -52,8 +52,10 @@ __global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *W
     const long total = nIn + nRec + nB + nPe;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         if (idx < nIn) {
+            // packed gate row r = (d*Hp + j)*4 + gate: a lane of the recurrent kernels moves n/i/f/o of
+            // one unit with a single 16-byte access
             const int r = idx / Pp, pc = idx % Pp;
-            const int d = r / (4 * Hp), gg = (r / Hp) % 4, j = r % Hp;
+            const int d = r / (4 * Hp), j = (r / 4) % Hp, gg = r % 4;
             const int i = unpad_col(pc, P, g.prevH, g.prevHp, g.prevDirs);
             float v = 0.f;
             if (j < H && i >= 0) v = w[(long)gg * L * P + (long)d * H * P + (long)j * P + i];
@@ -67,10 +69,10 @@ __global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *W
             if (j < H && i < H)
                 v = w[4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i];
             st_op<F32>(Wrec, ((long)d * 4 * Hp + gg * Hp + j) * Hp + i, v);
-            st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + gg * Hp + j, v);
+            st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + 4 * j + gg, v);
         } else if (idx < nIn + nRec + nB) {
             const int k = idx - nIn - nRec;
-            const int d = k / (4 * Hp), gg = (k / Hp) % 4, j = k % Hp;
+            const int d = k / (4 * Hp), j = (k / 4) % Hp, gg = k % 4;
             bias_p[k] = (j < H) ? bias * w[4L * L * P + gg * L + d * H + j] : 0.f;   // LstmLayer.cu:97-100
         } else {
             const int k = idx - nIn - nRec - nB;
@@ -101,15 +103,15 @@ __global__ void lstm_unpack_kernel(LstmGeom g, const float *dWin, const float *d
         if (idx < nIn) {
             const int gg = idx / ((long)L * P), rem = idx % ((long)L * P);
             const int blk = rem / P, i = rem % P, d = blk / H, j = blk % H;
-            v = dWin[((long)(d * 4 + gg) * Hp + j) * Pp + pad_col(i, g.prevH, g.prevHp)];
+            v = dWin[(((long)d * Hp + j) * 4 + gg) * Pp + pad_col(i, g.prevH, g.prevHp)];
         } else if (idx < nIn + nB) {
             const int k = idx - nIn, gg = k / L, blk = k % L, d = blk / H, j = blk % H;
-            v = dbias[(d * 4 + gg) * Hp + j];
+            v = dbias[(d * Hp + j) * 4 + gg];
         } else if (idx < nIn + nB + nRec) {
             const long k = idx - nIn - nB;
             const int gg = k / ((long)L * H), rem = k % ((long)L * H);
             const int blk = rem / H, i = rem % H, d = blk / H, j = blk % H;
-            v = dWrec[((long)d * 4 * Hp + gg * Hp + j) * Hp + i];
+            v = dWrec[((long)d * 4 * Hp + 4 * j + gg) * Hp + i];
         } else {
             const int k = idx - nIn - nB - nRec, pp = k / L, blk = k % L, d = blk / H, j = blk % H;
             v = dpeep[(d * 3 + pp) * Hp + j];
@@ -195,23 +197,23 @@ void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P,
 }
 
 template <bool BF16>
-__global__ void unpad_kernel(const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0)
+__global__ void unpad_kernel(const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0)
 {
     const long total = (long)N * L;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / L; const int j = idx % L;
         float v;
-        if constexpr (BF16) v = (float)((const __bf16 *)src)[n * ld + col0 + j];
-        else v = ((const float *)src)[n * ld + col0 + j];
+        if constexpr (BF16) v = (float)((const __bf16 *)src)[n * ld + col0 + (long)j * cstride];
+        else v = ((const float *)src)[n * ld + col0 + (long)j * cstride];
         dst[n * ldd + dcol0 + j] = v;
     }
 }
-void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0)
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0)
 {
     long total = (long)N * L; if (total <= 0) return;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    if (src_is_bf16) hipLaunchKernelGGL(unpad_kernel<true>, dim3(blocks), dim3(256), 0, s, src, ld, col0, N, L, dst, ldd, dcol0);
-    else             hipLaunchKernelGGL(unpad_kernel<false>, dim3(blocks), dim3(256), 0, s, src, ld, col0, N, L, dst, ldd, dcol0);
+    if (src_is_bf16) hipLaunchKernelGGL(unpad_kernel<true>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0);
+    else             hipLaunchKernelGGL(unpad_kernel<false>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0);
 }
 
 __global__ void pad_f32_kernel(const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp)

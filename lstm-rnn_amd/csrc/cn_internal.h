@@ -43,18 +43,19 @@ struct LstmRec {
     int H, Hp, dirs, PS, T, Tmin;
     const char *pat;              // [T*PS]
     // forward
-    float *acts;                  // [N][dirs][4][Hp] fp32: pre-activations in, n/i/f/o activations out
+    float *acts;                  // [N][dirs][Hp][4] fp32: pre-activations in, n/i/f/o activations out (gate innermost)
     float *cell;                  // [N][dirs][Hp]    fp32
     void  *y_op;                  // [N][dirs*Hp]     op  (layer output, GEMM operand)
     const void *Wrec;             // [dirs][4*Hp][Hp] op  (k = source unit contiguous)
     const float *peep;            // [dirs][3][Hp]
     // backward
     const float *err;             // [N][dirs*Hp] fp32 outputErrors of this layer
-    void  *delta_op;              // [N][dirs][4][Hp] op
-    const void *WrecT;            // [dirs][Hp][4*Hp] op  (k = (gate, target unit) contiguous)
-    float *dbias;                 // [dirs][4][Hp] fp32 accumulators (pre-zeroed)
+    void  *delta_op;              // [N][dirs][Hp][4] op
+    const void *WrecT;            // [dirs][Hp][4*Hp] op  (k = 4*target unit + gate contiguous)
+    float *dbias;                 // [dirs][Hp][4] fp32 accumulators (pre-zeroed)
     float *dpeep;                 // [dirs][3][Hp]
     float bias;                   // JSON bias value (scales the bias gradient)
+    int rpl_override;             // 0 = choose sequences per lane from PS; 1/2/4 force it (tests)
 };
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
 void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
@@ -92,7 +93,7 @@ void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const 
 // UpdateWeightFn over a flat range
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
-void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int N, int L, float *dst, long ldd, int dcol0);
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0);
 // scatter host-provided [N][L] fp32 into a padded fp32 matrix (tests)
 void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp);
 

@@ -8,43 +8,51 @@
 //
 // MI355X design:
 //   * parallel sequences never interact inside a layer pass, so the PS sequences are cut into
-//     groups of 16 (one MFMA M-tile) and every (direction, sequence group) pair is one workgroup
-//     that walks all T steps on its own: no inter-workgroup communication, no grid barrier.
+//     small groups (4, 8 or 16 sequences, picked so that the groups spread over the 256 CUs) and
+//     every (direction, sequence group) pair is one workgroup that walks all T steps on its own:
+//     no inter-workgroup communication, no grid barrier.  The per-step cost is a dependency chain
+//     (LDS hand-off -> MFMA -> cell update -> LDS hand-off), so fewer sequences per workgroup
+//     means fewer cell updates per lane and a shorter step.
 //   * the four gates are packed into one tile row: wave w owns hidden units [16w, 16w+16) and
 //     the 4 gate tiles of those units, so after the MFMAs every lane holds n/i/f/o of one unit
-//     for 4 sequences and the cell update needs no cross-lane traffic.  Gate pre-activations from
-//     the N-wide input GEMM (bias already added) enter as the MFMA C operand.
+//     and the cell update needs no cross-lane traffic.  Gate pre-activations from the N-wide input
+//     GEMM (bias already added) enter as the MFMA C operand; they are stored [frame][unit][gate] so
+//     a lane moves them with one 16-byte access.
 //   * W_rec fragments stay in registers for the whole pass when 4*Hp*Hp operands fit one CU's
 //     register file (Hp <= 128), otherwise they are streamed from L2 every step.
 //   * y[t] (forward) / the four deltas (backward) are exchanged between the waves of the workgroup
 //     through a double-buffered LDS tile in MFMA A-operand order; cell state, forget-gate carry and
-//     the peephole/bias gradient sums never leave registers.
+//     the peephole/bias gradient sums never leave registers.  Operands of the next two steps are
+//     prefetched from HBM while the current step computes; the LDS barrier does not drain them.
 //   * fw/bw halves are written straight into the interleaved [N][2*Hp] layer output.
 #include "cn_internal.h"
 
 namespace cn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-#define EXP_LIMIT 88.722839f   // helpers/NumericLimits.cuh:41
+#define LOG2E 1.4426950408889634f
 
-// Logistic::fn (Logistic.cuh:33-44); the explicit clamps reproduce the reference's exact 0 / 1.
+// Logistic::fn (Logistic.cuh:33-44).  The reference clamps to exactly 0 / 1 beyond |x| >= 88.72; both
+// forms below reach the same limits without a branch (exp overflows to +inf -> 1/inf = 0; exp underflows
+// -> 1/(1+0) = 1).  F32: libm-grade expf and IEEE division; bf16 mode: v_exp_f32 / v_rcp_f32.
 template <bool F32>
 __device__ __forceinline__ float logistic(float x)
 {
-    float r;
-    if constexpr (F32) r = 1.0f / (1.0f + expf(-x));
-    else r = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-    r = (x >= EXP_LIMIT) ? 1.0f : r;
-    r = (x <= -EXP_LIMIT) ? 0.0f : r;
-    return r;
+    if constexpr (F32) return 1.0f / (1.0f + expf(-x));
+    else return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-LOG2E * x));
 }
 // Tanh::fn = Maxmin1::fn(2x) = 2*Logistic::fn(2x) - 1 (Tanh.cuh:33-36, Maxmin1.cuh:33-36)
 template <bool F32>
-__device__ __forceinline__ float tanh_ref(float x) { return 2.0f * logistic<F32>(2.0f * x) - 1.0f; }
-__device__ __forceinline__ float clip1(float e) { return e < -1.0f ? -1.0f : (e > 1.0f ? 1.0f : e); }   // limitedError.cuh:31-34
+__device__ __forceinline__ float tanh_ref(float x)
+{
+    if constexpr (F32) return 2.0f * (1.0f / (1.0f + expf(-2.0f * x))) - 1.0f;
+    else return __builtin_fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.0f * LOG2E * x)), -1.0f);
+}
+__device__ __forceinline__ float clip1(float e) { return fminf(fmaxf(e, -1.0f), 1.0f); }   // limitedError.cuh:31-34
 
 // one 64-byte K chunk of a 16x16 tile product: 32 bf16 (one MFMA) or 16 fp32 (four MFMAs; the K order
 // inside the chunk is permuted identically for A and B)
@@ -63,11 +71,6 @@ __device__ __forceinline__ void mma16(f32x4 &acc, const u32x4 &a, const u32x4 &b
     }
 }
 
-template <bool F32> __device__ __forceinline__ void st_op(void *base, long idx, float v)
-{
-    if constexpr (F32) ((float *)base)[idx] = v; else ((__bf16 *)base)[idx] = (__bf16)v;
-}
-
 // workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
 // stay in flight across it (a __syncthreads() would drain vmcnt every step)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -77,7 +80,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---------------------------------------------------------------------------------------------
 // HP  : padded units per direction when the W_rec fragments are register resident, 0 = stream W_rec
 // UG  : unit groups (of 16) per wave
-template <bool F32, int HP, int UG>
+// RPL : sequences per lane; a workgroup handles 4*RPL sequences: sequence s0 + 4*r + q sits in MFMA
+//       tile row 4*q + r (q = lane>>4, r < RPL), rows r >= RPL are zero padding
+template <bool F32, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,12 +95,12 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 16;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * (4 * RPL);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * Hp;           // acts row stride (floats)
     const long crow = (long)dirs * Hp;               // cell / y row stride (elements)
 
-    // zero both y tiles (y[prev] of the first processed step is 0)
+    // zero both y tiles (y[prev] of the first processed step is 0; padding rows stay 0)
     for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
 
     int unit[UG];
@@ -117,50 +122,51 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
         }
     }
 
-    float cst[UG][4];
-    float pre[UG][4][4];
-    char pt[4];
+    bool valid[RPL];
+    long soff[RPL];                                  // sequence offset inside a time step
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) { const int s = s0 + 4 * r + q; valid[r] = s < PS; soff[r] = valid[r] ? s : 0; }
+
+    float cst[UG][RPL];
 #pragma unroll
     for (int u = 0; u < UG; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cst[u][r] = 0.f;
+        for (int r = 0; r < RPL; ++r) cst[u][r] = 0.f;
 
-    auto prefetch = [&](int t) {
+    // two prefetch stages (steps it and it+1), addressed statically through the lambda parameters
+    f32x4 preA[UG][RPL], preB[UG][RPL];
+    char ptA[RPL], ptB[RPL];
+    auto prefetch = [&](int t, f32x4 (&pre)[UG][RPL], char (&pt)[RPL]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = s0 + 4 * q + r;
-            const bool valid = s < PS;
-            const long n = (long)t * PS + s;
-            pt[r] = valid ? p.pat[n] : 0;
+        for (int r = 0; r < RPL; ++r) {
+            const long n = (long)t * PS + soff[r];
+            pt[r] = valid[r] ? p.pat[n] : 0;
 #pragma unroll
-            for (int u = 0; u < UG; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    pre[u][g][r] = valid ? p.acts[n * arow + (d * 4 + g) * Hp + unit[u]] : 0.f;
+            for (int u = 0; u < UG; ++u) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                pre[u][r] = valid[r] ? *(const f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) : z;
+            }
         }
     };
 
-    prefetch(d ? T - 1 : 0);
-    lds_barrier();
-
-    for (int it = 0; it < T; ++it) {
+    auto step = [&](int it, f32x4 (&pre)[UG][RPL], char (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
         const char *ycur = smem + (it & 1) * 16 * pitch;
         char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
 
         f32x4 acc[UG][4];
-        char ptc[4];
+        char ptc[RPL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ptc[r] = pt[r];
+        for (int r = 0; r < RPL; ++r) ptc[r] = pt[r];
 #pragma unroll
         for (int u = 0; u < UG; ++u)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[u][g][r] = pre[u][g][r];
+                for (int r = 0; r < 4; ++r) acc[u][g][r] = (r < RPL) ? pre[u][r < RPL ? r : 0][g] : 0.f;
 
-        if (it + 1 < T) prefetch(d ? t - 1 : t + 1);
+        if (it + 2 < T) prefetch(d ? t - 2 : t + 2, pre, pt);
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
         if constexpr (RES) {
@@ -187,15 +193,13 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
             }
         }
 
-        // cell update: C/D map of the 16x16 MFMA: col = lane&15 (unit), row = 4*(lane>>4)+reg (sequence)
+        // cell update: C/D map of the 16x16 MFMA: col = lane&15 (unit), row = 4*(lane>>4)+reg
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = s0 + 4 * q + r;
-                const bool valid = s < PS;
-                const bool dummy = !valid || (check && ptc[r] == 0);
-                const long n = (long)t * PS + s;
+            for (int r = 0; r < RPL; ++r) {
+                const bool dummy = !valid[r] || (check && ptc[r] == 0);
+                const long n = (long)t * PS + soff[r];
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
                 const float ni = tanh_ref<F32>(acc[u][0][r]);
@@ -209,37 +213,53 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
                 cst[u][r] = co;
                 if constexpr (F32) *(float *)(ynxt + (4 * q + r) * pitch + unit[u] * 4) = yo;
                 else *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit[u] * 2) = (__bf16)yo;
-                if (valid) {
+                if (valid[r]) {
                     if (!dummy) {
-                        float *ap = p.acts + n * arow + (long)d * 4 * Hp + unit[u];
-                        ap[0] = ni; ap[Hp] = ig; ap[2 * Hp] = fg; ap[3 * Hp] = og;
+                        const f32x4 av = {ni, ig, fg, og};
+                        *(f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) = av;
                     }
                     p.cell[n * crow + d * Hp + unit[u]] = co;
-                    st_op<F32>(p.y_op, n * crow + d * Hp + unit[u], yo);
+                    if constexpr (F32) ((float *)p.y_op)[n * crow + d * Hp + unit[u]] = yo;
+                    else ((__bf16 *)p.y_op)[n * crow + d * Hp + unit[u]] = (__bf16)yo;
                 }
             }
         }
         lds_barrier();
+    };
+
+    prefetch(d ? T - 1 : 0, preA, ptA);
+    if (T > 1) prefetch(d ? T - 2 : 1, preB, ptB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA, ptA);
+        if (it + 1 < T) step(it + 1, preB, ptB);
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward: e[t] = err[t] + Wrec delta[next(t)]; ComputeBlockErrorsFn; bias/peephole gradient sums
 // ---------------------------------------------------------------------------------------------
-template <bool F32, int HP, int UG>
+template <int UG, int RPL> struct BwdPre {
+    f32x4 a[UG][RPL];        // n, i, f, o of step t
+    float e[UG][RPL];        // outputErrors of step t
+    float cp[UG][RPL];       // cell state of prev(t)
+    char pt[RPL];
+};
+
+template <bool F32, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ELT = F32 ? 4 : 2;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
-    const int pitch = 4 * Hp * ELT + 16;             // LDS row pitch of the delta tile
+    const int pitch = 4 * Hp * ELT + 16;             // LDS row pitch of the delta tile, k = 4*unit + gate
     const int KC = 4 * Hp * ELT / 64;
     constexpr int KCR = RES ? 4 * HP * ELT / 64 : 1;
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
-    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 16;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * (4 * RPL);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * Hp;
     const long crow = (long)dirs * Hp;
@@ -263,72 +283,64 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
         }
     }
 
+    bool valid[RPL];
+    long soff[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) { const int s = s0 + 4 * r + q; valid[r] = s < PS; soff[r] = valid[r] ? s : 0; }
+
     // carried across steps (values of the step processed just before = next(t) in time)
-    float fgn[UG][4], ecn[UG][4], dign[UG][4], dfgn[UG][4], ccur[UG][4];
+    float fgn[UG][RPL], ecn[UG][RPL], dign[UG][RPL], dfgn[UG][RPL], ccur[UG][RPL];
     // gradient sums: bias (4 gates) and peepholes (i, f, o)
     float sb[UG][4], spi[UG], spf[UG], spo[UG];
-    // prefetched operands of the next step
-    float pe[UG][4], pa[UG][4][4], pcp[UG][4];
-    char pt[4];
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
         spi[u] = spf[u] = spo[u] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { fgn[u][r] = ecn[u][r] = dign[u][r] = dfgn[u][r] = 0.f; sb[u][r] = 0.f; }
+        for (int g = 0; g < 4; ++g) sb[u][g] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) fgn[u][r] = ecn[u][r] = dign[u][r] = dfgn[u][r] = 0.f;
     }
 
     // processing order is the reverse of the forward pass of this direction
     const int tfirst = d ? 0 : T - 1;
-    auto prefetch = [&](int t) {
+    BwdPre<UG, RPL> preA, preB;
+    auto prefetch = [&](int t, BwdPre<UG, RPL> &pre) {
         const int tprev = d ? t + 1 : t - 1;          // prev(t) in the forward processing order
         const bool hasprev = tprev >= 0 && tprev < T; // lastCall, LstmLayer.cu:947,981
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = s0 + 4 * q + r;
-            const bool valid = s < PS;
-            const long n = (long)t * PS + s;
-            pt[r] = valid ? p.pat[n] : 0;
+        for (int r = 0; r < RPL; ++r) {
+            const long n = (long)t * PS + soff[r];
+            pre.pt[r] = valid[r] ? p.pat[n] : 0;
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
-                pe[u][r] = valid ? p.err[n * crow + d * Hp + unit[u]] : 0.f;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    pa[u][g][r] = valid ? p.acts[n * arow + (d * 4 + g) * Hp + unit[u]] : 0.f;
-                pcp[u][r] = (valid && hasprev) ? p.cell[((long)tprev * PS + s) * crow + d * Hp + unit[u]] : 0.f;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                pre.e[u][r] = valid[r] ? p.err[n * crow + d * Hp + unit[u]] : 0.f;
+                pre.a[u][r] = valid[r] ? *(const f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) : z;
+                pre.cp[u][r] = (valid[r] && hasprev) ? p.cell[((long)tprev * PS + soff[r]) * crow + d * Hp + unit[u]] : 0.f;
             }
         }
     };
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int s = s0 + 4 * q + r;
-#pragma unroll
-        for (int u = 0; u < UG; ++u)
-            ccur[u][r] = (s < PS) ? p.cell[((long)tfirst * PS + s) * crow + d * Hp + unit[u]] : 0.f;
-    }
-    prefetch(tfirst);
-    lds_barrier();
 
-    for (int it = 0; it < T; ++it) {
+    auto step = [&](int it, BwdPre<UG, RPL> &pre) {
         const int t = d ? it : T - 1 - it;
         const char *dcur = smem + (it & 1) * 16 * pitch;
         char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
         const bool check = t >= p.Tmin;
 
         f32x4 acc[UG];
-        float a_[UG][4][4], cp_[UG][4];
-        char ptc[4];
+        f32x4 a_[UG][RPL];
+        float cp_[UG][RPL];
+        char ptc[RPL];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ptc[r] = pt[r];
+        for (int r = 0; r < RPL; ++r) ptc[r] = pre.pt[r];
 #pragma unroll
-        for (int u = 0; u < UG; ++u)
+        for (int u = 0; u < UG; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[u][r] = pe[u][r];
-                cp_[u][r] = pcp[u][r];
+            for (int r = 0; r < 4; ++r) acc[u][r] = (r < RPL) ? pre.e[u][r < RPL ? r : 0] : 0.f;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) a_[u][g][r] = pa[u][g][r];
-            }
-        if (it + 1 < T) prefetch(d ? t + 1 : t - 1);
+            for (int r = 0; r < RPL; ++r) { cp_[u][r] = pre.cp[u][r]; a_[u][r] = pre.a[u][r]; }
+        }
+        if (it + 2 < T) prefetch(d ? t + 2 : t - 2, pre);
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
         if constexpr (RES) {
@@ -352,14 +364,12 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int s = s0 + 4 * q + r;
-                const bool valid = s < PS;
-                const bool dummy = !valid || (check && ptc[r] == 0);
-                const long n = (long)t * PS + s;
+            for (int r = 0; r < RPL; ++r) {
+                const bool dummy = !valid[r] || (check && ptc[r] == 0);
+                const long n = (long)t * PS + soff[r];
                 // ComputeBlockErrorsFn, LstmLayer.cu:236-285
                 const float e = acc[u][r];
-                const float ni = a_[u][0][r], ig = a_[u][1][r], fg = a_[u][2][r], og = a_[u][3][r];
+                const float ni = a_[u][r][0], ig = a_[u][r][1], fg = a_[u][r][2], og = a_[u][r][3];
                 const float cs = ccur[u][r], cp = cp_[u][r];
                 const float th = tanh_ref<F32>(cs);
                 float dog = og * (1.0f - og) * th * e;
@@ -376,16 +386,31 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
                 // gradient sums (ComputeWeightUpdateFn bias / peephole cases, :392-408, :440-475)
                 sb[u][0] += dni; sb[u][1] += dig; sb[u][2] += dfg; sb[u][3] += dog;
                 spi[u] += cp * dig; spf[u] += cp * dfg; spo[u] += cs * dog;
-                const float dl[4] = {dni, dig, dfg, dog};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if constexpr (F32) *(float *)(dnxt + (4 * q + r) * pitch + (g * Hp + unit[u]) * 4) = dl[g];
-                    else *(__bf16 *)(dnxt + (4 * q + r) * pitch + (g * Hp + unit[u]) * 2) = (__bf16)dl[g];
-                    if (valid) st_op<F32>(p.delta_op, n * arow + (d * 4 + g) * Hp + unit[u], dl[g]);
+                if constexpr (F32) {
+                    const f32x4 dv = {dni, dig, dfg, dog};
+                    *(f32x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 16) = dv;
+                    if (valid[r]) *(f32x4 *)((float *)p.delta_op + n * arow + ((long)d * Hp + unit[u]) * 4) = dv;
+                } else {
+                    const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+                    *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 8) = dv;
+                    if (valid[r]) *(bf16x4 *)((__bf16 *)p.delta_op + n * arow + ((long)d * Hp + unit[u]) * 4) = dv;
                 }
             }
         }
         lds_barrier();
+    };
+
+#pragma unroll
+    for (int r = 0; r < RPL; ++r)
+#pragma unroll
+        for (int u = 0; u < UG; ++u)
+            ccur[u][r] = valid[r] ? p.cell[((long)tfirst * PS + soff[r]) * crow + d * Hp + unit[u]] : 0.f;
+    prefetch(tfirst, preA);
+    if (T > 1) prefetch(d ? 1 : T - 2, preB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA);
+        if (it + 1 < T) step(it + 1, preB);
     }
 
     // fold the 4 sequence quads of each unit column, then one atomic per (gate, unit) and workgroup
@@ -399,7 +424,7 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
         }
         if (q == 0) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * 4 + g) * Hp + unit[u]], p.bias * v[g]);
+            for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * Hp + unit[u]) * 4 + g], p.bias * v[g]);
 #pragma unroll
             for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * Hp + unit[u]], v[4 + g]);
         }
@@ -409,14 +434,14 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <bool F32, bool BWD, int HP, int UG>
+template <bool F32, bool BWD, int HP, int UG, int RPL>
 static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
 {
     const int ELT = F32 ? 4 : 2;
-    const int nsg = (p.PS + 15) / 16;
+    const int nsg = (p.PS + 4 * RPL - 1) / (4 * RPL);
     const int pitch = (BWD ? 4 : 1) * p.Hp * ELT + 16;
     const size_t lds = 2 * 16 * (size_t)pitch;
-    auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG> : lstm_fwd_kernel<F32, HP, UG>;
+    auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -425,20 +450,31 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
     hipLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds, s, p);
 }
 
+template <bool F32, bool BWD, int HP, int UG>
+static void launch_rpl(hipStream_t s, const LstmRec &p, int nwaves)
+{
+    // fewest sequences per workgroup that still fit one workgroup per CU (256 CUs)
+    const int rpl = p.rpl_override ? p.rpl_override
+                  : (p.dirs * ((p.PS + 3) / 4) <= 256 ? 1 : (p.dirs * ((p.PS + 7) / 8) <= 256 ? 2 : 4));
+    if (rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves);
+    else if (rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves);
+    else               launch_one<F32, BWD, HP, UG, 4>(s, p, nwaves);
+}
+
 template <bool F32, bool BWD>
 static void launch_rec(hipStream_t s, const LstmRec &p)
 {
     const int groups = p.Hp / 16;
     switch (p.Hp) {
-    case 32:  launch_one<F32, BWD, 32, 1>(s, p, 2); return;
-    case 64:  launch_one<F32, BWD, 64, 1>(s, p, 4); return;
-    case 96:  launch_one<F32, BWD, 96, 1>(s, p, 6); return;
-    case 128: launch_one<F32, BWD, 128, 1>(s, p, 8); return;
+    case 32:  launch_rpl<F32, BWD, 32, 1>(s, p, 2); return;
+    case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4); return;
+    case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6); return;
+    case 128: launch_rpl<F32, BWD, 128, 1>(s, p, 8); return;
     default: break;
     }
-    if (groups <= 16)      launch_one<F32, BWD, 0, 1>(s, p, groups);
-    else if (groups <= 32) launch_one<F32, BWD, 0, 2>(s, p, (groups + 1) / 2);
-    else                   launch_one<F32, BWD, 0, 4>(s, p, (groups + 3) / 4);
+    if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups);
+    else if (groups <= 32) launch_rpl<F32, BWD, 0, 2>(s, p, groups / 2);
+    else                   launch_rpl<F32, BWD, 0, 4>(s, p, groups / 4);
 }
 
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
