@@ -156,6 +156,9 @@ int  cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset);
 int  cn_layer_set_weights(cn_layer *layer, const float *host, int count);       /* flat reference layout */
 /* copy one reference-layout vector to the host; `dir` = 0 fw / 1 bw for LSTM internals.   [sync] */
 int  cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t count);
+/* overwrite a flat parameter vector (WEIGHTS / WEIGHT_UPDATES / WEIGHT_DELTAS) from the host: batch-mode
+ * accumulation (Optimizer.cu:72-85) and optimizer-state restore (SteepestDescentOptimizer.cu:125-131) */
+int  cn_layer_upload(cn_layer *layer, cn_buffer which, const float *host, size_t count);
 /* overwrite Layer::outputErrors() from the host (tests of a single layer's backward pass) */
 int  cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t count);
 /* raw fp32 device pointer of a flat parameter vector (WEIGHTS / WEIGHT_UPDATES / WEIGHT_DELTAS),

@@ -27,7 +27,7 @@ EXPORTS = [
     "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_last_error", "cn_device_arch",
     "cn_version", "cn_layer_create", "cn_layer_destroy", "cn_layer_size", "cn_layer_kind_of",
     "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_layer_forward",
-    "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors",
+    "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
     # include/currennt_hip_debug.h
@@ -96,6 +96,7 @@ def load_library():
     L.cn_layer_set_weights.argtypes = [vp, vp, ci]
     L.cn_layer_read.argtypes = [vp, ci, ci, vp, C.c_size_t]
     L.cn_layer_write_output_errors.argtypes = [vp, vp, C.c_size_t]
+    L.cn_layer_upload.argtypes = [vp, ci, vp, C.c_size_t]
     L.cn_layer_device_ptr.argtypes = [vp, ci]
     L.cn_layer_device_ptr.restype = vp
     L.cn_ctx_param_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -732,6 +732,22 @@ int cn_layer_set_weights(cn_layer *layer, const float *host, int count)
     });
 }
 
+int cn_layer_upload(cn_layer *layer, cn_buffer which, const float *host, size_t count)
+{
+    if (!layer || !host) { g_last_error = "cn_layer_upload: NULL argument"; return CN_ERR_BAD_ARG; }
+    if (which == CN_BUF_WEIGHTS) return cn_layer_set_weights(layer, host, (int)count);
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_upload: layer has no weights");
+        if (which != CN_BUF_WEIGHT_UPDATES && which != CN_BUF_WEIGHT_DELTAS) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_upload: not a parameter vector");
+        if (count != (size_t)layer->nw) throw cn_error(CN_ERR_SHAPE, "cn_layer_upload: count != weight count");
+        finalize(c);
+        HIP_CHECK(hipMemcpyAsync(which == CN_BUF_WEIGHT_UPDATES ? layer->wu : layer->wd, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+    });
+}
+
 int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t count)
 {
     if (!layer || !host) { g_last_error = "cn_layer_write_output_errors: NULL argument"; return CN_ERR_BAD_ARG; }

@@ -1,0 +1,172 @@
+#include "DataSet.hpp"
+
+#include <algorithm>
+#include <limits>
+#include <stdexcept>
+
+#include "../NetCdf3.hpp"
+
+namespace currennt_hip {
+namespace data_sets {
+
+DataSet::DataSet() {}
+
+DataSet::DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fraction, int truncSeqLength,
+                 bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed)
+    : m_fractionShuffling(fracShuf), m_sequenceShuffling(seqShuf), m_parallelSequences(parSeq),
+      m_minSeqLength(std::numeric_limits<int>::max()), m_maxSeqLength(std::numeric_limits<int>::min()),
+      m_rngState(randomSeed ? randomSeed : 5489u)
+{
+    if (fraction <= 0 || fraction > 1) throw std::runtime_error("Invalid fraction");        // DataSet.cpp:457-458
+    bool firstFile = true;
+    for (size_t fi = 0; fi < ncfiles.size(); ++fi) {
+        NetCdf3File nc(ncfiles[fi]);
+        const int maxSeqTagLength = nc.dimension("maxSeqTagLength");
+        if (firstFile) {                                                                       // :489-500
+            m_isClassificationData = nc.hasDimension("numLabels");
+            m_inputPatternSize = nc.dimension("inputPattSize");
+            if (m_isClassificationData) { int numLabels = nc.dimension("numLabels"); m_outputPatternSize = (numLabels == 2 ? 1 : numLabels); }
+            else m_outputPatternSize = nc.dimension("targetPattSize");
+        } else {                                                                               // :502-515
+            if (m_isClassificationData) {
+                if (!nc.hasDimension("numLabels")) throw std::runtime_error("Cannot combine classification with regression NC");
+                int numLabels = nc.dimension("numLabels");
+                if (m_outputPatternSize != (numLabels == 2 ? 1 : numLabels)) throw std::runtime_error("Number of classes mismatch in NC files");
+            } else if (m_outputPatternSize != nc.dimension("targetPattSize")) throw std::runtime_error("Number of targets mismatch in NC files");
+            if (m_inputPatternSize != nc.dimension("inputPattSize")) throw std::runtime_error("Number of inputs mismatch in NC files");
+        }
+        int nSeq = nc.dimension("numSeqs");
+        nSeq = std::max((int)((real_t)nSeq * fraction), 1);                                    // :518-520
+        std::vector<int> lengths = nc.readInts("seqLengths", 0, nSeq);
+        std::vector<sequence_t> sequences;
+        for (int i = 0; i < nSeq; ++i) {
+            int seqLength = lengths[i];
+            m_totalTimesteps += seqLength;
+            std::string seqTag = nc.readString("seqTags", i, maxSeqTagLength);
+            int k = 0;
+            while (seqLength > 0) {                                                            // truncation, :530-546
+                sequence_t seq;
+                seq.originalSeqIdx = k;
+                if (truncSeqLength > 0 && seqLength > 1.5 * truncSeqLength) seq.length = std::min(truncSeqLength, seqLength);
+                else seq.length = seqLength;
+                seq.seqTag = seqTag; seq.inputsBegin = 0; seq.targetsBegin = 0;
+                sequences.push_back(seq);
+                seqLength -= seq.length;
+                ++k;
+            }
+        }
+        size_t frames = 0;
+        for (size_t i = 0; i < sequences.size(); ++i) frames += sequences[i].length;
+        // bulk read (the reference reads sequence by sequence into its cache file, :549-575)
+        size_t inBase = m_inputData.size();
+        { std::vector<float> x = nc.readFloats("inputs", 0, frames * m_inputPatternSize); m_inputData.insert(m_inputData.end(), x.begin(), x.end()); }
+        size_t tgBase;
+        if (m_isClassificationData) {
+            tgBase = m_classData.size();
+            std::vector<int> t = nc.readInts("targetClasses", 0, frames); m_classData.insert(m_classData.end(), t.begin(), t.end());
+        } else {
+            tgBase = m_targetData.size();
+            std::vector<float> t = nc.readFloats("targetPatterns", 0, frames * m_outputPatternSize); m_targetData.insert(m_targetData.end(), t.begin(), t.end());
+        }
+        size_t pos = 0;
+        for (size_t i = 0; i < sequences.size(); ++i) {
+            m_minSeqLength = std::min(m_minSeqLength, sequences[i].length);
+            m_maxSeqLength = std::max(m_maxSeqLength, sequences[i].length);
+            sequences[i].inputsBegin = inBase + pos * m_inputPatternSize;
+            sequences[i].targetsBegin = tgBase + pos * (m_isClassificationData ? 1 : m_outputPatternSize);
+            pos += sequences[i].length;
+        }
+        if (firstFile) {                                                                       // :577-588
+            if (nc.hasVariable("outputMeans") && nc.hasVariable("outputStdevs")) {
+                m_outputMeans = nc.readFloats("outputMeans", 0, m_outputPatternSize);
+                m_outputStdevs = nc.readFloats("outputStdevs", 0, m_outputPatternSize);
+            } else { m_outputMeans.assign(m_outputPatternSize, 0.0f); m_outputStdevs.assign(m_outputPatternSize, 1.0f); }
+        }
+        m_sequences.insert(m_sequences.end(), sequences.begin(), sequences.end());
+        firstFile = false;
+    }
+    m_totalSequences = (int)m_sequences.size();
+    if (sortByLength)                                                                          // :603-605 (std::sort, comp_seqs :164-167)
+        std::sort(m_sequences.begin(), m_sequences.end(), [](const sequence_t &a, const sequence_t &b) { return a.length < b.length; });
+}
+
+unsigned DataSet::nextRandom(unsigned n)
+{
+    // The reference draws from boost::mt19937 (DataSet.cpp:169-181), which is not available here; a
+    // xorshift generator seeded from --random_seed keeps shuffles reproducible per seed.
+    m_rngState ^= m_rngState << 13; m_rngState ^= m_rngState >> 17; m_rngState ^= m_rngState << 5;
+    return n ? m_rngState % n : 0;
+}
+
+void DataSet::shuffleSequences()
+{
+    for (size_t i = m_sequences.size(); i > 1; --i) std::swap(m_sequences[i - 1], m_sequences[nextRandom((unsigned)i)]);
+}
+
+void DataSet::shuffleFractions()
+{
+    std::vector<std::vector<sequence_t> > fractions;
+    for (size_t i = 0; i < m_sequences.size(); ++i) {
+        if (i % m_parallelSequences == 0) fractions.resize(fractions.size() + 1);
+        fractions.back().push_back(m_sequences[i]);
+    }
+    for (size_t i = fractions.size(); i > 1; --i) std::swap(fractions[i - 1], fractions[nextRandom((unsigned)i)]);
+    m_sequences.clear();
+    for (size_t i = 0; i < fractions.size(); ++i) m_sequences.insert(m_sequences.end(), fractions[i].begin(), fractions[i].end());
+}
+
+void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac) const
+{
+    const int PS = m_parallelSequences;
+    *frac = DataSetFraction();
+    frac->m_inputPatternSize = m_inputPatternSize;
+    frac->m_outputPatternSize = m_outputPatternSize;
+    frac->m_maxSeqLength = std::numeric_limits<int>::min();
+    frac->m_minSeqLength = std::numeric_limits<int>::max();
+    for (int seqIdx = firstSeqIdx; seqIdx < firstSeqIdx + PS; ++seqIdx) {                      // :316-328
+        if (seqIdx >= (int)m_sequences.size()) continue;
+        frac->m_maxSeqLength = std::max(frac->m_maxSeqLength, m_sequences[seqIdx].length);
+        frac->m_minSeqLength = std::min(frac->m_minSeqLength, m_sequences[seqIdx].length);
+        DataSetFraction::seq_info_t si = { m_sequences[seqIdx].originalSeqIdx, m_sequences[seqIdx].length, m_sequences[seqIdx].seqTag };
+        frac->m_seqInfo.push_back(si);
+    }
+    const size_t slots = (size_t)frac->m_maxSeqLength * PS;
+    frac->m_inputs.assign(slots * m_inputPatternSize, 0.0f);                                   // :330-336
+    frac->m_patTypes.assign(slots, (char)PATTYPE_NONE);
+    if (m_isClassificationData) frac->m_targetClasses.assign(slots, -1);
+    else frac->m_outputs.assign(slots * m_outputPatternSize, 0.0f);
+    for (int i = 0; i < PS; ++i) {
+        if (firstSeqIdx + i >= (int)m_sequences.size()) continue;
+        const sequence_t &seq = m_sequences[firstSeqIdx + i];
+        for (int t = 0; t < seq.length; ++t) {
+            const size_t slot = (size_t)t * PS + i;
+            std::copy(m_inputData.begin() + seq.inputsBegin + (size_t)t * m_inputPatternSize,
+                      m_inputData.begin() + seq.inputsBegin + (size_t)(t + 1) * m_inputPatternSize,
+                      frac->m_inputs.begin() + slot * m_inputPatternSize);                      // :346-366
+            if (m_isClassificationData) frac->m_targetClasses[slot] = m_classData[seq.targetsBegin + t];   // :372-380
+            else std::copy(m_targetData.begin() + seq.targetsBegin + (size_t)t * m_outputPatternSize,
+                           m_targetData.begin() + seq.targetsBegin + (size_t)(t + 1) * m_outputPatternSize,
+                           frac->m_outputs.begin() + slot * m_outputPatternSize);                // :383-397
+            frac->m_patTypes[slot] = (char)(t == 0 ? PATTYPE_FIRST : (t == seq.length - 1 ? PATTYPE_LAST : PATTYPE_NORMAL));   // :400-407
+        }
+    }
+}
+
+bool DataSet::getNextFraction(DataSetFraction *frac)
+{
+    if (m_curFirstSeqIdx == -1 || m_curFirstSeqIdx == 0) {       // start of an epoch: _makeFirstFractionTask, :416-427
+        if (m_curFirstSeqIdx == -1) m_curFirstSeqIdx = 0;
+        if (m_sequenceShuffling) shuffleSequences();
+        if (m_fractionShuffling) shuffleFractions();
+    }
+    if (m_curFirstSeqIdx < (int)m_sequences.size()) {
+        makeFraction(m_curFirstSeqIdx, frac);
+        m_curFirstSeqIdx += m_parallelSequences;
+        return true;
+    }
+    m_curFirstSeqIdx = 0;                                        // :660-662
+    return false;
+}
+
+}  // namespace data_sets
+}  // namespace currennt_hip

@@ -1,0 +1,77 @@
+// In-memory data set and fraction packer: the host objects of currennt_lib/src/data_sets/
+// {DataSet,DataSetFraction}.{hpp,cpp} for NetCDF-3 classic files (the reference goes through
+// libnetcdf and a /tmp cache file; sequences here are kept in RAM).
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../Types.hpp"
+
+namespace currennt_hip {
+namespace data_sets {
+
+// one mini batch of parallel sequences (DataSetFraction.hpp:40-66)
+class DataSetFraction {
+public:
+    struct seq_info_t { int originalSeqIdx; int length; std::string seqTag; };
+
+    int inputPatternSize() const { return m_inputPatternSize; }
+    int outputPatternSize() const { return m_outputPatternSize; }
+    int maxSeqLength() const { return m_maxSeqLength; }
+    int minSeqLength() const { return m_minSeqLength; }
+    int numSequences() const { return (int)m_seqInfo.size(); }
+    const seq_info_t &seqInfo(int seqIdx) const { return m_seqInfo.at(seqIdx); }
+    const Hip::pattype_vector &patTypes() const { return m_patTypes; }
+    const Hip::real_vector &inputs() const { return m_inputs; }
+    const Hip::real_vector &outputs() const { return m_outputs; }
+    const Hip::int_vector &targetClasses() const { return m_targetClasses; }
+
+private:
+    friend class DataSet;
+    int m_inputPatternSize = 0, m_outputPatternSize = 0, m_maxSeqLength = 0, m_minSeqLength = 0;
+    std::vector<seq_info_t> m_seqInfo;
+    Hip::real_vector m_inputs, m_outputs;
+    Hip::pattype_vector m_patTypes;
+    Hip::int_vector m_targetClasses;
+};
+
+class DataSet {
+public:
+    struct sequence_t { int originalSeqIdx; int length; std::string seqTag; size_t inputsBegin; size_t targetsBegin; };
+
+    DataSet();                                              // empty set (DataSet.cpp:429-442)
+    // DataSet.cpp:443-606; `sortByLength` = Configuration::trainingMode() there (:603-605)
+    DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fraction, int truncSeqLength,
+            bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed);
+
+    bool isClassificationData() const { return m_isClassificationData; }
+    bool empty() const { return m_totalTimesteps == 0; }
+    // next fraction, or false once per epoch after the last one (DataSet.cpp:632-668)
+    bool getNextFraction(DataSetFraction *frac);
+    int totalSequences() const { return m_totalSequences; }
+    int totalTimesteps() const { return m_totalTimesteps; }
+    int minSeqLength() const { return m_minSeqLength; }
+    int maxSeqLength() const { return m_maxSeqLength; }
+    int inputPatternSize() const { return m_inputPatternSize; }
+    int outputPatternSize() const { return m_outputPatternSize; }
+    const Hip::real_vector &outputMeans() const { return m_outputMeans; }
+    const Hip::real_vector &outputStdevs() const { return m_outputStdevs; }
+
+private:
+    bool m_fractionShuffling = false, m_sequenceShuffling = false, m_isClassificationData = false;
+    int m_parallelSequences = 0, m_totalSequences = 0, m_totalTimesteps = 0, m_minSeqLength = 0, m_maxSeqLength = 0,
+        m_inputPatternSize = 0, m_outputPatternSize = 0, m_curFirstSeqIdx = -1;
+    unsigned m_rngState = 0;
+    Hip::real_vector m_outputMeans, m_outputStdevs, m_inputData, m_targetData;
+    Hip::int_vector m_classData;
+    std::vector<sequence_t> m_sequences;
+
+    void makeFraction(int firstSeqIdx, DataSetFraction *frac) const;   // _makeFractionTask, DataSet.cpp:300-414
+    void shuffleSequences();                                          // :226-230
+    void shuffleFractions();                                          // :232-250
+    unsigned nextRandom(unsigned n);
+};
+
+}  // namespace data_sets
+}  // namespace currennt_hip

@@ -1,0 +1,274 @@
+// currennt_hip: a `currennt`-compatible driver over the MI355X library (subset of currennt/src/main.cpp:
+// training loop with the progress table, trained_network.jsn export, forward pass writers
+// single_csv / csv / htk).  Exit code 2 and "FAILED: msg" on any error like main.cpp:492-495.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+
+#include "Configuration.hpp"
+#include "NeuralNetwork.hpp"
+#include "data_sets/DataSet.hpp"
+#include "optimizers/Optimizer.hpp"
+
+using namespace currennt_hip;
+
+namespace {
+
+enum data_set_type { DATA_SET_TRAINING, DATA_SET_VALIDATION, DATA_SET_TEST, DATA_SET_FEEDFORWARD };
+
+std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, data_set_type dsType)   // main.cpp:574-640
+{
+    std::string type; std::vector<std::string> filenames; real_t fraction = 1; bool fracShuf = false, seqShuf = false; int truncSeqLength = 0;
+    switch (dsType) {
+    case DATA_SET_TRAINING: type = "training set"; filenames = config.trainingFiles(); fraction = config.trainingFraction();
+        fracShuf = config.shuffleFractions(); seqShuf = config.shuffleSequences(); truncSeqLength = config.truncateSeqLength(); break;
+    case DATA_SET_VALIDATION: type = "validation set"; filenames = config.validationFiles(); fraction = config.validationFraction(); break;
+    case DATA_SET_TEST: type = "test set"; filenames = config.testFiles(); fraction = config.testFraction(); break;
+    default: type = "feed forward input set"; filenames = config.feedForwardInputFiles(); break;
+    }
+    printf("Loading %s ", type.c_str());
+    for (size_t i = 0; i < filenames.size(); ++i) printf("'%s' ", filenames[i].c_str());
+    printf("...");
+    fflush(stdout);
+    if (filenames.empty()) throw std::runtime_error("No " + type + " file given");
+    std::shared_ptr<data_sets::DataSet> ds = std::make_shared<data_sets::DataSet>(
+        filenames, config.parallelSequences(), fraction, truncSeqLength, fracShuf, seqShuf, config.trainingMode(), config.randomSeed());
+    printf("done.\n");
+    printf("Loaded fraction:  %d%%\n", (int)(fraction * 100));
+    printf("Sequences:        %d\n", ds->totalSequences());
+    printf("Sequence lengths: %d..%d\n", ds->minSeqLength(), ds->maxSeqLength());
+    printf("Total timesteps:  %d\n\n", ds->totalTimesteps());
+    return ds;
+}
+
+void printLayers(const NeuralNetwork &nn)                                                       // main.cpp:643-657
+{
+    int weights = 0;
+    for (size_t i = 0; i < nn.layers().size(); ++i) {
+        printf("(%d) %s ", (int)i, nn.layers()[i]->type().c_str());
+        printf("[size: %d", nn.layers()[i]->size());
+        const layers::TrainableLayer *tl = dynamic_cast<const layers::TrainableLayer *>(nn.layers()[i].get());
+        if (tl) { printf(", bias: %.1lf, weights: %d", (double)tl->bias(), tl->weightCount()); weights += tl->weightCount(); }
+        printf("]\n");
+    }
+    printf("Total weights: %d\n", weights);
+}
+
+void saveNetwork(const NeuralNetwork &nn, const std::string &filename)                          // main.cpp:681-698
+{
+    json::Value doc(json::Value::Object);
+    nn.exportLayers(&doc);
+    nn.exportWeights(&doc);
+    doc.writeFile(filename);
+}
+
+std::string printfRow(const char *format, ...)                                                  // main.cpp:760-775
+{
+    char buffer[100];
+    va_list args; va_start(args, format); vsnprintf(buffer, sizeof(buffer), format, args); va_end(args);
+    std::cout << buffer; fflush(stdout);
+    return std::string(buffer);
+}
+
+void makeDirs(const std::string &path)
+{
+    for (size_t i = 1; i <= path.size(); ++i)
+        if (i == path.size() || path[i] == '/') mkdir(path.substr(0, i).c_str(), 0777);
+}
+void swap32(void *p) { unsigned char *b = (unsigned char *)p; std::swap(b[0], b[3]); std::swap(b[1], b[2]); }
+void swap16(void *p) { unsigned char *b = (unsigned char *)p; std::swap(b[0], b[1]); }
+
+void feedForward(const Configuration &config, NeuralNetwork &nn, data_sets::DataSet &set)      // main.cpp:307-490
+{
+    const Hip::real_vector means = set.outputMeans(), stdevs = set.outputStdevs();
+    const bool unstandardize = config.revertStd();
+    if (unstandardize) printf("Outputs will be scaled by mean and standard deviation specified in NC file.\n");
+    std::ofstream single;
+    if (config.feedForwardFormat() == Configuration::FORMAT_SINGLE_CSV) single.open(config.feedForwardOutputFile().c_str());
+    data_sets::DataSetFraction frac;
+    int fracIdx = 0;
+    while (set.getNextFraction(&frac)) {
+        printf("Computing outputs for data fraction %d...", ++fracIdx);
+        fflush(stdout);
+        nn.loadSequences(frac);
+        nn.computeForwardPass();
+        std::vector<std::vector<std::vector<real_t> > > outputs = nn.getOutputs();
+        for (int psIdx = 0; psIdx < (int)outputs.size(); ++psIdx) {
+            const std::string &tag = frac.seqInfo(psIdx).seqTag;
+            auto value = [&](int t, int o) { real_t v = outputs[psIdx][t][o]; if (unstandardize) { v *= stdevs[o]; v += means[o]; } return v; };
+            if (config.feedForwardFormat() == Configuration::FORMAT_SINGLE_CSV) {
+                single << tag;
+                for (size_t t = 0; t < outputs[psIdx].size(); ++t)
+                    for (size_t o = 0; o < outputs[psIdx][t].size(); ++o) single << ';' << value((int)t, (int)o);
+                single << '\n';
+                continue;
+            }
+            // one file per sequence below <ff_output_file>/<dir of tag>/
+            std::string rel = tag;
+            while (!rel.empty() && rel[0] == '/') rel.erase(0, 1);
+            size_t slash = rel.find_last_of('/');
+            std::string dir = config.feedForwardOutputFile() + (slash == std::string::npos ? "" : "/" + rel.substr(0, slash));
+            std::string base = slash == std::string::npos ? rel : rel.substr(slash + 1);
+            makeDirs(dir);
+            if (config.feedForwardFormat() == Configuration::FORMAT_CSV) {
+                size_t dot = base.find_last_of('.');
+                if (dot != std::string::npos && dot > 0) base = base.substr(0, dot);
+                std::ofstream file((dir + "/" + base + ".csv").c_str());
+                for (size_t t = 0; t < outputs[psIdx].size(); ++t) {
+                    for (size_t o = 0; o < outputs[psIdx][t].size(); ++o) { if (o) file << ';'; file << value((int)t, (int)o); }
+                    file << '\n';
+                }
+            } else if (!outputs[psIdx].empty()) {                                                // FORMAT_HTK, main.cpp:432-480
+                std::ofstream file((dir + "/" + base + ".htk").c_str(), std::ofstream::out | std::ios::binary);
+                unsigned tmp = (unsigned)outputs[psIdx].size(); swap32(&tmp); file.write((const char *)&tmp, 4);
+                tmp = (unsigned)(config.featurePeriod() * 1e4); swap32(&tmp); file.write((const char *)&tmp, 4);
+                unsigned short tmp2 = (unsigned short)(outputs[psIdx][0].size() * sizeof(float)); swap16(&tmp2); file.write((const char *)&tmp2, 2);
+                tmp2 = (unsigned short)config.outputFeatureKind(); swap16(&tmp2); file.write((const char *)&tmp2, 2);
+                for (size_t t = 0; t < outputs[psIdx].size(); ++t)
+                    for (size_t o = 0; o < outputs[psIdx][t].size(); ++o) { float v = value((int)t, (int)o); swap32(&v); file.write((const char *)&v, 4); }
+            }
+        }
+        printf(" done.\n");
+    }
+}
+
+int trainerMain(const Configuration &config)                                                    // main.cpp:97-498
+{
+    try {
+        printf("Reading network from '%s'... ", config.networkFile().c_str());
+        fflush(stdout);
+        json::Value netDoc = json::Value::parseFile(config.networkFile());
+        printf("done.\n\n");
+
+        std::shared_ptr<data_sets::DataSet> trainingSet = std::make_shared<data_sets::DataSet>(), validationSet = trainingSet,
+                                             testSet = trainingSet, feedForwardSet = trainingSet;
+        validationSet = std::make_shared<data_sets::DataSet>(); testSet = std::make_shared<data_sets::DataSet>();
+        feedForwardSet = std::make_shared<data_sets::DataSet>();
+        if (config.trainingMode()) {
+            trainingSet = loadDataSet(config, DATA_SET_TRAINING);
+            if (!config.validationFiles().empty()) validationSet = loadDataSet(config, DATA_SET_VALIDATION);
+            if (!config.testFiles().empty()) testSet = loadDataSet(config, DATA_SET_TEST);
+        } else feedForwardSet = loadDataSet(config, DATA_SET_FEEDFORWARD);
+
+        int maxSeqLength = config.trainingMode()
+            ? std::max(trainingSet->maxSeqLength(), std::max(validationSet->maxSeqLength(), testSet->maxSeqLength()))
+            : feedForwardSet->maxSeqLength();
+
+        if (config.dumpFractions()) {     // host-only check of reader + packer (no GPU needed)
+            data_sets::DataSet &ds = config.trainingMode() ? *trainingSet : *feedForwardSet;
+            data_sets::DataSetFraction frac;
+            int idx = 0;
+            while (ds.getNextFraction(&frac)) {
+                double sx = 0; long st = 0; int none = 0;
+                for (size_t i = 0; i < frac.inputs().size(); ++i) sx += frac.inputs()[i];
+                for (size_t i = 0; i < frac.targetClasses().size(); ++i) if (frac.targetClasses()[i] >= 0) st += frac.targetClasses()[i];
+                for (size_t i = 0; i < frac.outputs().size(); ++i) sx += 1000.0 * frac.outputs()[i];
+                for (size_t i = 0; i < frac.patTypes().size(); ++i) none += frac.patTypes()[i] == PATTYPE_NONE;
+                printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s\n", idx++, frac.maxSeqLength(),
+                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.seqInfo(0).seqTag.c_str());
+            }
+            return 0;
+        }
+
+        printf("Creating the neural network... ");
+        fflush(stdout);
+        const int inputSize = config.trainingMode() ? trainingSet->inputPatternSize() : -1;      // main.cpp:146-148
+        NeuralNetwork::WeightsInit wi = { config.weightsDistributionIsNormal(), config.weightsDistributionUniformMin(),
+                                          config.weightsDistributionUniformMax(), config.weightsDistributionNormalSigma(),
+                                          config.weightsDistributionNormalMean(), config.randomSeed() };
+        NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device(), &wi);
+        if (!trainingSet->empty() && trainingSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
+            throw std::runtime_error("Post output layer size != target pattern size of the training set");
+        if (!validationSet->empty() && validationSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
+            throw std::runtime_error("Post output layer size != target pattern size of the validation set");
+        if (!testSet->empty() && testSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
+            throw std::runtime_error("Post output layer size != target pattern size of the test set");
+        printf("done.\nLayers:\n");
+        printLayers(neuralNetwork);
+        printf("\n");
+
+        const bool classificationTask = dynamic_cast<layers::MulticlassClassificationLayer *>(&neuralNetwork.postOutputLayer()) != 0;
+
+        if (config.trainingMode()) {
+            printf("Creating the optimizer... ");
+            fflush(stdout);
+            optimizers::SteepestDescentOptimizer optimizer(neuralNetwork, *trainingSet, *validationSet, *testSet, config.maxEpochs(),
+                                                           config.maxEpochsNoBest(), config.validateEvery(), config.testEvery(),
+                                                           config.learningRate(), config.momentum(), config.hybridOnlineBatch());
+            printf("done.\n");
+            printf("Optimizer type: Steepest descent with momentum\n");                         // main.cpp:660-678
+            printf("Max training epochs:       %d\n", config.maxEpochs());
+            printf("Max epochs until new best: %d\n", config.maxEpochsNoBest());
+            printf("Validation error every:    %d\n", config.validateEvery());
+            printf("Test error every:          %d\n", config.testEvery());
+            printf("Learning rate:             %g\n", (double)config.learningRate());
+            printf("Momentum:                  %g\n\n", (double)config.momentum());
+
+            printf("Starting training...\n\n");
+            printf(" Epoch | Duration |  Training error  | Validation error |    Test error    | New best \n");
+            printf("-------+----------+------------------+------------------+------------------+----------\n");
+            bool finished = false;
+            while (!finished) {
+                const char *errFormat = (classificationTask ? "%6.2lf%%%10.3lf |" : "%17.3lf |");
+                const char *errSpace = "                  |";
+                printfRow(" %5d | ", optimizer.currentEpoch() + 1);
+                auto t0 = std::chrono::steady_clock::now();
+                finished = optimizer.train();
+                double duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                printfRow("%8.1lf |", duration);
+                if (classificationTask) printfRow(errFormat, (double)optimizer.curTrainingClassError() * 100.0, (double)optimizer.curTrainingError());
+                else printfRow(errFormat, (double)optimizer.curTrainingError());
+                const bool validated = !validationSet->empty() && optimizer.currentEpoch() % config.validateEvery() == 0;
+                if (validated) {
+                    if (classificationTask) printfRow(errFormat, (double)optimizer.curValidationClassError() * 100.0, (double)optimizer.curValidationError());
+                    else printfRow(errFormat, (double)optimizer.curValidationError());
+                } else printfRow("%s", errSpace);
+                if (!testSet->empty() && optimizer.currentEpoch() % config.testEvery() == 0) {
+                    if (classificationTask) printfRow(errFormat, (double)optimizer.curTestClassError() * 100.0, (double)optimizer.curTestError());
+                    else printfRow(errFormat, (double)optimizer.curTestError());
+                } else printfRow("%s", errSpace);
+                if (validated) printfRow(optimizer.epochsSinceLowestValidationError() == 0 ? "  yes   \n" : "  no    \n");
+                else printfRow("        \n");
+            }
+            printf("\n");
+            if (optimizer.epochsSinceLowestValidationError() == config.maxEpochsNoBest())
+                printf("No new lowest error since %d epochs. Training stopped.\n", config.maxEpochsNoBest());
+            else printf("Maximum number of training epochs reached. Training stopped.\n");
+            if (!validationSet->empty()) printf("Lowest validation error: %lf\n", optimizer.lowestValidationError());
+            else printf("Final training set error: %lf\n", optimizer.curTrainingError());
+            printf("\n");
+            printf("Storing the trained network in '%s'... ", config.trainedNetworkFile().c_str());
+            saveNetwork(neuralNetwork, config.trainedNetworkFile());
+            printf("done.\n");
+        } else {
+            feedForward(config, neuralNetwork, *feedForwardSet);
+        }
+    } catch (const std::exception &e) {
+        printf("FAILED: %s\n", e.what());
+        return 2;
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, const char *argv[])
+{
+    try {
+        Configuration config(argc, argv);
+        if (config.help()) { fputs(Configuration::usage(), stdout); return 0; }
+        printf("Started in %s training mode.\n", config.hybridOnlineBatch() ? "hybrid online/batch" : "batch");   // Configuration.cpp:316
+        printf("Computations run on the MI355X (libcurrennt_hip: %s, %s operands).\n", cn_version(),
+               config.precision() == CN_PREC_BF16 ? "bf16" : "fp32");
+        return trainerMain(config);
+    } catch (const std::exception &e) {
+        printf("FAILED: %s\n", e.what());
+        return 2;
+    }
+}

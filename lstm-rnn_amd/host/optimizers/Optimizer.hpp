@@ -1,0 +1,69 @@
+// Epoch protocol and momentum SGD (currennt_lib/src/optimizers/{Optimizer,SteepestDescentOptimizer}.*).
+// Gradient accumulation, the update and best-weight bookkeeping all stay on the device; the host only
+// sequences them.
+#pragma once
+
+#include <vector>
+
+#include "../NeuralNetwork.hpp"
+#include "../data_sets/DataSet.hpp"
+
+namespace currennt_hip {
+namespace optimizers {
+
+class Optimizer {
+public:
+    Optimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingSet, data_sets::DataSet &validationSet,
+              data_sets::DataSet &testSet, int maxEpochs, int maxEpochsNoBest, int validateEvery, int testEvery,
+              bool hybridOnlineBatch);
+    virtual ~Optimizer() {}
+
+    bool finished() const { return m_finished; }
+    int currentEpoch() const { return m_curEpoch; }
+    real_t lowestValidationError() const { return m_lowestValidationError; }
+    int epochsSinceLowestValidationError() const { return m_epochsSinceLowestError; }
+    real_t curTrainingError() const { return m_curTrainingError; }
+    real_t curValidationError() const { return m_curValidationError; }
+    real_t curTestError() const { return m_curTestError; }
+    real_t curTrainingClassError() const { return m_curTrainingClassError; }
+    real_t curValidationClassError() const { return m_curValidationClassError; }
+    real_t curTestClassError() const { return m_curTestClassError; }
+
+    bool train();                                                       // Optimizer.cu:283-324
+
+protected:
+    virtual void _updateWeights() = 0;
+    real_t _processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates, real_t *classError);   // Optimizer.cu:37-104
+    void _storeWeights();                                               // :151-158
+    void _restoreWeights();                                             // :160-168
+    NeuralNetwork &_neuralNetwork() { return m_neuralNetwork; }
+    // accumulated weightUpdates of the epoch (batch mode); per layer, reference layout
+    std::vector<Hip::real_vector> &_curWeightUpdates() { return m_curWeightUpdates; }
+
+private:
+    NeuralNetwork &m_neuralNetwork;
+    data_sets::DataSet &m_trainingSet, &m_validationSet, &m_testSet;
+    const int m_maxEpochs, m_maxEpochsNoBest, m_validateEvery, m_testEvery;
+    const bool m_hybridOnlineBatch;
+    bool m_finished;
+    int m_curEpoch, m_epochsSinceLowestError;
+    real_t m_lowestValidationError, m_curTrainingError, m_curValidationError, m_curTestError,
+           m_curValidationClassError, m_curTrainingClassError, m_curTestClassError;
+    std::vector<Hip::real_vector> m_curWeightUpdates, m_bestWeights;
+protected:
+    bool hybridOnlineBatch() const { return m_hybridOnlineBatch; }
+};
+
+class SteepestDescentOptimizer : public Optimizer {
+public:
+    SteepestDescentOptimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingSet, data_sets::DataSet &validationSet,
+                             data_sets::DataSet &testSet, int maxEpochs, int maxEpochsNoBest, int validateEvery, int testEvery,
+                             real_t learningRate, real_t momentum, bool hybridOnlineBatch);
+protected:
+    void _updateWeights();                                              // SteepestDescentOptimizer.cu:67-94
+private:
+    real_t m_learningRate, m_momentum;
+};
+
+}  // namespace optimizers
+}  // namespace currennt_hip

@@ -1,0 +1,104 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/*.h declares, the
+fraction packer follows DataSet::_makeFractionTask, and the oracle's primitive products follow
+helpers/Matrix.cu.  No compute call is made without a GPU."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_exports_every_declared_symbol(pkg, hiplib):
+    from lstm_rnn_amd import binding
+    decl = declared_symbols()
+    assert decl, "no declarations found in include/*.h"
+    missing = [n for n in sorted(decl) if not hasattr(hiplib, n)]
+    assert not missing, missing
+    assert set(binding.EXPORTS) == decl, sorted(set(binding.EXPORTS) ^ decl)
+    assert hiplib.cn_version().decode().startswith("currennt_hip")
+
+
+def test_no_cpu_fallback(pkg, hiplib):
+    """Without a GPU the product path must fail loudly (CN_ERR_NO_DEVICE), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    rc = hiplib.cn_ctx_create(0, 0, None, C.byref(ctx))
+    assert rc == -5 and not ctx.value
+    assert b"no HIP device" in hiplib.cn_last_error(None)
+    layers = [{"name": "i", "type": "input", "size": 2}, {"name": "o", "type": "softmax", "size": 2, "bias": 1.0},
+              {"name": "p", "type": "multiclass_classification", "size": 2}]
+    with pytest.raises(pkg.CurrenntHipError):
+        pkg.NeuralNetwork(layers, None, 1, 2, seed=0)
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference the oracle (test infrastructure)."""
+    for path in glob.glob(os.path.join(ROOT, "lstm-rnn_amd", "**", "*"), recursive=True):
+        if os.path.isfile(path) and path.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+            assert "oracle" not in open(path, errors="ignore").read().lower().replace("nothing here touches the cpu oracle", ""), path
+
+
+def test_fraction_packer_layout(pkg):
+    xs = [np.arange(3 * 2, dtype=np.float32).reshape(3, 2) + 10, np.arange(1 * 2, dtype=np.float32).reshape(1, 2) + 50]
+    ts = [np.array([1, 2, 0], np.int32), np.array([2], np.int32)]
+    f = pkg.make_fraction(xs, ts, 3)
+    assert (f["T"], f["Tmin"], f["PS"], f["numSeqs"]) == (3, 1, 3, 2)
+    x = f["inputs"].reshape(3, 3, 2)
+    assert np.all(x[:, 0] == xs[0]) and np.all(x[0, 1] == xs[1][0]) and np.all(x[1:, 1] == 0) and np.all(x[:, 2] == 0)
+    pat = f["patTypes"].reshape(3, 3)
+    assert pat[:, 0].tolist() == [1, 2, 3]          # FIRST, NORMAL, LAST (DataSet.cpp:400-407)
+    assert pat[:, 1].tolist() == [1, 0, 0]          # a length-1 sequence is FIRST (timestep == 0 wins)
+    assert pat[:, 2].tolist() == [0, 0, 0]          # missing column stays NONE (:331)
+    tc = f["targetClasses"].reshape(3, 3)
+    assert tc[:, 0].tolist() == [1, 2, 0] and tc[:, 1].tolist() == [2, -1, -1] and tc[:, 2].tolist() == [-1, -1, -1]
+    fr = pkg.make_fractions(xs * 3, ts * 3, 4, sort_by_length=True)
+    assert [q["numSeqs"] for q in fr] == [4, 2] and fr[0]["seqLengths"] == [1, 1, 1, 3]
+
+
+def test_oracle_matmul_kinds(orc):
+    """orc_matmul restates the three column-major products of helpers/Matrix.cu:41-183."""
+    rng = np.random.RandomState(0)
+    L = orc.lib()
+    A = rng.randn(5, 7).astype(np.float32); B = rng.randn(7, 3).astype(np.float32)
+    c = np.zeros(5 * 3, np.float32)
+    L.orc_matmul(0, c, np.ascontiguousarray(A.T).reshape(-1), 5, 7, np.ascontiguousarray(B.T).reshape(-1), 7, 3, 0)
+    assert np.allclose(c.reshape(3, 5).T, A @ B, atol=1e-5)
+    A2 = rng.randn(7, 5).astype(np.float32)     # C = A2^T B
+    c = np.ones(5 * 3, np.float32)
+    L.orc_matmul(1, c, np.ascontiguousarray(A2.T).reshape(-1), 7, 5, np.ascontiguousarray(B.T).reshape(-1), 7, 3, 1)
+    assert np.allclose(c.reshape(3, 5).T, 1 + A2.T @ B, atol=1e-5)
+    B2 = rng.randn(3, 7).astype(np.float32)     # C = A B2^T
+    c = np.zeros(5 * 3, np.float32)
+    L.orc_matmul(2, c, np.ascontiguousarray(A.T).reshape(-1), 5, 7, np.ascontiguousarray(B2.T).reshape(-1), 3, 7, 0)
+    assert np.allclose(c.reshape(3, 5).T, A @ B2.T, atol=1e-5)
+
+
+def test_oracle_quirks(orc):
+    """Q3 (softmax offset with max initialised to FLT_MIN), Q1 (dummy slots), Q10 (momentum SGD)."""
+    L = orc.lib()
+    P, C_, N = 2, 3, 2
+    w = np.array([0, 0, 0, 0, 0, 0, -5.0, -6.0, -7.0], np.float32)   # zero input weights, negative biases
+    x = np.zeros((N, P), np.float32); y = np.zeros(N * C_, np.float32); tmp = np.zeros(N, np.float32)
+    pat = np.array([2, 0], np.int8)
+    L.orc_softmax_forward(P, C_, 1.0, N, pat, w, x.reshape(-1), y, tmp)
+    e = np.exp(np.array([-5.0, -6.0, -7.0]) - 0.5 * (-7.0 + 0.0))     # max stays ~0: offset = -3.5
+    assert np.allclose(y[:3], e / e.sum(), rtol=1e-6)
+    assert np.allclose(y[3:], [-5, -6, -7])                           # dummy slot keeps the pre-activation
+    wts = np.array([1.0, 2.0], np.float32); g = np.array([0.5, -1.0], np.float32); dl = np.array([0.1, 0.0], np.float32)
+    L.orc_sgd_update(2, 0.1, 0.9, wts, g, dl)
+    assert np.allclose(dl, [0.9 * 0.1 - 0.05, 0.1]) and np.allclose(wts, [1.04, 2.1])

@@ -1,0 +1,136 @@
+"""The C++ host side (lstm-rnn_amd/host, binary lstm-rnn_amd/currennt_hip).
+
+CPU part: NetCDF-3 reader + fraction packer + length sort against the Python packer on a synthetic
+file.  GPU part (-m gpu): the `currennt`-style driver trains / forward-passes a network from the same
+network.jsn + .nc inputs the reference would take, and its outputs match the oracle driven from Python."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+from helpers import net_desc, random_weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "lstm-rnn_amd", "currennt_hip")
+
+
+def write_nc(path, xs, ts, num_labels):
+    """CURRENNT classification file (reference README:600-646)."""
+    f = netcdf_file(path, "w")
+    n = sum(len(x) for x in xs)
+    f.createDimension("numSeqs", len(xs)); f.createDimension("numTimesteps", n)
+    f.createDimension("inputPattSize", xs[0].shape[1]); f.createDimension("numLabels", num_labels)
+    f.createDimension("maxSeqTagLength", 16)
+    tags = f.createVariable("seqTags", "c", ("numSeqs", "maxSeqTagLength"))
+    for i in range(len(xs)):
+        t = ("dir/seq%03d.wav" % i).ljust(16, "\0")
+        tags[i] = np.array(list(t), "c")
+    v = f.createVariable("seqLengths", "i", ("numSeqs",)); v[:] = np.array([len(x) for x in xs], np.int32)
+    v = f.createVariable("targetClasses", "i", ("numTimesteps",)); v[:] = np.concatenate(ts).astype(np.int32)
+    v = f.createVariable("inputs", "f", ("numTimesteps", "inputPattSize")); v[:] = np.concatenate(xs).astype(np.float32)
+    f.close()
+
+
+def problem(tmp_path, lens=(11, 5, 9, 3, 14, 7, 8)):
+    rng = np.random.RandomState(31)
+    P, C = 6, 4
+    layers = net_desc(P, [("blstm", 8), ("feedforward_tanh", 5)], C)
+    weights = random_weights(layers, rng, 0.3)
+    xs = [rng.randn(n, P).astype(np.float32) for n in lens]
+    ts = [rng.randint(0, C, n).astype(np.int32) for n in lens]
+    nc = str(tmp_path / "train.nc")
+    write_nc(nc, xs, ts, C)
+    net = str(tmp_path / "network.jsn")
+    doc = {"layers": layers, "weights": {k: {a: np.asarray(b).tolist() for a, b in w.items()} for k, w in weights.items()}}
+    json.dump(doc, open(net, "w"))
+    return layers, weights, xs, ts, nc, net
+
+
+def test_reader_and_packer_cpu(pkg, tmp_path):
+    if not os.path.exists(BIN):
+        import __graft_entry__ as ge
+        ge.build()
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    out = subprocess.run([BIN, "--train", "true", "--train_file", nc, "--network", net, "--parallel_sequences", "3",
+                          "--dump_fractions", "true"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l for l in out.stdout.splitlines() if l.startswith("FRACTION")]
+    fracs = pkg.make_fractions(xs, ts, 3, sort_by_length=True)       # training sets are length-sorted, DataSet.cpp:603-605
+    assert len(rows) == len(fracs) == 3
+    for row, f in zip(rows, fracs):
+        kv = dict(p.split("=") for p in row.split()[2:])
+        assert int(kv["T"]) == f["T"] and int(kv["Tmin"]) == f["Tmin"] and int(kv["seqs"]) == f["numSeqs"]
+        assert int(kv["none"]) == int((f["patTypes"] == 0).sum())
+        assert abs(float(kv["sum_inputs"]) - float(f["inputs"].astype(np.float64).sum())) < 1e-3
+        assert int(kv["sum_targets"]) == int(f["targetClasses"][f["targetClasses"] >= 0].sum())
+
+
+def test_driver_failure_exit_code(tmp_path):
+    """Errors end as "FAILED: <msg>" with exit code 2 (main.cpp:492-495)."""
+    if not os.path.exists(BIN):
+        pytest.skip("driver not built")
+    out = subprocess.run([BIN, "--train", "true", "--train_file", str(tmp_path / "missing.nc"), "--network", str(tmp_path / "missing.jsn")],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "FAILED:" in out.stdout
+
+
+@pytest.mark.gpu
+def test_driver_trains_like_oracle(pkg, orc, tmp_path):
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    trained = str(tmp_path / "trained.jsn")
+    out = subprocess.run([BIN, "--train", "true", "--stochastic", "true", "--train_file", nc, "--network", net,
+                          "--parallel_sequences", "3", "--max_epochs", "2", "--learning_rate", "1e-2", "--momentum", "0.9",
+                          "--save_network", trained], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert " Epoch | Duration |" in out.stdout and "Storing the trained network" in out.stdout
+    got = json.load(open(trained))
+    assert [l["name"] for l in got["layers"]] == [l["name"] for l in layers]
+    # oracle: same epoch protocol (Optimizer.cu:37-104): sorted sequences, update after every fraction
+    fracs = pkg.make_fractions(xs, ts, 3, sort_by_length=True)
+    ref = orc.OracleNetwork(layers, weights, 3, max(len(x) for x in xs))
+    for epoch in range(2):
+        for f in fracs:
+            ref.load_sequences(f); ref.compute_forward_pass(); ref.compute_backward_pass(); ref.update_weights(1e-2, 0.9)
+    for lay in ref.trainable_layers():
+        w = got["weights"][lay.name]
+        flat = np.concatenate([np.asarray(w[k], np.float32) for k in ("input", "bias", "internal")])
+        assert np.abs(flat - lay.weights).max() < 2e-5, lay.name
+
+
+@pytest.mark.gpu
+def test_driver_forward_pass_writers(pkg, orc, tmp_path):
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    csv = str(tmp_path / "ff.csv")
+    out = subprocess.run([BIN, "--train", "false", "--ff_input_file", nc, "--network", net, "--parallel_sequences", "4",
+                          "--ff_output_file", csv, "--ff_output_format", "single_csv", "--revert_std", "false"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = open(csv).read().strip().split("\n")
+    assert len(rows) == len(xs)
+    fracs = pkg.make_fractions(xs, ts, 4)                          # forward pass: file order, no sort
+    ref = orc.OracleNetwork(layers, weights, 4, max(len(x) for x in xs))
+    k = 0
+    for f in fracs:
+        ref.load_sequences(f); ref.compute_forward_pass()
+        y = ref.outputs()
+        for i, n in enumerate(f["seqLengths"]):
+            cells = rows[k].split(";")
+            assert cells[0] == "dir/seq%03d.wav" % k
+            vals = np.array(cells[1:], np.float64).reshape(n, -1)
+            assert np.abs(vals - y[:n, i, :]).max() < 1e-4        # csv carries 6 significant digits
+            k += 1
+    # HTK writer: big-endian header nSamples, period, bytes/frame, kind (main.cpp:446-459)
+    hdir = str(tmp_path / "htk")
+    out = subprocess.run([BIN, "--train", "false", "--ff_input_file", nc, "--network", net, "--parallel_sequences", "4",
+                          "--ff_output_file", hdir, "--ff_output_format", "htk", "--revert_std", "false"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = open(os.path.join(hdir, "dir", "seq000.wav.htk"), "rb").read()
+    n, period, bpf, kind = np.frombuffer(raw[:12], ">i4,>i4,>i2,>i2")[0]
+    assert (n, period, bpf, kind) == (len(xs[0]), 100000, 4 * 4, 9)
+    vals = np.frombuffer(raw[12:], ">f4").reshape(n, 4)
+    ref.load_sequences(fracs[0]); ref.compute_forward_pass()
+    assert np.abs(vals - ref.outputs()[:n, 0, :]).max() < 1e-5
