@@ -58,7 +58,10 @@ struct cn_ctx {
     std::vector<cn_layer *> layers;
 
     // current fraction (Layer::loadSequences, Layer.cpp:134-141)
-    int PS = 0, maxT = 0, T = 0, Tmin = 0, N = 0, numSeqs = 0;
+    // PS: parallel sequences as the caller sees them; PSp >= PS: sequence slots per time step on the
+    // device (padded to the recurrent kernels' sequence-group size; pad slots are permanent dummies).
+    // N = T*PSp frames on the device, Next = T*PS frames in host layouts.
+    int PS = 0, PSp = 0, rpl = 1, maxT = 0, T = 0, Tmin = 0, N = 0, Next = 0, numSeqs = 0;
     bool loaded = false;
     char *d_pat = nullptr;
     int *d_tcls = nullptr;
@@ -88,7 +91,7 @@ struct cn_layer {
     cn_layer *prev = nullptr;
     int size = 0;
     float bias = 0.f;
-    int PS = 0, maxT = 0;
+    int PS = 0, PSp = 0, maxT = 0;
     bool trainable = false, post = false, lstm = false, has_follower = false;
 
     int dirs = 1, H = 0, Hp = 0;          // lstm geometry
@@ -122,7 +125,7 @@ struct cn_layer {
 
     std::vector<void *> owned;            // device allocations to free
 
-    size_t maxN() const { return (size_t)PS * maxT; }
+    size_t maxN() const { return (size_t)PSp * maxT; }
 };
 
 namespace {
@@ -245,12 +248,12 @@ void require_loaded(cn_ctx *c)
 void lstm_rec_args(cn_layer *l, LstmRec &r)
 {
     cn_ctx *c = l->ctx;
-    r.H = l->H; r.Hp = l->Hp; r.dirs = l->dirs; r.PS = c->PS; r.T = c->T; r.Tmin = c->Tmin;
+    r.H = l->H; r.Hp = l->Hp; r.dirs = l->dirs; r.PS = c->PSp; r.T = c->T; r.Tmin = c->Tmin;
     r.pat = c->d_pat;
     r.acts = l->acts; r.cell = l->cell; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
-    r.rpl_override = c->rpl_override;
+    r.rpl = c->rpl;
 }
 
 void lstm_forward(cn_layer *l)
@@ -276,7 +279,7 @@ void lstm_forward(cn_layer *l)
 void lstm_backward(cn_layer *l)
 {
     cn_ctx *c = l->ctx;
-    const int R = l->dirs * 4 * l->Hp, Hp = l->Hp, PS = c->PS, N = c->N;
+    const int R = l->dirs * 4 * l->Hp, Hp = l->Hp, PS = c->PSp, N = c->N;
     const size_t e = c->esz();
     repack(l);
     {
@@ -413,7 +416,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-        if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);
+        if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
@@ -471,6 +474,15 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
         l->ctx = ctx; l->kind = kind; l->prev = preceding; l->size = size; l->bias = bias;
         l->PS = preceding ? preceding->PS : parallel_sequences;
         l->maxT = preceding ? preceding->maxT : max_seq_length;
+        if (!preceding) {
+            // sequences per workgroup of the recurrent kernels: the fewest (4, 8, 16) that still give at most
+            // one workgroup per CU for a bidirectional layer; PS is padded to a whole number of groups
+            int rpl = ctx->rpl_override ? ctx->rpl_override : (2 * ((l->PS + 3) / 4) <= 256 ? 1 : (2 * ((l->PS + 7) / 8) <= 256 ? 2 : 4));
+            if (rpl != 1 && rpl != 2 && rpl != 4) throw cn_error(CN_ERR_BAD_ARG, "CN_RPL must be 1, 2 or 4");
+            ctx->rpl = rpl;
+            ctx->PSp = round_up(l->PS, 4 * rpl);
+        }
+        l->PSp = ctx->PSp;
         const size_t maxN = l->maxN(), e = ctx->esz();
         if (preceding) { l->P = preceding->size; l->Pp = preceding->Lp; }
 
@@ -482,7 +494,8 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             ctx->PS = l->PS; ctx->maxT = l->maxT;
             HIP_CHECK(hipMalloc((void **)&ctx->d_pat, maxN));
             HIP_CHECK(hipMalloc((void **)&ctx->d_tcls, maxN * sizeof(int)));
-            HIP_CHECK(hipMemsetAsync(ctx->d_pat, 0, maxN, ctx->stream));
+            HIP_CHECK(hipMemsetAsync(ctx->d_pat, 0, maxN, ctx->stream));                       // pad slots: PATTYPE_NONE forever
+            HIP_CHECK(hipMemsetAsync(ctx->d_tcls, 0xFF, maxN * sizeof(int), ctx->stream));     // pad slots: target class -1
             break; }
         case CN_LAYER_LSTM:
         case CN_LAYER_BLSTM: {
@@ -590,21 +603,25 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
         if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
         finalize(ctx);
-        const size_t N = (size_t)T * ctx->PS;
+        const size_t PS = ctx->PS, PSp = ctx->PSp;
+        const size_t N = (size_t)T * PSp;
         Timed tm(ctx, KC_OTHER);
-        HIP_CHECK(hipMemcpyAsync(ctx->d_pat, f->pat_types, N, kind, ctx->stream));
-        HIP_CHECK(hipMemcpyAsync(input->stage_in, f->inputs, N * input->size * sizeof(float), kind, ctx->stream));
+        // strided copies [T][PS] -> [T][PSp]: pad slots keep their permanent NONE / -1 / 0 contents
+        HIP_CHECK(hipMemcpy2DAsync(ctx->d_pat, PSp, f->pat_types, PS, PS, T, kind, ctx->stream));
+        const size_t irow = (size_t)input->size * sizeof(float);
+        HIP_CHECK(hipMemcpy2DAsync(input->stage_in, PSp * irow, f->inputs, PS * irow, PS * irow, T, kind, ctx->stream));
         if (post_output) {
             if (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
                 if (!f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
-                HIP_CHECK(hipMemcpyAsync(ctx->d_tcls, f->target_classes, N * sizeof(int), kind, ctx->stream));
+                HIP_CHECK(hipMemcpy2DAsync(ctx->d_tcls, PSp * sizeof(int), f->target_classes, PS * sizeof(int), PS * sizeof(int), T, kind, ctx->stream));
             } else {
                 if (!f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
-                HIP_CHECK(hipMemcpyAsync(post_output->targets, f->targets, N * post_output->size * sizeof(float), kind, ctx->stream));
+                const size_t trow = (size_t)post_output->size * sizeof(float);
+                HIP_CHECK(hipMemcpy2DAsync(post_output->targets, PSp * trow, f->targets, PS * trow, PS * trow, T, kind, ctx->stream));
             }
         }
         launch_pad_convert(ctx->stream, ctx->f32, input->stage_in, (int)N, input->size, input->out_op, input->Lp);
-        ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->numSeqs = f->num_sequences;
+        ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
         ctx->loaded = true;
     });
 }
@@ -756,12 +773,12 @@ int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t coun
         HIP_CHECK(hipSetDevice(c->device));
         require_loaded(c);
         if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_write_output_errors: layer has no outputErrors");
-        if (count != (size_t)c->N * layer->size) throw cn_error(CN_ERR_SHAPE, "cn_layer_write_output_errors: count != T*PS*size");
+        if (count != (size_t)c->Next * layer->size) throw cn_error(CN_ERR_SHAPE, "cn_layer_write_output_errors: count != T*PS*size");
         float *tmp = nullptr;
         HIP_CHECK(hipMalloc((void **)&tmp, count * sizeof(float)));
         HIP_CHECK(hipMemcpyAsync(tmp, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipMemsetAsync(layer->err, 0, (size_t)c->N * layer->Lp * sizeof(float), c->stream));
-        launch_pad_f32(c->stream, tmp, c->N, layer->size, layer->err, layer->Lp, layer->lstm ? layer->H : 0, layer->lstm ? layer->Hp : 0);
+        launch_pad_f32(c->stream, tmp, c->Next, layer->size, layer->err, layer->Lp, layer->lstm ? layer->H : 0, layer->lstm ? layer->Hp : 0, c->PS, c->PSp);
         HIP_CHECK(hipStreamSynchronize(c->stream));
         hipFree(tmp);
     });
@@ -786,7 +803,7 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
             return;
         }
         require_loaded(c);
-        const int N = c->N;
+        const int N = c->Next;                 // host layout: T*PS patterns
         int width = layer->size;
         if (which >= CN_BUF_LSTM_CELL_STATES) {
             if (!layer->lstm) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: not an LSTM layer");
@@ -799,26 +816,26 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
         const int R = layer->dirs * 4 * layer->Hp, Hp = layer->Hp, H = layer->H;
         switch (which) {
         case CN_BUF_OUTPUTS:
-            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, 1, N, layer->size, tmp, layer->size, 0);
+            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else if (layer->lstm)
-                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H);
-            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0);
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
+            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputs");
             break;
         case CN_BUF_OUTPUT_ERRORS:
             if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputErrors");
             if (layer->lstm)
-                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H);
-            else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0);
+                for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
+            else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             break;
         case CN_BUF_LSTM_CELL_STATES:
-            launch_unpad(c->stream, false, layer->cell, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, false, layer->cell, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0, c->PS, c->PSp); break;
         case CN_BUF_LSTM_TMP_OUTPUTS:
-            launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, dir * Hp, 1, N, H, tmp, H, 0, c->PS, c->PSp); break;
         case CN_BUF_LSTM_NI_ACTS: case CN_BUF_LSTM_IG_ACTS: case CN_BUF_LSTM_FG_ACTS: case CN_BUF_LSTM_OG_ACTS:
-            launch_unpad(c->stream, false, layer->acts, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_ACTS), 4, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, false, layer->acts, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_ACTS), 4, N, H, tmp, H, 0, c->PS, c->PSp); break;
         case CN_BUF_LSTM_NI_DELTAS: case CN_BUF_LSTM_IG_DELTAS: case CN_BUF_LSTM_FG_DELTAS: case CN_BUF_LSTM_OG_DELTAS:
-            launch_unpad(c->stream, opbf, layer->delta_op, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_DELTAS), 4, N, H, tmp, H, 0); break;
+            launch_unpad(c->stream, opbf, layer->delta_op, R, dir * 4 * Hp + (which - CN_BUF_LSTM_NI_DELTAS), 4, N, H, tmp, H, 0, c->PS, c->PSp); break;
         default:
             hipFree(tmp);
             throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: unknown buffer");

@@ -197,38 +197,39 @@ void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P,
 }
 
 template <bool BF16>
-__global__ void unpad_kernel(const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0)
+__global__ void unpad_kernel(const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp)
 {
     const long total = (long)N * L;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / L; const int j = idx % L;
+        const long ns = (n / PS) * PSp + n % PS;          // device row of host pattern n
         float v;
-        if constexpr (BF16) v = (float)((const __bf16 *)src)[n * ld + col0 + (long)j * cstride];
-        else v = ((const float *)src)[n * ld + col0 + (long)j * cstride];
+        if constexpr (BF16) v = (float)((const __bf16 *)src)[ns * ld + col0 + (long)j * cstride];
+        else v = ((const float *)src)[ns * ld + col0 + (long)j * cstride];
         dst[n * ldd + dcol0 + j] = v;
     }
 }
-void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0)
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp)
 {
     long total = (long)N * L; if (total <= 0) return;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    if (src_is_bf16) hipLaunchKernelGGL(unpad_kernel<true>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0);
-    else             hipLaunchKernelGGL(unpad_kernel<false>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0);
+    if (src_is_bf16) hipLaunchKernelGGL(unpad_kernel<true>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0, PS, PSp);
+    else             hipLaunchKernelGGL(unpad_kernel<false>, dim3(blocks), dim3(256), 0, s, src, ld, col0, cstride, N, L, dst, ldd, dcol0, PS, PSp);
 }
 
-__global__ void pad_f32_kernel(const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp)
+__global__ void pad_f32_kernel(const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp, int PS, int PSp)
 {
     const long total = (long)N * L;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long n = idx / L; const int j = idx % L;
-        dst[n * ld + pad_col(j, prevH, prevHp)] = src[idx];
+        dst[((n / PS) * PSp + n % PS) * ld + pad_col(j, prevH, prevHp)] = src[idx];
     }
 }
-void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp)
+void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp, int PS, int PSp)
 {
     long total = (long)N * L; if (total <= 0) return;
     int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pad_f32_kernel, dim3(blocks), dim3(256), 0, s, src, N, L, dst, ld, prevH, prevHp);
+    hipLaunchKernelGGL(pad_f32_kernel, dim3(blocks), dim3(256), 0, s, src, N, L, dst, ld, prevH, prevHp, PS, PSp);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -55,7 +55,7 @@ struct LstmRec {
     float *dbias;                 // [dirs][Hp][4] fp32 accumulators (pre-zeroed)
     float *dpeep;                 // [dirs][3][Hp]
     float bias;                   // JSON bias value (scales the bias gradient)
-    int rpl_override;             // 0 = choose sequences per lane from PS; 1/2/4 force it (tests)
+    int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
 };
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
 void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
@@ -93,8 +93,9 @@ void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const 
 // UpdateWeightFn over a flat range
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
-void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0);
+// (host row n = t*PS + s maps to device row t*PSp + s)
+void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp);
 // scatter host-provided [N][L] fp32 into a padded fp32 matrix (tests)
-void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp);
+void launch_pad_f32(hipStream_t s, const float *src, int N, int L, float *dst, long ld, int prevH, int prevHp, int PS, int PSp);
 
 }  // namespace cn

@@ -122,10 +122,22 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
         }
     }
 
-    bool valid[RPL];
-    long soff[RPL];                                  // sequence offset inside a time step
+    // per-lane element offsets inside one time step (32-bit; the time step itself moves a wave-uniform
+    // base pointer, so a step costs no 64-bit per-lane address arithmetic)
+    // PS is padded to a multiple of 4*RPL on the device (pad slots are permanent dummies), so every lane
+    // owns real memory: no lane predication, no divergent branch inside the time loop.
+    int oP[RPL], oA[UG][RPL], oC[UG][RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) { const int s = s0 + 4 * r + q; valid[r] = s < PS; soff[r] = valid[r] ? s : 0; }
+    for (int r = 0; r < RPL; ++r) {
+        const int sv = s0 + 4 * r + q;
+        oP[r] = sv;
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            oA[u][r] = sv * (int)arow + (d * Hp + unit[u]) * 4;
+            oC[u][r] = sv * (int)crow + d * Hp + unit[u];
+        }
+    }
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
 
     float cst[UG][RPL];
 #pragma unroll
@@ -133,19 +145,20 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
 #pragma unroll
         for (int r = 0; r < RPL; ++r) cst[u][r] = 0.f;
 
-    // two prefetch stages (steps it and it+1), addressed statically through the lambda parameters
+    // two prefetch stages (steps it and it+1), addressed statically through the lambda parameters.
+    // Prefetches are unconditional (time index clamped) so the staged registers are plain load
+    // results: no select against an old value, no wait at the loop back edge.
     f32x4 preA[UG][RPL], preB[UG][RPL];
     char ptA[RPL], ptB[RPL];
     auto prefetch = [&](int t, f32x4 (&pre)[UG][RPL], char (&pt)[RPL]) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float *actsT = p.acts + t * stepA;
+        const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const long n = (long)t * PS + soff[r];
-            pt[r] = valid[r] ? p.pat[n] : 0;
+            pt[r] = patT[oP[r]];
 #pragma unroll
-            for (int u = 0; u < UG; ++u) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                pre[u][r] = valid[r] ? *(const f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) : z;
-            }
+            for (int u = 0; u < UG; ++u) pre[u][r] = *(const f32x4 *)(actsT + oA[u][r]);
         }
     };
 
@@ -154,6 +167,8 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
         const char *ycur = smem + (it & 1) * 16 * pitch;
         char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
+        float *actsT = p.acts + t * stepA;
+        float *cellT = p.cell + t * stepC;
 
         f32x4 acc[UG][4];
         char ptc[RPL];
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[u][g][r] = (r < RPL) ? pre[u][r < RPL ? r : 0][g] : 0.f;
 
-        if (it + 2 < T) prefetch(d ? t - 2 : t + 2, pre, pt);
+        prefetch(d ? t - 2 : t + 2, pre, pt);
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
         if constexpr (RES) {
@@ -198,8 +213,7 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                const bool dummy = !valid[r] || (check && ptc[r] == 0);
-                const long n = (long)t * PS + soff[r];
+                const bool dummy = check && ptc[r] == 0;
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
                 const float ni = tanh_ref<F32>(acc[u][0][r]);
@@ -213,22 +227,18 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
                 cst[u][r] = co;
                 if constexpr (F32) *(float *)(ynxt + (4 * q + r) * pitch + unit[u] * 4) = yo;
                 else *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit[u] * 2) = (__bf16)yo;
-                if (valid[r]) {
-                    if (!dummy) {
-                        const f32x4 av = {ni, ig, fg, og};
-                        *(f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) = av;
-                    }
-                    p.cell[n * crow + d * Hp + unit[u]] = co;
-                    if constexpr (F32) ((float *)p.y_op)[n * crow + d * Hp + unit[u]] = yo;
-                    else ((__bf16 *)p.y_op)[n * crow + d * Hp + unit[u]] = (__bf16)yo;
-                }
+                const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
+                *(f32x4 *)(actsT + oA[u][r]) = av;
+                cellT[oC[u][r]] = co;
+                if constexpr (F32) ((float *)p.y_op + t * stepC)[oC[u][r]] = yo;
+                else ((__bf16 *)p.y_op + t * stepC)[oC[u][r]] = (__bf16)yo;
             }
         }
         lds_barrier();
     };
 
     prefetch(d ? T - 1 : 0, preA, ptA);
-    if (T > 1) prefetch(d ? T - 2 : 1, preB, ptB);
+    prefetch(d ? T - 2 : 1, preB, ptB);
     lds_barrier();
     for (int it = 0; it < T; it += 2) {
         step(it, preA, ptA);
@@ -283,10 +293,18 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
         }
     }
 
-    bool valid[RPL];
-    long soff[RPL];
+    int oP[RPL], oA[UG][RPL], oC[UG][RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; ++r) { const int s = s0 + 4 * r + q; valid[r] = s < PS; soff[r] = valid[r] ? s : 0; }
+    for (int r = 0; r < RPL; ++r) {
+        const int sv = s0 + 4 * r + q;
+        oP[r] = sv;
+#pragma unroll
+        for (int u = 0; u < UG; ++u) {
+            oA[u][r] = sv * (int)arow + (d * Hp + unit[u]) * 4;
+            oC[u][r] = sv * (int)crow + d * Hp + unit[u];
+        }
+    }
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
 
     // carried across steps (values of the step processed just before = next(t) in time)
     float fgn[UG][RPL], ecn[UG][RPL], dign[UG][RPL], dfgn[UG][RPL], ccur[UG][RPL];
@@ -305,18 +323,20 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
     const int tfirst = d ? 0 : T - 1;
     BwdPre<UG, RPL> preA, preB;
     auto prefetch = [&](int t, BwdPre<UG, RPL> &pre) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);         // unconditional, clamped (see the forward kernel)
         const int tprev = d ? t + 1 : t - 1;          // prev(t) in the forward processing order
         const bool hasprev = tprev >= 0 && tprev < T; // lastCall, LstmLayer.cu:947,981
+        const float *actsT = p.acts + t * stepA, *errT = p.err + t * stepC;
+        const float *cellP = p.cell + (hasprev ? tprev : t) * stepC;
+        const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            const long n = (long)t * PS + soff[r];
-            pre.pt[r] = valid[r] ? p.pat[n] : 0;
+            pre.pt[r] = patT[oP[r]];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                pre.e[u][r] = valid[r] ? p.err[n * crow + d * Hp + unit[u]] : 0.f;
-                pre.a[u][r] = valid[r] ? *(const f32x4 *)(p.acts + n * arow + ((long)d * Hp + unit[u]) * 4) : z;
-                pre.cp[u][r] = (valid[r] && hasprev) ? p.cell[((long)tprev * PS + soff[r]) * crow + d * Hp + unit[u]] : 0.f;
+                pre.e[u][r] = errT[oC[u][r]];
+                pre.a[u][r] = *(const f32x4 *)(actsT + oA[u][r]);
+                pre.cp[u][r] = cellP[oC[u][r]];      // raw; masked with lastCall when consumed (no wait here)
             }
         }
     };
@@ -326,6 +346,8 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
         const char *dcur = smem + (it & 1) * 16 * pitch;
         char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
         const bool check = t >= p.Tmin;
+        const int tprev_ = d ? t + 1 : t - 1;
+        const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
 
         f32x4 acc[UG];
         f32x4 a_[UG][RPL];
@@ -338,9 +360,9 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[u][r] = (r < RPL) ? pre.e[u][r < RPL ? r : 0] : 0.f;
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) { cp_[u][r] = pre.cp[u][r]; a_[u][r] = pre.a[u][r]; }
+            for (int r = 0; r < RPL; ++r) { cp_[u][r] = hasprev_ ? pre.cp[u][r] : 0.f; a_[u][r] = pre.a[u][r]; }
         }
-        if (it + 2 < T) prefetch(d ? t + 2 : t - 2, pre);
+        prefetch(d ? t + 2 : t - 2, pre);
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
         if constexpr (RES) {
@@ -365,8 +387,7 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                const bool dummy = !valid[r] || (check && ptc[r] == 0);
-                const long n = (long)t * PS + soff[r];
+                const bool dummy = check && ptc[r] == 0;
                 // ComputeBlockErrorsFn, LstmLayer.cu:236-285
                 const float e = acc[u][r];
                 const float ni = a_[u][r][0], ig = a_[u][r][1], fg = a_[u][r][2], og = a_[u][r][3];
@@ -389,11 +410,11 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
                 if constexpr (F32) {
                     const f32x4 dv = {dni, dig, dfg, dog};
                     *(f32x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 16) = dv;
-                    if (valid[r]) *(f32x4 *)((float *)p.delta_op + n * arow + ((long)d * Hp + unit[u]) * 4) = dv;
+                    *(f32x4 *)((float *)p.delta_op + t * stepA + oA[u][r]) = dv;
                 } else {
                     const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
                     *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 8) = dv;
-                    if (valid[r]) *(bf16x4 *)((__bf16 *)p.delta_op + n * arow + ((long)d * Hp + unit[u]) * 4) = dv;
+                    *(bf16x4 *)((__bf16 *)p.delta_op + t * stepA + oA[u][r]) = dv;
                 }
             }
         }
@@ -404,9 +425,9 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
     for (int r = 0; r < RPL; ++r)
 #pragma unroll
         for (int u = 0; u < UG; ++u)
-            ccur[u][r] = valid[r] ? p.cell[((long)tfirst * PS + soff[r]) * crow + d * Hp + unit[u]] : 0.f;
+            ccur[u][r] = (p.cell + tfirst * stepC)[oC[u][r]];
     prefetch(tfirst, preA);
-    if (T > 1) prefetch(d ? 1 : T - 2, preB);
+    prefetch(d ? 1 : T - 2, preB);
     lds_barrier();
     for (int it = 0; it < T; it += 2) {
         step(it, preA);
@@ -438,7 +459,7 @@ template <bool F32, bool BWD, int HP, int UG, int RPL>
 static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
 {
     const int ELT = F32 ? 4 : 2;
-    const int nsg = (p.PS + 4 * RPL - 1) / (4 * RPL);
+    const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
     const int pitch = (BWD ? 4 : 1) * p.Hp * ELT + 16;
     const size_t lds = 2 * 16 * (size_t)pitch;
     auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
@@ -453,11 +474,8 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
 template <bool F32, bool BWD, int HP, int UG>
 static void launch_rpl(hipStream_t s, const LstmRec &p, int nwaves)
 {
-    // fewest sequences per workgroup that still fit one workgroup per CU (256 CUs)
-    const int rpl = p.rpl_override ? p.rpl_override
-                  : (p.dirs * ((p.PS + 3) / 4) <= 256 ? 1 : (p.dirs * ((p.PS + 7) / 8) <= 256 ? 2 : 4));
-    if (rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves);
-    else if (rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves);
+    if (p.rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves);
+    else if (p.rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves);
     else               launch_one<F32, BWD, HP, UG, 4>(s, p, nwaves);
 }
 
