@@ -159,6 +159,7 @@ def main():
             net.loss_accumulate()
             net.compute_backward_pass()
             if world > 1:
+                net.join()                                  # gradient GEMMs run on the library's side stream
                 dist.all_reduce(grads, op=dist.ReduceOp.SUM)
             net.update_weights_fused(args.lr, args.momentum)
             return f["frames"]

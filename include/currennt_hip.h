@@ -103,6 +103,11 @@ typedef struct cn_fraction {
 int  cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **out);
 int  cn_ctx_destroy(cn_ctx *ctx);
 int  cn_ctx_synchronize(cn_ctx *ctx);                                   /* [sync] */
+/* The weight-gradient GEMMs of a backward pass run on an internal side stream beside the next layer's
+ * recurrent kernel.  Every entry point of this library orders itself behind them; call cn_ctx_join before
+ * ANOTHER library (e.g. RCCL through torch.distributed) reads weightUpdates on the ctx stream: it makes the
+ * ctx stream wait (device-side, no host sync) for the side stream. */
+int  cn_ctx_join(cn_ctx *ctx);
 /* message of the last failed call on this thread (ctx may be NULL for creation failures) */
 const char *cn_last_error(cn_ctx *ctx);
 /* "gfx950" etc. of the bound device; version string of the library */

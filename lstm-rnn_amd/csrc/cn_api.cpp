@@ -53,6 +53,10 @@ struct cn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // side stream: weight-gradient GEMMs run beside the next layer's (latency-bound, 26-CU) recurrent kernel
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet
+    bool overlap = true;
     bool f32 = true;
     std::string arch;
     std::vector<cn_layer *> layers;
@@ -123,6 +127,8 @@ struct cn_layer {
     size_t grad_block_floats = 0;
     float *dWin = nullptr, *dWrec = nullptr, *dbias = nullptr, *dpeep = nullptr;
 
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+
     std::vector<void *> owned;            // device allocations to free
 
     size_t maxN() const { return (size_t)PSp * maxT; }
@@ -147,19 +153,39 @@ hipEvent_t get_event(cn_ctx *c)
     hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return e;
 }
 struct Timed {
-    cn_ctx *c; int cls; hipEvent_t a = nullptr;
-    Timed(cn_ctx *ctx, int k) : c(ctx), cls(k)
+    cn_ctx *c; int cls; hipEvent_t a = nullptr; hipStream_t st;
+    Timed(cn_ctx *ctx, int k, hipStream_t stream = nullptr) : c(ctx), cls(k), st(stream ? stream : ctx->stream)
     {
-        if (c->timing) { a = get_event(c); hipEventRecord(a, c->stream); }
+        if (c->timing) { a = get_event(c); hipEventRecord(a, st); }
     }
     ~Timed()
     {
-        if (a) { hipEvent_t b = get_event(c); hipEventRecord(b, c->stream); c->spans[cls].push_back({a, b}); }
+        if (a) { hipEvent_t b = get_event(c); hipEventRecord(b, st); c->spans[cls].push_back({a, b}); }
     }
 };
+
+// the main stream waits for everything the side stream still has in flight
+void join_side(cn_ctx *c)
+{
+    for (hipEvent_t e : c->pending_joins) HIP_CHECK(hipStreamWaitEvent(c->stream, e, 0));
+    c->pending_joins.clear();
+}
+// run `f(stream)` on the side stream after everything enqueued on the main stream so far
+template <typename F> void on_side(cn_layer *l, F &&f)
+{
+    cn_ctx *c = l->ctx;
+    if (!c->overlap) { f(c->stream); return; }
+    if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
+    HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
+    HIP_CHECK(hipStreamWaitEvent(c->side, l->ev_fork, 0));
+    f(c->side);
+    HIP_CHECK(hipEventRecord(l->ev_join, c->side));
+    c->pending_joins.push_back(l->ev_join);
+}
 void timing_collect(cn_ctx *c)
 {
     HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (c->side) HIP_CHECK(hipStreamSynchronize(c->side));
     for (int k = 0; k < KC_COUNT; ++k) {
         for (auto &sp : c->spans[k]) {
             float ms = 0.f;
@@ -299,30 +325,34 @@ void lstm_backward(cn_layer *l)
         g.M = N; g.N = l->Pp; g.K = R;
         launch_gemm_nt(c->stream, c->f32, g);
     }
-    {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
-        Timed tm(c, KC_GEMM_GRAD);
-        GemmTN g{};
-        g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
-        g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
-        launch_gemm_tn(c->stream, c->f32, g);
-        // K9 recurrent weights: dWrec[(g,j)][i] = sum_t delta[t][(g,j)] y[prev(t)][i]
-        if (N > PS) {
-            for (int d = 0; d < l->dirs; ++d) {
-                GemmTN r{};
-                const char *dl = (const char *)l->delta_op + (size_t)d * 4 * Hp * e;
-                const char *y = (const char *)l->out_op + (size_t)d * Hp * e;
-                if (d == 0) { r.A = dl + (size_t)PS * R * e; r.B = y; }                       // skipFirstPattern, LstmLayer.cu:432-435
-                else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
-                r.lda = R; r.ldb = l->Lp;
-                r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
-                launch_gemm_tn(c->stream, c->f32, r);
+    // K9 runs on the side stream: it only feeds weightUpdates, forked AFTER K8 so the critical-path GEMM has the chip to itself, and running beside the
+    // preceding layer's recurrent kernel (which occupies ~10 % of the CUs)
+    on_side(l, [&](hipStream_t st) {
+        {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
+            Timed tm(c, KC_GEMM_GRAD, st);
+            GemmTN g{};
+            g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
+            g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
+            launch_gemm_tn(st, c->f32, g);
+            // K9 recurrent weights: dWrec[(j,g)][i] = sum_t delta[t][(j,g)] y[prev(t)][i]
+            if (N > PS) {
+                for (int d = 0; d < l->dirs; ++d) {
+                    GemmTN r{};
+                    const char *dl = (const char *)l->delta_op + (size_t)d * 4 * Hp * e;
+                    const char *y = (const char *)l->out_op + (size_t)d * Hp * e;
+                    if (d == 0) { r.A = dl + (size_t)PS * R * e; r.B = y; }                       // skipFirstPattern, LstmLayer.cu:432-435
+                    else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
+                    r.lda = R; r.ldb = l->Lp;
+                    r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
+                    launch_gemm_tn(st, c->f32, r);
+                }
             }
         }
-    }
-    {
-        Timed tm(c, KC_OTHER);
-        launch_lstm_unpack_grads(c->stream, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu);
-    }
+        {
+            Timed tm(c, KC_OTHER, st);
+            launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu);
+        }
+    });
 }
 
 void ff_forward(cn_layer *l)
@@ -367,17 +397,19 @@ void ff_backward(cn_layer *l)
         g.M = N; g.N = l->Pp; g.K = l->Lp;
         launch_gemm_nt(c->stream, c->f32, g);
     }
-    {   // FeedForwardLayer.cu:200-207
-        Timed tm(c, KC_GEMM_GRAD);
-        GemmTN g{};
-        g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
-        g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
-        launch_gemm_tn(c->stream, c->f32, g);
-    }
-    {
-        Timed tm(c, KC_OTHER);
-        launch_ff_unpack_grads(c->stream, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu);
-    }
+    on_side(l, [&](hipStream_t st) {
+        {   // FeedForwardLayer.cu:200-207
+            Timed tm(c, KC_GEMM_GRAD, st);
+            GemmTN g{};
+            g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
+            g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
+            launch_gemm_tn(st, c->f32, g);
+        }
+        {
+            Timed tm(c, KC_OTHER, st);
+            launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu);
+        }
+    });
 }
 
 }  // namespace
@@ -416,6 +448,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
@@ -432,8 +466,13 @@ int cn_ctx_destroy(cn_ctx *ctx)
     return guarded([&] {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
+        if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
         std::vector<cn_layer *> ls = ctx->layers;
-        for (cn_layer *l : ls) { for (void *p : l->owned) hipFree(p); delete l; }
+        for (cn_layer *l : ls) {
+            for (void *p : l->owned) hipFree(p);
+            if (l->ev_fork) { hipEventDestroy(l->ev_fork); hipEventDestroy(l->ev_join); }
+            delete l;
+        }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
         hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena);
@@ -445,7 +484,18 @@ int cn_ctx_destroy(cn_ctx *ctx)
 int cn_ctx_synchronize(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_ctx_synchronize: ctx is NULL"; return CN_ERR_BAD_ARG; }
-    return guarded([&] { HIP_CHECK(hipStreamSynchronize(ctx->stream)); HIP_CHECK(hipGetLastError()); });
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        join_side(ctx);
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        HIP_CHECK(hipGetLastError());
+    });
+}
+
+int cn_ctx_join(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_ctx_join: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); join_side(ctx); });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -603,6 +653,7 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
         if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
         finalize(ctx);
+        join_side(ctx);                      // gradient GEMMs of the previous fraction still read the activations
         const size_t PS = ctx->PS, PSp = ctx->PSp;
         const size_t N = (size_t)T * PSp;
         Timed tm(ctx, KC_OTHER);
@@ -645,6 +696,7 @@ int cn_layer_forward(cn_layer *layer)
         HIP_CHECK(hipSetDevice(layer->ctx->device));
         require_loaded(layer->ctx);
         finalize(layer->ctx);
+        join_side(layer->ctx);
         if (layer->lstm) lstm_forward(layer);
         else if (layer->trainable) ff_forward(layer);
         /* input and post output layers: no-op (InputLayer.cpp:62-65, SsePostOutputLayer.cu:134-137) */
@@ -760,6 +812,7 @@ int cn_layer_upload(cn_layer *layer, cn_buffer which, const float *host, size_t 
         if (which != CN_BUF_WEIGHT_UPDATES && which != CN_BUF_WEIGHT_DELTAS) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_upload: not a parameter vector");
         if (count != (size_t)layer->nw) throw cn_error(CN_ERR_SHAPE, "cn_layer_upload: count != weight count");
         finalize(c);
+        join_side(c);
         HIP_CHECK(hipMemcpyAsync(which == CN_BUF_WEIGHT_UPDATES ? layer->wu : layer->wd, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
     });
@@ -791,6 +844,7 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
         cn_ctx *c = layer->ctx;
         HIP_CHECK(hipSetDevice(c->device));
         finalize(c);
+        join_side(c);
         const size_t e = c->esz();
         const bool opbf = !c->f32;
         // flat parameter vectors
@@ -887,6 +941,7 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
         HIP_CHECK(hipSetDevice(c->device));
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_sgd_update: layer has no weights");
         finalize(c);
+        join_side(c);
         Timed tm(c, KC_OTHER);
         launch_sgd(c->stream, layer->w, layer->wu, layer->wd, (size_t)layer->nw, learning_rate, momentum);
         layer->dirty = true;
@@ -899,6 +954,7 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
     return guarded([&] {
         HIP_CHECK(hipSetDevice(ctx->device));
         finalize(ctx);
+        join_side(ctx);
         Timed tm(ctx, KC_OTHER);
         launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum);
         for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;

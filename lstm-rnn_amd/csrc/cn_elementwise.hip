@@ -395,7 +395,7 @@ void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int 
 {
     if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
     if (N <= 0) return;
-    int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
+    int blocks = (N + 3) / 4; if (blocks > 256) blocks = 256;       // 2 same-address atomics per block: keep them few
     hipLaunchKernelGGL(mcc_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, loss2);
 }
 
@@ -435,7 +435,7 @@ void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char
 {
     if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
     if (N <= 0) return;
-    int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
+    int blocks = (N + 3) / 4; if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(sse_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, loss2);
 }
 

@@ -320,9 +320,11 @@ void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
     int tiles_m = (g.M + TN_BM - 1) / TN_BM, tiles_n = (g.N + TN_BN - 1) / TN_BN;
     int ntiles = tiles_m * tiles_n;
-    // enough K splits to fill the 256 CUs a few times over, each at least 4 K-tiles deep
-    int want = (1024 + ntiles - 1) / ntiles;
-    int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
+    // K splits: about one workgroup per CU.  Every split ends in M*N fp32 atomics, and the chip adds only
+    // ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md, global float atomics), so more splits than needed to
+    // fill the CUs turn the kernel atomic-bound (measured: 1024 workgroups -> 64 MB of atomics per launch).
+    int want = (256 + ntiles - 1) / ntiles;
+    int maxsplit = (g.K + 8 * TN_BK - 1) / (8 * TN_BK);
     int splits = want < maxsplit ? want : maxsplit;
     if (splits < 1) splits = 1;
     int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;

@@ -24,6 +24,11 @@
 //     through a double-buffered LDS tile in MFMA A-operand order; cell state, forget-gate carry and
 //     the peephole/bias gradient sums never leave registers.  Operands of the next two steps are
 //     prefetched from HBM while the current step computes; the LDS barrier does not drain them.
+//     (Measured and rejected: issuing the loop's loads as LDS-DMA into a per-wave ring plus asm stores with
+//     exact s_waitcnt vmcnt(2*ST+LD) counts -- bit-identical results, 5-8 % SLOWER: the step is bound by
+//     the MFMA -> cell-update -> LDS hand-off chain, not by memory waits.  A register-destination asm
+//     load is not an option at all: hipcc rotates the staged registers with v_mov while the load is in
+//     flight.)
 //   * fw/bw halves are written straight into the interleaved [N][2*Hp] layer output.
 #include "cn_internal.h"
 

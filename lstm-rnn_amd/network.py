@@ -255,6 +255,10 @@ class NeuralNetwork:
         """Output layer activations [T][PS][C] (NeuralNetwork.cpp:237-262 de-interleaves per sequence)."""
         return self.output_layer().outputs()
 
+    def join(self):
+        """Order the ctx stream behind the internal side stream (before an external all-reduce)."""
+        B.check(self.lib.cn_ctx_join(self.ctx), self.ctx)
+
     def synchronize(self):
         B.check(self.lib.cn_ctx_synchronize(self.ctx), self.ctx)
 
