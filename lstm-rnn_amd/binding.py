@@ -51,7 +51,8 @@ class Fraction(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libcurrennt_hip.so")
+    # CURRENNT_HIP_LIB: alternative build of the same library (A/B timing of two builds on one device)
+    return os.environ.get("CURRENNT_HIP_LIB") or os.path.join(_HERE, "libcurrennt_hip.so")
 
 
 def build_library(verbose=False):

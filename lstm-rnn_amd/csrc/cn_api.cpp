@@ -71,6 +71,8 @@ struct cn_ctx {
     int *d_tcls = nullptr;
     float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
     float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
+    float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
+    cn_layer *rowstat_of = nullptr;
 
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
@@ -97,6 +99,7 @@ struct cn_layer {
     float bias = 0.f;
     int PS = 0, PSp = 0, maxT = 0;
     bool trainable = false, post = false, lstm = false, has_follower = false;
+    bool mcc_pending = false;             // softmax layer: multiclass error injection deferred into the fused backward kernel
 
     int dirs = 1, H = 0, Hp = 0;          // lstm geometry
     int Lp = 0;                           // padded output width (row stride of out/err)
@@ -308,10 +311,7 @@ void lstm_backward(cn_layer *l)
     const int R = l->dirs * 4 * l->Hp, Hp = l->Hp, PS = c->PSp, N = c->N;
     const size_t e = c->esz();
     repack(l);
-    {
-        Timed tm(c, KC_OTHER);
-        HIP_CHECK(hipMemsetAsync(l->grad_block, 0, l->grad_block_floats * sizeof(float), c->stream));
-    }
+    // (the packed gradient accumulators are zero here: allocation clears them, the unpack kernel re-clears them)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
@@ -372,7 +372,9 @@ void ff_forward(cn_layer *l)
     }
     if (softmax) {
         Timed tm(c, KC_OTHER);
-        launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp);
+        const bool stat = c->d_rowstat != nullptr;
+        launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp, stat ? c->d_tcls : nullptr, stat ? c->d_rowstat : nullptr);
+        c->rowstat_of = stat ? l : nullptr;
         if (!c->f32 && l->has_follower) launch_pad_convert(c->stream, false, l->out_f32, c->N, l->Lp, l->out_op, l->Lp);
     }
 }
@@ -384,10 +386,15 @@ void ff_backward(cn_layer *l)
     repack(l);
     {
         Timed tm(c, KC_OTHER);
-        if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, l->out_f32, l->err, c->d_pat, N, l->size, l->Lp);
-        launch_ff_delta(c->stream, c->f32, ff_act(l->kind), l->out_f32, l->err, l->delta_op, N, l->size, l->Lp);
-        HIP_CHECK(hipMemsetAsync(l->grad_block, 0, l->grad_block_floats * sizeof(float), c->stream));
-        launch_colsum(c->stream, l->err, N, l->Lp, l->dbias);
+        if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 256) {
+            launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, l->err, l->delta_op, l->dbias);
+        } else {
+            if (l->mcc_pending) launch_mcc_backward(c->stream, l->out_f32, c->d_tcls, N, l->size, l->Lp, l->err);
+            if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, l->out_f32, l->err, c->d_pat, N, l->size, l->Lp);
+            launch_ff_delta(c->stream, c->f32, ff_act(l->kind), l->out_f32, l->err, l->delta_op, N, l->size, l->Lp);
+            launch_colsum(c->stream, l->err, N, l->Lp, l->dbias);
+        }
+        l->mcc_pending = false;
     }
     if (l->prev->trainable) {   // FeedForwardLayer.cu:188-198
         Timed tm(c, KC_GEMM_WIDE);
@@ -475,7 +482,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
-        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena);
+        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
     });
@@ -597,6 +604,8 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && size == 1)                                  // MulticlassClassificationLayer.cu:146-147
                 throw cn_error(CN_ERR_SHAPE, "The multiclass classification post output layer cannot be used for an output layer size of 1");
             l->post = true; l->Lp = preceding->Lp;
+            if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && preceding->kind == CN_LAYER_SOFTMAX && !ctx->d_rowstat)
+                HIP_CHECK(hipMalloc((void **)&ctx->d_rowstat, maxN * 2 * sizeof(float)));
             if (kind == CN_LAYER_SSE) l->targets = (float *)dalloc(l, maxN * size * sizeof(float));
             break; }
         default:
@@ -717,7 +726,7 @@ int cn_layer_backward(cn_layer *layer)
             Timed tm(c, KC_OTHER);
             cn_layer *o = layer->prev;
             if (layer->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-                launch_mcc_backward(c->stream, o->out_f32, c->d_tcls, c->N, layer->size, o->Lp, o->err);
+                o->mcc_pending = true;         // injected inside the output layer's backward pass (fused kernel)
             else
                 launch_sse_backward(c->stream, o->out_f32, layer->targets, c->d_pat, c->N, layer->size, o->Lp, o->err);
         }
@@ -735,7 +744,9 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
         cn_layer *o = post->prev;
         {
             Timed tm(c, KC_OTHER);
-            if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
+            if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
+                launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss, true);
+            else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
                 launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
             else
                 launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss, true);
@@ -761,7 +772,9 @@ int cn_loss_accumulate(cn_layer *post)
         require_loaded(c);
         cn_layer *o = post->prev;
         Timed tm(c, KC_OTHER);
-        if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
+        if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
+            launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
+        else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
             launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
         else
             launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss_acc, false);
@@ -830,6 +843,7 @@ int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t coun
         float *tmp = nullptr;
         HIP_CHECK(hipMalloc((void **)&tmp, count * sizeof(float)));
         HIP_CHECK(hipMemcpyAsync(tmp, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        layer->mcc_pending = false;
         HIP_CHECK(hipMemsetAsync(layer->err, 0, (size_t)c->N * layer->Lp * sizeof(float), c->stream));
         launch_pad_f32(c->stream, tmp, c->Next, layer->size, layer->err, layer->Lp, layer->lstm ? layer->H : 0, layer->lstm ? layer->Hp : 0, c->PS, c->PSp);
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -878,6 +892,10 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
             break;
         case CN_BUF_OUTPUT_ERRORS:
             if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputErrors");
+            if (layer->mcc_pending) {     // the deferred multiclass error injection becomes visible here
+                launch_mcc_backward(c->stream, layer->out_f32, c->d_tcls, c->N, layer->size, layer->Lp, layer->err);
+                layer->mcc_pending = false;
+            }
             if (layer->lstm)
                 for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
             else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);

@@ -92,8 +92,9 @@ void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, co
 }
 
 // packed fp32 gradients -> flat weightUpdates (same layout as the weights, LstmLayer.cu:577-581)
-__global__ void lstm_unpack_kernel(LstmGeom g, const float *dWin, const float *dWrec, const float *dbias,
-                                   const float *dpeep, float *wu)
+// Every packed accumulator is cleared right after it is read, so the next backward pass finds zeros without
+// a separate memset (padded entries only ever receive exact zeros).
+__global__ void lstm_unpack_kernel(LstmGeom g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu)
 {
     const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp;
     const long nIn = 4L * L * P, nB = 4L * L, nRec = 4L * L * H, nPe = 3L * L;
@@ -103,25 +104,28 @@ __global__ void lstm_unpack_kernel(LstmGeom g, const float *dWin, const float *d
         if (idx < nIn) {
             const int gg = idx / ((long)L * P), rem = idx % ((long)L * P);
             const int blk = rem / P, i = rem % P, d = blk / H, j = blk % H;
-            v = dWin[(((long)d * Hp + j) * 4 + gg) * Pp + pad_col(i, g.prevH, g.prevHp)];
+            float *src = &dWin[(((long)d * Hp + j) * 4 + gg) * Pp + pad_col(i, g.prevH, g.prevHp)];
+            v = *src; *src = 0.f;
         } else if (idx < nIn + nB) {
             const int k = idx - nIn, gg = k / L, blk = k % L, d = blk / H, j = blk % H;
-            v = dbias[(d * Hp + j) * 4 + gg];
+            float *src = &dbias[(d * Hp + j) * 4 + gg];
+            v = *src; *src = 0.f;
         } else if (idx < nIn + nB + nRec) {
             const long k = idx - nIn - nB;
             const int gg = k / ((long)L * H), rem = k % ((long)L * H);
             const int blk = rem / H, i = rem % H, d = blk / H, j = blk % H;
-            v = dWrec[((long)d * 4 * Hp + 4 * j + gg) * Hp + i];
+            float *src = &dWrec[((long)d * 4 * Hp + 4 * j + gg) * Hp + i];
+            v = *src; *src = 0.f;
         } else {
             const int k = idx - nIn - nB - nRec, pp = k / L, blk = k % L, d = blk / H, j = blk % H;
-            v = dpeep[(d * 3 + pp) * Hp + j];
+            float *src = &dpeep[(d * 3 + pp) * Hp + j];
+            v = *src; *src = 0.f;
         }
         wu[idx] = v;
     }
 }
 
-void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, const float *dWin, const float *dWrec,
-                              const float *dbias, const float *dpeep, float *wu)
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu)
 {
     long total = (long)g.L * (4 * (g.P + 1) + 4 * g.H + 3);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -157,19 +161,21 @@ void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const 
     else     hipLaunchKernelGGL(ff_pack_kernel<false>, dim3(blocks), dim3(256), 0, s, g, bias, w, W, WT, bias_p);
 }
 
-__global__ void ff_unpack_kernel(FfGeom g, float bias, const float *dW, const float *colsum, float *wu)
+__global__ void ff_unpack_kernel(FfGeom g, float bias, float *dW, float *colsum, float *wu)
 {
     const long nW = (long)g.L * g.P, total = nW + g.L;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         if (idx < nW) {
             const int j = idx / g.P, i = idx % g.P;
-            wu[idx] = dW[(long)j * g.Pp + pad_col(i, g.prevH, g.prevHp)];
+            float *src = &dW[(long)j * g.Pp + pad_col(i, g.prevH, g.prevHp)];
+            wu[idx] = *src; *src = 0.f;
         } else {
             wu[idx] = bias * colsum[idx - nW];                                     // FeedForwardLayer.cu:94-100
+            colsum[idx - nW] = 0.f;
         }
     }
 }
-void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, const float *dW, const float *colsum, float *wu)
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu)
 {
     long total = (long)g.L * (g.P + 1);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
@@ -315,12 +321,18 @@ __device__ __forceinline__ float safe_exp(float x)      // helpers/safeExp.cuh:3
     return expf(x);
 }
 
-__global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int Lp)
+// rowstat (optional): per pattern {log max(FLT_MIN, p_target), 1 if argmax == target} for the multiclass
+// post output layer, so that the loss evaluation is a fixed-order reduction of N pairs instead of a second
+// pass over the posteriors (MulticlassClassificationLayer.cu:55-68, :77-105)
+__global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int Lp, const int *tcls, float2 *rowstat)
 {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= N) return;
-    if (pat[row] == 0) return;                           // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+    if (pat[row] == 0) {                                 // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+        if (rowstat && lane == 0) rowstat[row] = make_float2(0.f, 0.f);
+        return;
+    }
     float *r = y + row * Lp;
     float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
     for (int j = lane; j < L; j += 64) { float v = r[j]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
@@ -329,12 +341,50 @@ __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int 
     float sum = 0.f;
     for (int j = lane; j < L; j += 64) { float x = safe_exp(r[j] - offset); r[j] = x; sum += x; }
     sum = wave_sum(sum);
-    for (int j = lane; j < L; j += 64) r[j] = r[j] / sum; // :152
+    float best = 0.f; int bi = 0;                        // CountCorrectClassificationsFn :89-99
+    const int tc = rowstat ? tcls[row] : -1;
+    float ptv = 0.f;                                     // posterior of the target class (one lane holds it)
+    for (int j = lane; j < L; j += 64) {
+        float v = r[j] / sum; r[j] = v;                  // :152
+        if (v > best) { best = v; bi = j; }
+        if (j == tc) ptv = v;
+    }
+    if (rowstat) {
+        ptv = wave_sum(ptv);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (best <= 0.f) bi = 0;
+        if (lane == 0) rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
+    }
 }
-void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp)
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat)
 {
     if (N <= 0) return;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp);
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
+}
+
+// fixed-order reduction of the row statistics: loss2[0] += -sum(log p), loss2[1] (int) += #correct
+__global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2)
+{
+    __shared__ float sl[1024]; __shared__ int sc[1024];
+    float l = 0.f; int c = 0;
+    for (int i = threadIdx.x; i < N; i += 1024) { float2 v = rowstat[i]; l += v.x; c += (int)v.y; }
+    sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss2[0] += -sl[0]; ((int *)loss2)[1] += sc[0]; }
+}
+void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset)
+{
+    if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
+    if (N <= 0) return;
+    hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float2 *)rowstat, N, loss2);
 }
 
 __global__ void softmax_bwd_kernel(const float *y, float *err, const char *pat, int N, int L, int Lp)
@@ -353,6 +403,49 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 {
     if (N <= 0) return;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, err, pat, N, L, Lp);
+}
+
+// multiclass_classification::computeBackwardPass + SoftmaxLayer::computeBackwardPass + the Identity delta +
+// ComputeBiasWeightUpdateFn in one pass over the posteriors (MulticlassClassificationLayer.cu:220-240,
+// SoftmaxLayer.cu:317-349, FeedForwardLayer.cu:69-102).  The injected error is -1/max(FLT_MIN, p_t) at the
+// target and 0 elsewhere, so sum_j y_j e_j has exactly one non-zero term: bit-identical to the three passes.
+// Requires Lp <= 256 (column sums live in 4 registers per lane).
+template <bool F32>
+__global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
+                                       float *err, void *delta_op, float *colsum)
+{
+    __shared__ float part[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
+        const int tc = tcls[row];
+        const bool real = pat[row] != 0;
+        const float *yr = y + row * Lp;
+        float et = 0.f, off = 0.f;
+        if (real && tc >= 0) { const float pt_ = yr[tc]; et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            if (j >= Lp) break;
+            float dl = 0.f;
+            if (real && j < L) dl = yr[j] * ((j == tc ? et : 0.f) - off);
+            err[row * Lp + j] = dl;
+            if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
+            cs[k] += dl;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[wv][lane + 64 * k] = cs[k];
+    __syncthreads();
+    for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
+}
+void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
+                            float *err, void *delta_op, float *colsum)
+{
+    if (N <= 0) return;
+    int blocks = (N + 3) / 4; if (blocks > 512) blocks = 512;
+    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
+    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
 }
 
 // ---------------------------------------------------------------------------------------------

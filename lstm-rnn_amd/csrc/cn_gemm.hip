@@ -182,28 +182,30 @@ void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
 // ---------------------------------------------------------------------------------------------
 // gemm_tn
 // ---------------------------------------------------------------------------------------------
-constexpr int TN_BM = 128, TN_BN = 128, TN_BK = 32;
-template <bool F32> struct TnGeom {
+// BT x BT output tile (BT = 64 or 128), 4 waves as 2 x 2, each wave (BT/2) x (BT/2) in 32x32 MFMA tiles.
+constexpr int TN_BK = 32;
+template <bool F32, int BT> struct TnGeom {
     static constexpr int ELT = F32 ? 4 : 2;
-    static constexpr int PITCH = TN_BM * ELT + 64;         // bf16: 320 B, f32: 576 B
+    static constexpr int PITCH = BT * ELT + 64;            // K-major rows; 4 consecutive k rows hit distinct bank quarters
     static constexpr int TILE = TN_BK * PITCH;
     static constexpr int LDS = 4 * TILE;                   // (A,B) x 2 buffers
-    static constexpr int CPR = TN_BM * ELT / 16;           // 16-byte chunks per tile row (16 / 32)
-    static constexpr int NLD = TN_BK * CPR / 256;          // chunks per thread per operand (2 / 4)
+    static constexpr int CPR = BT * ELT / 16;              // 16-byte chunks per tile row
+    static constexpr int NLD = TN_BK * CPR / 256;          // chunks per thread per operand
+    static constexpr int WT = BT / 64;                     // 32x32 MFMA tiles per wave and dimension
 };
 
-template <bool F32>
+template <bool F32, int BT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int ntiles, int kchunk)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = TnGeom<F32>;
-    constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD;
+    using G = TnGeom<F32, BT>;
+    constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD, WT = G::WT;
     constexpr int CH = 16 / ELT;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
-    const int m0 = (tile / tiles_n) * TN_BM, n0 = (tile % tiles_n) * TN_BN;
+    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     if (kbeg >= kend) return;
@@ -234,11 +236,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -253,16 +255,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
             // v_mfma_f32_32x32x2_f32: lane (r,h) holds A[m=r][k=2s+h] / B[k=2s+h][n=r]
 #pragma unroll 4
             for (int s2 = 0; s2 < TN_BK / 2; ++s2) {
-                float a[2], b[2];
+                float a[WT], b[WT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = *(const float *)(sa + (2 * s2 + fh) * PITCH + (wm * 64 + i * 32 + fr) * 4);
-                    b[i] = *(const float *)(sb + (2 * s2 + fh) * PITCH + (wn * 64 + i * 32 + fr) * 4);
+                for (int i = 0; i < WT; ++i) {
+                    a[i] = *(const float *)(sa + (2 * s2 + fh) * PITCH + (wm * (BT / 2) + i * 32 + fr) * 4);
+                    b[i] = *(const float *)(sb + (2 * s2 + fh) * PITCH + (wn * (BT / 2) + i * 32 + fr) * 4);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
@@ -271,14 +273,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
             const int g16 = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
 #pragma unroll
             for (int ks = 0; ks < TN_BK / 16; ++ks) {
-                bf16x8 a[2], b[2];
+                bf16x8 a[WT], b[WT];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < WT; ++i) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         int k = ks * 16 + 8 * (g16 >> 1) + 4 * jj + q;
-                        int ma = wm * 64 + i * 32 + 16 * (g16 & 1) + 4 * pp;
-                        int nb = wn * 64 + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                        int ma = wm * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                        int nb = wn * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
                         s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                             (s16x4 __attribute__((address_space(3))) *)(sa + k * PITCH + ma * 2));
                         s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -289,9 +291,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -300,14 +302,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
     }
 
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
+    for (int j = 0; j < WT; ++j) {
+        const int n = n0 + wn * (BT / 2) + j * 32 + fr;
         if (n >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int m = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= p.M) continue;
                 atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
             }
@@ -315,28 +317,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
     }
 }
 
-void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
+template <bool F32, int BT>
+static void launch_tn(hipStream_t s, const GemmTN &g)
 {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    int tiles_m = (g.M + TN_BM - 1) / TN_BM, tiles_n = (g.N + TN_BN - 1) / TN_BN;
-    int ntiles = tiles_m * tiles_n;
-    // K splits: about one workgroup per CU.  Every split ends in M*N fp32 atomics, and the chip adds only
-    // ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md, global float atomics), so more splits than needed to
-    // fill the CUs turn the kernel atomic-bound (measured: 1024 workgroups -> 64 MB of atomics per launch).
-    int want = (256 + ntiles - 1) / ntiles;
-    int maxsplit = (g.K + 8 * TN_BK - 1) / (8 * TN_BK);
-    int splits = want < maxsplit ? want : maxsplit;
+    const int tiles_m = (g.M + BT - 1) / BT, tiles_n = (g.N + BT - 1) / BT, ntiles = tiles_m * tiles_n;
+    // K splits: enough workgroups (~4 per CU) to hide the latency of the short per-workgroup K loops, but every
+    // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
+    // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
+    long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
+    int splits = (1024 + ntiles - 1) / ntiles;
+    int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
+    if (splits > maxsplit) splits = maxsplit;
+    if (splits > cap_atomic) splits = (int)cap_atomic;
     if (splits < 1) splits = 1;
     int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
     splits = (g.K + kchunk - 1) / kchunk;
+    auto kern = gemm_tn_kernel<F32, BT>;
+    constexpr int lds = TnGeom<F32, BT>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TnGeom<true>::LDS);
-        (void)hipFuncSetAttribute((const void *)gemm_tn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TnGeom<false>::LDS);
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    if (f32) hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(ntiles * splits), dim3(256), TnGeom<true>::LDS, s, g, tiles_n, ntiles, kchunk);
-    else     hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(ntiles * splits), dim3(256), TnGeom<false>::LDS, s, g, tiles_n, ntiles, kchunk);
+    hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(256), lds, s, g, tiles_n, ntiles, kchunk);
+}
+
+void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
+{
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+    // weight matrices of this workload are small (<= 1024 x 256): 64 x 64 tiles give the grid enough workgroups
+    // without deep K splits; 128 x 128 tiles take over once the output alone fills the chip
+    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (tiles64 >= 2048) { if (f32) launch_tn<true, 128>(s, g); else launch_tn<false, 128>(s, g); }
+    else                 { if (f32) launch_tn<true, 64>(s, g);  else launch_tn<false, 64>(s, g); }
 }
 
 }  // namespace cn

@@ -67,12 +67,12 @@ struct LstmGeom { int P, Pp, L, H, Hp, dirs; int prevH, prevHp, prevDirs; /* pre
 void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, const float *w,
                       void *Win, void *WinT, void *Wrec, void *WrecT, float *bias_p, float *peep_p);
 // packed fp32 gradients -> flat reference layout
-void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, const float *dWin, const float *dWrec,
-                              const float *dbias, const float *dpeep, float *wu);
+// (the packed accumulators are cleared as they are read)
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu);
 struct FfGeom { int P, Pp, L, Lp; int prevH, prevHp, prevDirs; };
 void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w,
                     void *W, void *WT, float *bias_p);
-void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, const float *dW, const float *colsum, float *wu);
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu);
 
 // inputs [N][P] fp32 (reference layout) -> [N][Pp] op, zero padded
 void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P, void *dst, int Pp);
@@ -81,7 +81,12 @@ void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *er
 // column sums of delta over the N slots (FeedForwardLayer.cu:82-102): colsum[j] += sum_n err[n][j]
 void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum);
 // softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
-void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp);
+// optional: tcls + rowstat[N][2] = {log p_target, argmax == target} for the multiclass loss
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat);
+void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset);
+// multiclass error injection + softmax Jacobian + delta copy + bias column sums in one pass (Lp <= 256)
+void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
+                            float *err, void *delta_op, float *colsum);
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
 // multiclass_classification: loss/#correct reduction and error injection

@@ -175,16 +175,22 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
 
+        // accumulators start at 0 (inline constant, nothing to set up before the first MFMA); the gate
+        // pre-activation of the N-wide GEMM is added to the real rows afterwards
         f32x4 acc[UG][4];
+        f32x4 g_[UG][RPL];
         char ptc[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) ptc[r] = pt[r];
 #pragma unroll
-        for (int u = 0; u < UG; ++u)
+        for (int u = 0; u < UG; ++u) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) g_[u][r] = pre[u][r];
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[u][g][r] = (r < RPL) ? pre[u][r < RPL ? r : 0][g] : 0.f;
+                for (int r = 0; r < 4; ++r) acc[u][g][r] = 0.f;
+        }
 
         prefetch(d ? t - 2 : t + 2, pre, pt);
 
@@ -221,11 +227,11 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
                 const bool dummy = check && ptc[r] == 0;
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
-                const float ni = tanh_ref<F32>(acc[u][0][r]);
-                const float ig = logistic<F32>(acc[u][1][r] + cp * pi[u]);
-                const float fg = logistic<F32>(acc[u][2][r] + cp * pf[u]);
+                const float ni = tanh_ref<F32>(acc[u][0][r] + g_[u][r][0]);
+                const float ig = logistic<F32>(acc[u][1][r] + g_[u][r][1] + cp * pi[u]);
+                const float fg = logistic<F32>(acc[u][2][r] + g_[u][r][2] + cp * pf[u]);
                 const float cs = ni * ig + cp * fg;
-                const float og = logistic<F32>(acc[u][3][r] + cs * po[u]);
+                const float og = logistic<F32>(acc[u][3][r] + g_[u][r][3] + cs * po[u]);
                 const float y = tanh_ref<F32>(cs) * og;
                 const float yo = dummy ? 0.f : y;
                 const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u][r] = (r < RPL) ? pre.e[u][r < RPL ? r : 0] : 0.f;
+            for (int r = 0; r < 4; ++r) acc[u][r] = (r < RPL) ? pre.e[u][r < RPL ? r : 0] : 0.f;     // err enters as the MFMA C operand
 #pragma unroll
             for (int r = 0; r < RPL; ++r) { cp_[u][r] = hasprev_ ? pre.cp[u][r] : 0.f; a_[u][r] = pre.a[u][r]; }
         }
