@@ -32,6 +32,8 @@
 //   * fw/bw halves are written straight into the interleaved [N][2*Hp] layer output.
 #include "cn_internal.h"
 
+#include <cstdlib>
+
 namespace cn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -88,7 +90,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // RPL : sequences per lane; a workgroup handles 4*RPL sequences: sequence s0 + 4*r + q sits in MFMA
 //       tile row 4*q + r (q = lane>>4, r < RPL), rows r >= RPL are zero padding
 template <bool F32, int HP, int UG, int RPL>
-__global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_fwd_kernel(LstmRec p)
+__global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ELT = F32 ? 4 : 2;
@@ -268,7 +270,7 @@ template <int UG, int RPL> struct BwdPre {
 };
 
 template <bool F32, int HP, int UG, int RPL>
-__global__ __launch_bounds__(HP ? HP * 4 : 1024) void lstm_bwd_kernel(LstmRec p)
+__global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ELT = F32 ? 4 : 2;
@@ -498,7 +500,13 @@ static void launch_rec(hipStream_t s, const LstmRec &p)
     case 32:  launch_rpl<F32, BWD, 32, 1>(s, p, 2); return;
     case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4); return;
     case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6); return;
-    case 128: launch_rpl<F32, BWD, 128, 1>(s, p, 8); return;
+    case 128:
+        // backward, bf16: every wave reads the whole 16 x 4Hp delta tile from LDS each step, so 8 waves move
+        // 128 KB per step through the 256 B/clk LDS port (as long as the MFMAs themselves); 4 waves owning two
+        // unit groups each halve that traffic at the same MFMA and VALU work per SIMD
+        if (BWD && !F32 && !getenv("CN_BWD_UG1")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);
+        else launch_rpl<F32, BWD, 128, 1>(s, p, 8);
+        return;
     default: break;
     }
     if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups);
