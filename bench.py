@@ -33,6 +33,21 @@ WORKLOADS = {
     "timit_1x128_lstm": dict(P=39, hidden=[("lstm", 128)], C=183),
 }
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak
+
+
+def pmc_bytes_per_launch(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc.json, made by
+    tools/make_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench's default
+    command; FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no summary matches."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    for k, v in data.items():
+        if kernel in k:
+            return v["bytes_per_launch"], os.path.basename(files[-1])
+    return None, None
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
@@ -227,13 +242,18 @@ def main():
             dom = "lstm_bwd_kernel" if tm["rec_bwd"][0] >= tm["rec_fwd"][0] else "lstm_fwd_kernel"
             ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if dom == "lstm_bwd_kernel" else (tm["rec_fwd"][0], nl_f, b_fwd)
             nlayers = len(wl["hidden"])
-            frames_per_launch = fr / (nl / 1.0) * 1.0            # every launch sees one fraction, one layer
+            frames_per_launch = fr / (nl / float(nlayers))      # one launch = one layer pass over one fraction
             bytes_per_launch = bpf / nlayers * frames_per_launch
             avg_s = ms / nl * 1e-3
             ach = bytes_per_launch / avg_s / 1e9
             total_ms = sum(v[0] for v in tm.values())
+            traffic, src = (None, None)
+            if args.workload == "timit_3x250_blstm_H125" and args.parallel_sequences == 50 and args.precision == "bf16":
+                tb, src = pmc_bytes_per_launch(dom)
+                traffic = tb / avg_s / 1e9 if tb else None
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                               "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
+                               "algorithmic_bytes_per_launch": bytes_per_launch,
                                "avg_launch_ms": ms / nl, "launches": nl,
                                "note": "latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
                                        "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items())}

@@ -1,0 +1,49 @@
+"""-m gpu: the flat parameter arena aliased as a torch tensor (what the RCCL all-reduce of bench.py sums),
+and the bench entry point under torch.distributed with one rank."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import net_desc, random_sequences, random_weights
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_arena_aliases_weight_updates(pkg):
+    import torch
+    rng = np.random.RandomState(4)
+    layers = net_desc(5, [("blstm", 8), ("lstm", 6)], 4)
+    weights = random_weights(layers, rng, 0.3)
+    xs, ts = random_sequences(rng, [7, 5, 3], 5, C=4)
+    frac = pkg.make_fraction(xs, ts, 3)
+    with pkg.NeuralNetwork(layers, weights, 3, 7) as net:
+        net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass()
+        wptr, gptr, dptr, count = net.param_arena()
+        net.join(); net.synchronize()
+        g = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device="cuda")
+        w = torch.as_tensor(pkg.parallel.DeviceArray(wptr, count), device="cuda")
+        flat_g = pkg.parallel.flatten_updates([l.weight_updates() for l in net.trainable_layers()])
+        flat_w = pkg.parallel.flatten_updates([l.weights() for l in net.trainable_layers()])
+        assert np.array_equal(g.cpu().numpy(), flat_g) and np.array_equal(w.cpu().numpy(), flat_w)
+        g.mul_(2.0)                                   # what a 2-rank all-reduce of equal shards would do
+        torch.cuda.synchronize()
+        for l, ref in zip(net.trainable_layers(), [l.weight_updates() for l in net.trainable_layers()]):
+            pass
+        assert np.allclose(pkg.parallel.flatten_updates([l.weight_updates() for l in net.trainable_layers()]), 2 * flat_g)
+
+
+def test_bench_under_torchrun_one_rank():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s" and d["scaling"] == "weak"
