@@ -71,6 +71,8 @@ struct cn_ctx {
     int *d_tcls = nullptr;
     float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
     float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
+    unsigned long long *d_xch = nullptr; size_t xch_bytes = 0;   // cluster kernels' exchange granules
+    int *d_fault = nullptr;       // device fault word (bounded spins)
     float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
     cn_layer *rowstat_of = nullptr;
 
@@ -268,6 +270,17 @@ void repack(cn_layer *l)
     l->dirty = false;
 }
 
+// after a stream sync: did a bounded spin of a cluster kernel give up?
+void check_fault(cn_ctx *c)
+{
+    int f = 0;
+    HIP_CHECK(hipMemcpy(&f, c->d_fault, sizeof(int), hipMemcpyDeviceToHost));
+    if (f) {
+        HIP_CHECK(hipMemset(c->d_fault, 0, sizeof(int)));
+        throw cn_error(CN_ERR_HIP, "recurrent cluster kernel: inter-workgroup hand-off timed out (results of this pass are invalid)");
+    }
+}
+
 void require_loaded(cn_ctx *c)
 {
     if (!c->loaded) throw cn_error(CN_ERR_STATE, "no fraction loaded (call cn_fraction_load first)");
@@ -283,6 +296,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
     r.rpl = c->rpl;
+    r.xch = c->d_xch; r.fault = c->d_fault;
 }
 
 void lstm_forward(cn_layer *l)
@@ -301,7 +315,7 @@ void lstm_forward(cn_layer *l)
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
-        launch_lstm_forward(c->stream, c->f32, r);
+        if (!launch_lstm_cluster(c->stream, c->f32, false, r)) launch_lstm_forward(c->stream, c->f32, r);
     }
 }
 
@@ -315,7 +329,7 @@ void lstm_backward(cn_layer *l)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        launch_lstm_backward(c->stream, c->f32, r);
+        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) launch_lstm_backward(c->stream, c->f32, r);
     }
     if (l->prev->trainable) {   // K8 (LstmLayer.cu:990-1009): one K = R product instead of 4*dirs
         Timed tm(c, KC_GEMM_WIDE);
@@ -461,6 +475,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
+        HIP_CHECK(hipMalloc((void **)&c->d_fault, sizeof(int)));
+        HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));
     });
     if (rc != CN_OK) { delete c; return rc; }
     *out = c;
@@ -482,7 +498,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
-        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat);
+        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
     });
@@ -496,6 +512,7 @@ int cn_ctx_synchronize(cn_ctx *ctx)
         join_side(ctx);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         HIP_CHECK(hipGetLastError());
+        check_fault(ctx);
     });
 }
 
@@ -576,6 +593,14 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->grad_block_floats = R * l->Pp + R * l->Hp + R + (size_t)l->dirs * 3 * l->Hp;
             l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
             l->dWin = l->grad_block; l->dWrec = l->dWin + R * l->Pp; l->dbias = l->dWrec + R * l->Hp; l->dpeep = l->dbias + R;
+            {   // exchange buffer of the multi-CU cluster kernels (layers whose W_rec exceeds one CU)
+                const size_t xb = lstm_cluster_xch_bytes(ctx->f32, l->Hp, l->dirs, ctx->PSp, ctx->rpl);
+                if (xb > ctx->xch_bytes) {
+                    if (ctx->d_xch) HIP_CHECK(hipFree(ctx->d_xch));
+                    HIP_CHECK(hipMalloc((void **)&ctx->d_xch, xb));
+                    ctx->xch_bytes = xb;
+                }
+            }
             break; }
         case CN_LAYER_FF_TANH:
         case CN_LAYER_FF_LOGISTIC:
@@ -754,6 +779,7 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
         float h[2];
         HIP_CHECK(hipMemcpyAsync(h, c->d_loss, sizeof(h), hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipStreamSynchronize(c->stream));
+        check_fault(c);
         *error = h[0];
         if (correct) {
             int cc; memcpy(&cc, &h[1], sizeof(int));
@@ -790,6 +816,7 @@ int cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
         HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         if (reset) HIP_CHECK(hipMemsetAsync(ctx->d_loss_acc, 0, sizeof(h), ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        check_fault(ctx);
         if (error_sum) *error_sum = h[0];
         if (correct_sum) { int cc; memcpy(&cc, &h[1], sizeof(int)); *correct_sum = cc; }
     });

@@ -56,9 +56,15 @@ struct LstmRec {
     float *dpeep;                 // [dirs][3][Hp]
     float bias;                   // JSON bias value (scales the bias gradient)
     int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
+    // multi-CU cluster kernels (cn_lstm_cluster.hip)
+    unsigned long long *xch;      // exchange granules, zeroed per launch (nullable: cluster path off)
+    int *fault;                   // set to 1 by a bounded spin that gave up
 };
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
 void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
+// cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
+size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl);
+bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p);
 
 // ---- element-wise / packing kernels -----------------------------------------------------------
 struct LstmGeom { int P, Pp, L, H, Hp, dirs; int prevH, prevHp, prevDirs; /* prevH=0: identity column map */ };

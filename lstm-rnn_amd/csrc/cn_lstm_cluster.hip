@@ -1,0 +1,374 @@
+// Recurrent LSTM kernels for layers whose W_rec does not fit one CU: a CLUSTER of CUs per (direction,
+// sequence group), each CU keeping the W_rec fragments of its own slice of hidden units in registers for the
+// whole pass and exchanging only y[t] (forward) / the four deltas (backward) of its units with its partners
+// once per time step.
+//
+// Why: with Hp = 256 (the Graves ASRU'13 reading of "3x250 BLSTM", CURRENNT "size": 500) the bf16 W_rec of one
+// direction is 512 KB -- more than the 160 KB LDS or the usable part of the 512 KB register file of a CU.
+// Streaming it from L2 every step (cn_lstm.hip, HP = 0) costs ~17 us per step; the hand-off below costs ~1 us.
+//
+// Hand-off (cdna_hip_programming.md Guideline 16, form R2 "the data IS the flag"): every lane publishes its
+// value as ONE naturally aligned 8-byte granule {tag = step + 1, value} with a relaxed agent-scope atomic store
+// (sc1, write-through); the consumer re-reads the granule with relaxed agent-scope atomic loads (sc1, bypasses
+// the per-CU L1) until the tag matches -- no fences, placement independent.  Granule slots alternate with the
+// step parity: a producer can only overwrite slot p at step t+2 after it has consumed its partners' step t+1,
+// which they published after consuming its step t from that very slot.  The exchange buffer is zeroed before
+// every launch (tags restart at 1); every spin is bounded and reports through a fault word instead of hanging.
+// Cluster members sit 8 block ids apart (same XCD under round-robin placement: speed only, never correctness);
+// the launcher only uses this path when the whole grid is resident (<= one workgroup per CU).
+//
+// Arithmetic is identical to cn_lstm.hip (same MFMA tiles, same cell update); bf16 operand mode only.
+#include "cn_internal.h"
+#include "cn_lstm_device.h"
+
+#include <cstdlib>
+
+namespace cn {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void publish(u64 *slot, unsigned epoch, unsigned value)
+{
+    __hip_atomic_store(slot, ((u64)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned consume(const u64 *slot, unsigned epoch, int *fault)
+{
+    u64 x;
+    int spins = 0;
+    for (;;) {
+        x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) break;
+        if (++spins > (1 << 21)) { *fault = 1; break; }      // ~1 s: a partner never arrived (not resident / faulted)
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return (unsigned)x;
+}
+
+// block id -> (cluster, member): the CS members of a cluster are 8 ids apart
+template <int CS>
+__device__ __forceinline__ void cluster_of(int &cluster, int &member)
+{
+    member = (blockIdx.x / 8) % CS;
+    cluster = (blockIdx.x / (8 * CS)) * 8 + blockIdx.x % 8;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int HP, int UPC, int RPL>
+__global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CS = HP / UPC, NT = UPC * 4, KC = HP / 32;
+    constexpr int pitch = HP * 2 + 16;
+    int cluster, member;
+    cluster_of<CS>(cluster, member);
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    if (cluster >= dirs * (PS / (4 * RPL))) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * (4 * RPL);
+    const int lunit = 16 * wave + c, unit = member * UPC + lunit;      // unit inside the slice / the direction
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x4 wreg[4][KC];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+            wreg[g][kc] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kc * 64 + q * 16);
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+
+    int oP[RPL], oA[RPL], oC[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int sv = s0 + 4 * r + q;
+        oP[r] = sv; oA[r] = sv * (int)arow + (d * HP + unit) * 4; oC[r] = sv * (int)crow + d * HP + unit;
+    }
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * NT);
+
+    float cst[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) cst[r] = 0.f;
+
+    f32x4 preA[RPL], preB[RPL];
+    char ptA[RPL], ptB[RPL];
+    auto prefetch = [&](int t, f32x4 (&pre)[RPL], char (&pt)[RPL]) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const float *actsT = p.acts + t * stepA;
+        const char *patT = p.pat + (long)t * PS;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { pt[r] = patT[oP[r]]; pre[r] = *(const f32x4 *)(actsT + oA[r]); }
+    };
+
+    auto step = [&](int it, f32x4 (&pre)[RPL], char (&pt)[RPL]) {
+        const int t = d ? T - 1 - it : it;
+        const char *ycur = smem + (it & 1) * 16 * pitch;
+        char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const bool check = t >= p.Tmin;
+        float *actsT = p.acts + t * stepA, *cellT = p.cell + t * stepC;
+        __bf16 *yT = (__bf16 *)p.y_op + t * stepC;
+        u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * NT);
+
+        f32x4 acc[4], g_[RPL];
+        char ptc[RPL];
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { ptc[r] = pt[r]; g_[r] = pre[r]; }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
+        prefetch(d ? t - 2 : t + 2, pre, pt);
+
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][kc]);
+        }
+
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const bool dummy = check && ptc[r] == 0;
+            const float cp = cst[r];
+            // ComputeBlockOutputFn, LstmLayer.cu:87-136
+            const float ni = tanh_ref<false>(acc[0][r] + g_[r][0]);
+            const float ig = logistic<false>(acc[1][r] + g_[r][1] + cp * pi);
+            const float fg = logistic<false>(acc[2][r] + g_[r][2] + cp * pf);
+            const float cs = ni * ig + cp * fg;
+            const float og = logistic<false>(acc[3][r] + g_[r][3] + cs * po);
+            const float y = tanh_ref<false>(cs) * og;
+            const float co = dummy ? 0.f : cs;
+            const __bf16 yb = (__bf16)(dummy ? 0.f : y);
+            cst[r] = co;
+            // hand y[t] of this unit to the partners first (it is on their critical path), then keep it here
+            if (it + 1 < T) publish(xslot + (long)member * (RPL * NT) + r * NT + tid, it + 1, __builtin_bit_cast(unsigned short, yb));
+            *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit * 2) = yb;
+            const f32x4 av = {ni, ig, fg, og};
+            *(f32x4 *)(actsT + oA[r]) = av;
+            cellT[oC[r]] = co;
+            yT[oC[r]] = yb;
+        }
+        // y[t] of the partners' units
+        if (it + 1 < T) {
+#pragma unroll
+            for (int m = 0; m < CS; ++m) {
+                if (m == member) continue;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const unsigned v = consume(xslot + (long)m * (RPL * NT) + r * NT + tid, it + 1, p.fault);
+                    *(unsigned short *)(ynxt + (4 * q + r) * pitch + (m * UPC + lunit) * 2) = (unsigned short)v;
+                }
+            }
+        }
+        lds_barrier();
+    };
+
+    prefetch(d ? T - 1 : 0, preA, ptA);
+    prefetch(d ? T - 2 : 1, preB, ptB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA, ptA);
+        if (it + 1 < T) step(it + 1, preB, ptB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+template <int RPL> struct ClBwdPre { f32x4 a[RPL]; float e[RPL], cp[RPL]; char pt[RPL]; };
+
+template <int HP, int UPC, int RPL>
+__global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CS = HP / UPC, NT = UPC * 4, KC = 4 * HP / 32;
+    constexpr int pitch = 4 * HP * 2 + 16;           // delta tile row: k = 4*unit + gate
+    int cluster, member;
+    cluster_of<CS>(cluster, member);
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    if (cluster >= dirs * (PS / (4 * RPL))) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * (4 * RPL);
+    const int lunit = 16 * wave + c, unit = member * UPC + lunit;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x4 wreg[KC];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) wreg[kc] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kc * 64 + q * 16);
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+
+    int oP[RPL], oA[RPL], oC[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+        const int sv = s0 + 4 * r + q;
+        oP[r] = sv; oA[r] = sv * (int)arow + (d * HP + unit) * 4; oC[r] = sv * (int)crow + d * HP + unit;
+    }
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * 2 * NT);
+
+    float fgn[RPL], ecn[RPL], dign[RPL], dfgn[RPL], ccur[RPL];
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) fgn[r] = ecn[r] = dign[r] = dfgn[r] = 0.f;
+
+    const int tfirst = d ? 0 : T - 1;
+    ClBwdPre<RPL> preA, preB;
+    auto prefetch = [&](int t, ClBwdPre<RPL> &pre) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const int tprev = d ? t + 1 : t - 1;
+        const bool hasprev = tprev >= 0 && tprev < T;
+        const float *actsT = p.acts + t * stepA, *errT = p.err + t * stepC;
+        const float *cellP = p.cell + (hasprev ? tprev : t) * stepC;
+        const char *patT = p.pat + (long)t * PS;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            pre.pt[r] = patT[oP[r]];
+            pre.e[r] = errT[oC[r]];
+            pre.a[r] = *(const f32x4 *)(actsT + oA[r]);
+            pre.cp[r] = cellP[oC[r]];
+        }
+    };
+
+    auto step = [&](int it, ClBwdPre<RPL> &pre) {
+        const int t = d ? it : T - 1 - it;
+        const char *dcur = smem + (it & 1) * 16 * pitch;
+        char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const bool check = t >= p.Tmin;
+        const int tprev_ = d ? t + 1 : t - 1;
+        const bool hasprev_ = tprev_ >= 0 && tprev_ < T;
+        __bf16 *deltaT = (__bf16 *)p.delta_op + t * stepA;
+        u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * 2 * NT);
+
+        f32x4 acc, a_[RPL];
+        float cp_[RPL];
+        char ptc[RPL];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (r < RPL) ? pre.e[r < RPL ? r : 0] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) { ptc[r] = pre.pt[r]; cp_[r] = hasprev_ ? pre.cp[r] : 0.f; a_[r] = pre.a[r]; }
+        prefetch(d ? t + 2 : t - 2, pre);
+
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+            mma16<false>(acc, a, wreg[kc]);
+        }
+
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            const bool dummy = check && ptc[r] == 0;
+            // ComputeBlockErrorsFn, LstmLayer.cu:236-285
+            const float e = acc[r];
+            const float ni = a_[r][0], ig = a_[r][1], fg = a_[r][2], og = a_[r][3];
+            const float cs = ccur[r], cp = cp_[r];
+            const float th = tanh_ref<false>(cs);
+            float dog = og * (1.0f - og) * th * e;
+            float ec = og * (1.0f - th * th) * e + po * dog;
+            ec += fgn[r] * ecn[r] + pi * dign[r] + pf * dfgn[r];
+            float dni = ig * (1.0f - ni * ni) * ec;
+            float dfg = fg * (1.0f - fg) * cp * ec;
+            float dig = ig * (1.0f - ig) * ni * ec;
+            dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
+            if (dummy) { dni = dig = dfg = dog = 0.f; ec = 0.f; }
+            fgn[r] = dummy ? 0.f : fg;
+            ecn[r] = ec; dign[r] = dig; dfgn[r] = dfg;
+            ccur[r] = cp;
+            sb[0] += dni; sb[1] += dig; sb[2] += dfg; sb[3] += dog;
+            spi += cp * dig; spf += cp * dfg; spo += cs * dog;
+            const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+            const u64 bits = __builtin_bit_cast(u64, dv);
+            if (it + 1 < T) {
+                u64 *mine = xslot + (long)member * (RPL * 2 * NT) + (r * 2) * NT + tid;
+                publish(mine, it + 1, (unsigned)bits);
+                publish(mine + NT, it + 1, (unsigned)(bits >> 32));
+            }
+            *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit * 8) = dv;
+            *(bf16x4 *)(deltaT + oA[r]) = dv;
+        }
+        if (it + 1 < T) {
+#pragma unroll
+            for (int m = 0; m < CS; ++m) {
+                if (m == member) continue;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const u64 *theirs = xslot + (long)m * (RPL * 2 * NT) + (r * 2) * NT + tid;
+                    const unsigned lo = consume(theirs, it + 1, p.fault);
+                    const unsigned hi = consume(theirs + NT, it + 1, p.fault);
+                    uint2 v = make_uint2(lo, hi);
+                    *(uint2 *)(dnxt + (4 * q + r) * pitch + (m * UPC + lunit) * 8) = v;
+                }
+            }
+        }
+        lds_barrier();
+    };
+
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) ccur[r] = (p.cell + tfirst * stepC)[oC[r]];
+    prefetch(tfirst, preA);
+    prefetch(d ? 1 : T - 2, preB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA);
+        if (it + 1 < T) step(it + 1, preB);
+    }
+
+    float v[7] = {sb[0], sb[1], sb[2], sb[3], spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
+    if (q == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------
+template <int HP, int UPC, int RPL, bool BWD>
+static void launch_cluster(hipStream_t s, const LstmRec &p)
+{
+    constexpr int CS = HP / UPC, NT = UPC * 4;
+    const int nclusters = p.dirs * (p.PS / (4 * RPL));
+    const int grid = (nclusters + 7) / 8 * 8 * CS;
+    const size_t lds = 2 * 16 * (size_t)((BWD ? 4 : 1) * HP * 2 + 16);
+    const size_t xbytes = (size_t)nclusters * 2 * CS * RPL * (BWD ? 2 : 1) * NT * sizeof(u64);
+    (void)hipMemsetAsync(p.xch, 0, xbytes, s);       // tags restart at 1 every launch
+    auto kern = BWD ? lstm_bwd_cluster_kernel<HP, UPC, RPL> : lstm_fwd_cluster_kernel<HP, UPC, RPL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
+}
+
+// bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
+size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl)
+{
+    if (f32 || Hp != 256 || getenv("CN_NO_CLUSTER")) return 0;
+    const int nclusters = dirs * (PS / (4 * rpl));
+    if ((nclusters + 7) / 8 * 8 * 2 > 256) return 0;           // every member must be resident (one workgroup per CU)
+    return (size_t)nclusters * 2 * 2 * rpl * 2 * 512 * sizeof(u64);
+}
+
+bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p)
+{
+    if (!p.xch || lstm_cluster_xch_bytes(f32, p.Hp, p.dirs, p.PS, p.rpl) == 0) return false;
+    if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
+    else if (p.rpl == 2) { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
+    else return false;
+    return true;
+}
+
+}  // namespace cn

@@ -191,3 +191,39 @@ def test_error_texts(pkg):
     bad = net_desc(5, [("blstm", 7)], 3)
     with pytest.raises(pkg.CurrenntHipError, match="Cannot create a bidirectional layer with an odd layer size"):
         pkg.NeuralNetwork(bad, None, 2, 4, seed=1)
+
+
+def test_cluster_kernel_matches_streaming_kernel(pkg, orc):
+    """H = 250 per direction (reading B: CURRENNT size 500 -> Hp = 256): in bf16 mode W_rec is split over a
+    2-CU cluster with a per-step hand-off (cn_lstm_cluster.hip).  Same arithmetic as the single-CU streaming
+    kernel, so the two agree to bf16 noise; both track the fp32 oracle loosely."""
+    import os
+    rng = np.random.RandomState(14)
+    P, C, PS = 20, 12, 10
+    layers = net_desc(P, [("blstm", 500)], C)
+    weights = random_weights(layers, rng, 0.06)
+    xs, ts = random_sequences(rng, [25, 25, 24, 22, 22, 20, 17, 15, 9, 4], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    res = {}
+    for mode in ("cluster", "stream"):
+        if mode == "stream":
+            os.environ["CN_NO_CLUSTER"] = "1"
+        try:
+            with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=1) as net:
+                net.load_sequences(frac); net.compute_forward_pass()
+                e, c = net.error_and_correct()
+                net.compute_backward_pass()
+                res[mode] = (net.outputs(), e, [l.weight_updates() for l in net.trainable_layers()],
+                             net.layers[1].internal("tmpOutputs", 1))
+        finally:
+            os.environ.pop("CN_NO_CLUSTER", None)
+    (y1, e1, g1, h1), (y2, e2, g2, h2) = res["cluster"], res["stream"]
+    assert np.abs(h1 - h2).max() < 1e-2 and np.abs(y1 - y2).max() < 2e-3
+    assert abs(e1 - e2) < 1e-3 * abs(e2)
+    for a, b in zip(g1, g2):
+        assert rel_err(a, b) < 1e-2
+    ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    ref.load_sequences(frac); ref.compute_forward_pass(); ref.compute_backward_pass()
+    assert np.abs(y1 - ref.outputs()).max() < 3e-2
+    for a, lay in zip(g1, ref.trainable_layers()):
+        assert rel_err(a, lay.weightUpdates) < 6e-2, lay.name
