@@ -47,3 +47,10 @@ def test_bench_under_torchrun_one_rank():
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s" and d["scaling"] == "weak"
+
+
+def test_rccl_allreduce_on_aliased_arena():
+    """RCCL (torch.distributed backend nccl, one rank) all-reduces the aliased weightUpdates arena in place."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_one_rank.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
