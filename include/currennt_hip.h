@@ -59,7 +59,15 @@ typedef enum cn_layer_kind {
     CN_LAYER_FF_IDENTITY,                 /* "feedforward_identity"                                 */
     CN_LAYER_SOFTMAX,                     /* "softmax"                    SoftmaxLayer.cu           */
     CN_LAYER_SSE,                         /* "sse"                        SsePostOutputLayer.cu     */
-    CN_LAYER_MULTICLASS_CLASSIFICATION    /* "multiclass_classification"  MulticlassClassificationLayer.cu */
+    CN_LAYER_MULTICLASS_CLASSIFICATION,   /* "multiclass_classification"  MulticlassClassificationLayer.cu */
+    /* remaining post output layers of LayerFactory.cu:52-87.  The weighted kinds have size == 2 * size of
+     * the output layer and take interleaved (target, weight | filter input) pairs in cn_fraction.targets;
+     * binary_classification has size 1 and reads cn_fraction.target_classes. */
+    CN_LAYER_WEIGHTEDSSE,                 /* "weightedsse"                WeightedSsePostOutputLayer.cu    */
+    CN_LAYER_SSE_MASK,                    /* "wf"                         SseMaskPostOutputLayer.cu        */
+    CN_LAYER_CE,                          /* "ce"                         CePostOutputLayer.cu             */
+    CN_LAYER_RMSE,                        /* "rmse"                       RmsePostOutputLayer.cu           */
+    CN_LAYER_BINARY_CLASSIFICATION        /* "binary_classification"      BinaryClassificationLayer.cu     */
 } cn_layer_kind;
 
 /* which device vector cn_layer_read / cn_layer_device_ptr addresses */

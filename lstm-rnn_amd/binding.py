@@ -13,6 +13,7 @@ LAYER_KINDS = {
     "input": 0, "lstm": 1, "blstm": 2,
     "feedforward_tanh": 3, "feedforward_logistic": 4, "feedforward_identity": 5,
     "softmax": 6, "sse": 7, "multiclass_classification": 8,
+    "weightedsse": 9, "wf": 10, "ce": 11, "rmse": 12, "binary_classification": 13,
 }
 
 # cn_buffer

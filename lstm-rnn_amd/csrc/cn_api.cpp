@@ -621,17 +621,29 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->dWin = l->grad_block; l->dbias = l->dWin + (size_t)l->Lp * l->Pp;
             break; }
         case CN_LAYER_SSE:
+        case CN_LAYER_WEIGHTEDSSE:
+        case CN_LAYER_SSE_MASK:
+        case CN_LAYER_CE:
+        case CN_LAYER_RMSE:
+        case CN_LAYER_BINARY_CLASSIFICATION:
         case CN_LAYER_MULTICLASS_CLASSIFICATION: {
             if (!preceding->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: a post output layer needs a trainable preceding layer");
             if (preceding->lstm) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: post output layers directly after an LSTM layer are not supported");
-            if (size != preceding->size)                                                                 // PostOutputLayer.cpp:58-59
+            const bool paired = kind == CN_LAYER_WEIGHTEDSSE || kind == CN_LAYER_SSE_MASK;
+            // PostOutputLayer.cpp:58-59; the weighted layers take (target, weight) pairs: PostOutputLayer.cpp:52-56
+            if (paired ? size != 2 * preceding->size : size != preceding->size)
                 throw cn_error(CN_ERR_SHAPE, "Size mismatch: " + std::to_string(size) + " vs. " + std::to_string(preceding->size));
+            if (kind == CN_LAYER_BINARY_CLASSIFICATION && size != 1)                                      // BinaryClassificationLayer.cu:139-140
+                throw cn_error(CN_ERR_SHAPE, "The binary classification post output layer cannot be used for an output layer size != 1");
             if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && size == 1)                                  // MulticlassClassificationLayer.cu:146-147
                 throw cn_error(CN_ERR_SHAPE, "The multiclass classification post output layer cannot be used for an output layer size of 1");
             l->post = true; l->Lp = preceding->Lp;
             if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && preceding->kind == CN_LAYER_SOFTMAX && !ctx->d_rowstat)
                 HIP_CHECK(hipMalloc((void **)&ctx->d_rowstat, maxN * 2 * sizeof(float)));
-            if (kind == CN_LAYER_SSE) l->targets = (float *)dalloc(l, maxN * size * sizeof(float));
+            if (kind != CN_LAYER_MULTICLASS_CLASSIFICATION) {
+                l->targets = (float *)dalloc(l, maxN * size * sizeof(float));
+                if (!ctx->d_rowstat) HIP_CHECK(hipMalloc((void **)&ctx->d_rowstat, maxN * 2 * sizeof(float)));
+            }
             break; }
         default:
             throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: unknown layer kind");
@@ -696,9 +708,11 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         const size_t irow = (size_t)input->size * sizeof(float);
         HIP_CHECK(hipMemcpy2DAsync(input->stage_in, PSp * irow, f->inputs, PS * irow, PS * irow, T, kind, ctx->stream));
         if (post_output) {
-            if (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
+            if (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION) {
                 if (!f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
                 HIP_CHECK(hipMemcpy2DAsync(ctx->d_tcls, PSp * sizeof(int), f->target_classes, PS * sizeof(int), PS * sizeof(int), T, kind, ctx->stream));
+                if (post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
+                    launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
             } else {
                 if (!f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
                 const size_t trow = (size_t)post_output->size * sizeof(float);
@@ -723,6 +737,18 @@ int cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_outpu
 // ---------------------------------------------------------------------------------------------
 // forward / backward / loss
 // ---------------------------------------------------------------------------------------------
+static int post_kind(const cn_layer *l)
+{
+    switch (l->kind) {
+    case CN_LAYER_WEIGHTEDSSE:           return POST_WEIGHTEDSSE;
+    case CN_LAYER_SSE_MASK:              return POST_SSE_MASK;
+    case CN_LAYER_CE:                    return POST_CE;
+    case CN_LAYER_RMSE:                  return POST_RMSE;
+    case CN_LAYER_BINARY_CLASSIFICATION: return POST_BINARY;
+    default:                             return POST_SSE;
+    }
+}
+
 int cn_layer_forward(cn_layer *layer)
 {
     if (!layer) { g_last_error = "cn_layer_forward: layer is NULL"; return CN_ERR_BAD_ARG; }
@@ -753,7 +779,7 @@ int cn_layer_backward(cn_layer *layer)
             if (layer->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
                 o->mcc_pending = true;         // injected inside the output layer's backward pass (fused kernel)
             else
-                launch_sse_backward(c->stream, o->out_f32, layer->targets, c->d_pat, c->N, layer->size, o->Lp, o->err);
+                launch_post_backward(c->stream, post_kind(layer), o->out_f32, layer->targets, c->d_pat, c->N, o->size, o->Lp, o->err);
         }
     });
 }
@@ -773,8 +799,10 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
                 launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss, true);
             else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
                 launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
-            else
-                launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss, true);
+            else {
+                launch_post_eval(c->stream, post_kind(post), o->out_f32, post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss, true);
+                c->rowstat_of = nullptr;       // the softmax row statistics were overwritten
+            }
         }
         float h[2];
         HIP_CHECK(hipMemcpyAsync(h, c->d_loss, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -783,7 +811,7 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
         *error = h[0];
         if (correct) {
             int cc; memcpy(&cc, &h[1], sizeof(int));
-            *correct = (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) ? cc : -1;
+            *correct = (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post->kind == CN_LAYER_BINARY_CLASSIFICATION) ? cc : -1;
         }
     });
 }
@@ -802,8 +830,10 @@ int cn_loss_accumulate(cn_layer *post)
             launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
         else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
             launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
-        else
-            launch_sse_eval(c->stream, o->out_f32, post->targets, c->d_pat, c->N, post->size, o->Lp, c->d_loss_acc, false);
+        else {
+            launch_post_eval(c->stream, post_kind(post), o->out_f32, post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss_acc, false);
+            c->rowstat_of = nullptr;
+        }
     });
 }
 

@@ -7,7 +7,7 @@
 //   layers/SoftmaxLayer.cu:45-160      offset/exp/sum/normalise  -> softmax_fwd_kernel (one pass)
 //   layers/SoftmaxLayer.cu:162-219     error offset / errors     -> softmax_bwd_kernel (one pass)
 //   layers/MulticlassClassificationLayer.cu:48-135               -> mcc_rows_kernel, mcc_backward_kernel
-//   layers/SsePostOutputLayer.cu:39-88                           -> sse_rows_kernel, sse_backward_kernel
+//   layers/SsePostOutputLayer.cu:39-88 and the other post output layers -> post_rows_kernel, post_backward_kernel
 //   optimizers/SteepestDescentOptimizer.cu:39-59 UpdateWeightFn  -> sgd_kernel
 #include "cn_internal.h"
 
@@ -367,7 +367,7 @@ void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, 
 }
 
 // fixed-order reduction of the row statistics: loss2[0] += -sum(log p), loss2[1] (int) += #correct
-__global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2)
+__global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2, float scale)
 {
     __shared__ float sl[1024]; __shared__ int sc[1024];
     float l = 0.f; int c = 0;
@@ -378,13 +378,13 @@ __global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2
         if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { loss2[0] += -sl[0]; ((int *)loss2)[1] += sc[0]; }
+    if (threadIdx.x == 0) { loss2[0] += scale * sl[0]; ((int *)loss2)[1] += sc[0]; }
 }
-void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset)
+void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset, float scale)
 {
     if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
     if (N <= 0) return;
-    hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float2 *)rowstat, N, loss2);
+    hipLaunchKernelGGL(rowstat_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float2 *)rowstat, N, loss2, scale);
 }
 
 __global__ void softmax_bwd_kernel(const float *y, float *err, const char *pat, int N, int L, int Lp)
@@ -509,44 +509,104 @@ void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, 
     hipLaunchKernelGGL(mcc_backward_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, err);
 }
 
-__global__ void sse_rows_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2)
+// ---------------------------------------------------------------------------------------------
+// post output layers other than multiclass_classification (sse: SsePostOutputLayer.cu:39-88; the rest is
+// SURVEY section 8 row f4).  L = size of the output layer, y pitch Lp;
+// targets hold L values per pattern, or 2L interleaved (target, weight | filter input) pairs.
+//   weightedsse  WeightedSsePostOutputLayer.cu:44-88     wf   SseMaskPostOutputLayer.cu:44-88
+//   ce           CePostOutputLayer.cu:44-96              rmse RmsePostOutputLayer.cu:44-93
+//   binary_classification  BinaryClassificationLayer.cu:48-113
+// One wave per pattern; the per-pattern term lands in rowstat[N] = {term, correct} and is summed
+// in a fixed order by rowstat_reduce_kernel (reproducible, no float atomics).
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ float post_term(float y, const float *tg, long i)
 {
-    __shared__ float sl[4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float lsum = 0.f;
-    for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
-        if (pat[row] == 0) continue;                              // SsePostOutputLayer.cu:53-54
-        float a = 0.f;
-        for (int j = lane; j < L; j += 64) { float df = tgt[row * L + j] - y[row * Lp + j]; a += df * df; }
-        lsum += wave_sum(a);
-    }
-    if (lane == 0) sl[wv] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&loss2[0], 0.5f * ((sl[0] + sl[1]) + (sl[2] + sl[3])));   // :121
+    if (KIND == POST_SSE)         { float df = tg[i] - y; return df * df; }
+    if (KIND == POST_WEIGHTEDSSE) { float df = (y - tg[2 * i]) * tg[2 * i + 1]; return df * df; }
+    if (KIND == POST_SSE_MASK)    { float df = y * tg[2 * i + 1] - tg[2 * i]; return df * df; }
+    if (KIND == POST_CE)          { float t = tg[i]; return t * logf(fmaxf(NL_MIN, t) / fmaxf(NL_MIN, y)); }
+    if (KIND == POST_RMSE)        { float df = y - tg[i]; return df * df; }
+    /* POST_BINARY */               float act = fmaxf(y, NL_MIN); return -logf(tg[i] > 0.f ? act : 1.f - act);
 }
-void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2, bool reset)
+template <int KIND>
+__device__ __forceinline__ float post_err(float y, const float *tg, long i, float rmse)
 {
-    if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
-    if (N <= 0) return;
-    int blocks = (N + 3) / 4; if (blocks > 256) blocks = 256;
-    hipLaunchKernelGGL(sse_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, loss2);
+    if (KIND == POST_SSE)         return y - tg[i];
+    if (KIND == POST_WEIGHTEDSSE) return (y - tg[2 * i]) * tg[2 * i + 1];
+    if (KIND == POST_SSE_MASK)    return (y * tg[2 * i + 1] - tg[2 * i]) * tg[2 * i + 1];
+    if (KIND == POST_CE)          return fminf(100.f, fmaxf(-100.f, -tg[i] / fmaxf(NL_MIN, y)));
+    if (KIND == POST_RMSE)        return rmse * (y - tg[i]);
+    /* POST_BINARY */               float act = fmaxf(y, NL_MIN); float tp = tg[i] > 0.f ? act : 1.f - act;
+                                    return tg[i] > 0.f ? -(1.f / tp) : (1.f / tp);
 }
 
-__global__ void sse_backward_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
+template <int KIND>
+__global__ void post_rows_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float2 *rowstat)
 {
-    const long total = (long)N * Lp;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long n = idx / Lp; const int j = idx % Lp;
-        float v = 0.f;
-        if (j < L && pat[n] != 0) v = y[idx] - tgt[n * L + j];    // SsePostOutputLayer.cu:79-86
-        err[idx] = v;
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    float a = 0.f, corr = 0.f;
+    if (pat[row] != 0) {
+        for (int j = lane; j < L; j += 64) a += post_term<KIND>(y[row * Lp + j], tgt, row * L + j);
+        a = wave_sum(a);
+        if (KIND == POST_RMSE) a = sqrtf(a / (float)L);
+        if (KIND == POST_BINARY) corr = ((tgt[row] > 0.5f) == (y[row * Lp] > 0.5f)) ? 1.f : 0.f;
     }
+    if (lane == 0) rowstat[row] = make_float2(a, corr);
 }
-void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
+
+template <int KIND>
+__global__ void post_backward_kernel(const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
 {
-    long total = (long)N * Lp; if (total <= 0) return;
-    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sse_backward_kernel, dim3(blocks), dim3(256), 0, s, y, tgt, pat, N, L, Lp, err);
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const bool real = pat[row] != 0;
+    float rmse = 0.f;
+    if (KIND == POST_RMSE && real) {
+        float a = 0.f;
+        for (int j = lane; j < L; j += 64) a += post_term<POST_RMSE>(y[row * Lp + j], tgt, row * L + j);
+        rmse = sqrtf(wave_sum(a) / (float)L);
+    }
+    for (int j = lane; j < Lp; j += 64)
+        err[row * Lp + j] = (real && j < L) ? post_err<KIND>(y[row * Lp + j], tgt, row * L + j, rmse) : 0.f;
+}
+
+#define POST_DISPATCH(KERN, ...)                                                                              \
+    switch (kind) {                                                                                           \
+    case POST_SSE:         hipLaunchKernelGGL(KERN<POST_SSE>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break;         \
+    case POST_WEIGHTEDSSE: hipLaunchKernelGGL(KERN<POST_WEIGHTEDSSE>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break; \
+    case POST_SSE_MASK:    hipLaunchKernelGGL(KERN<POST_SSE_MASK>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break;    \
+    case POST_CE:          hipLaunchKernelGGL(KERN<POST_CE>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break;          \
+    case POST_RMSE:        hipLaunchKernelGGL(KERN<POST_RMSE>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break;        \
+    default:               hipLaunchKernelGGL(KERN<POST_BINARY>, dim3((N + 3) / 4), dim3(256), 0, s, __VA_ARGS__); break;      \
+    }
+
+void launch_post_eval(hipStream_t s, int kind, const float *y, const float *tgt, const char *pat, int N, int L, int Lp,
+                      float *rowstat, float *loss2, bool reset)
+{
+    if (N > 0) { POST_DISPATCH(post_rows_kernel, y, tgt, pat, N, L, Lp, (float2 *)rowstat) }
+    const bool half = kind == POST_SSE || kind == POST_WEIGHTEDSSE || kind == POST_SSE_MASK;
+    launch_rowstat_reduce(s, rowstat, N, loss2, reset, half ? 0.5f : 1.0f);
+}
+void launch_post_backward(hipStream_t s, int kind, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err)
+{
+    if (N <= 0) return;
+    POST_DISPATCH(post_backward_kernel, y, tgt, pat, N, L, Lp, err)
+}
+
+// BinaryClassificationLayer.cu:146-154: the targets are the target classes copied as floats
+__global__ void classes_to_targets_kernel(const int *tcls, float *tgt, int N)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) tgt[i] = (float)tcls[i];
+}
+void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N)
+{
+    if (N <= 0) return;
+    hipLaunchKernelGGL(classes_to_targets_kernel, dim3((N + 255) / 256), dim3(256), 0, s, tcls, tgt, N);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -89,7 +89,13 @@ void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum
 // softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
 // optional: tcls + rowstat[N][2] = {log p_target, argmax == target} for the multiclass loss
 void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat);
-void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset);
+void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset, float scale = -1.0f);
+// remaining post output layers (row f4): per-pattern terms -> rowstat -> fixed-order sum
+enum { POST_SSE = 0, POST_WEIGHTEDSSE, POST_SSE_MASK, POST_CE, POST_RMSE, POST_BINARY };
+void launch_post_eval(hipStream_t s, int kind, const float *y, const float *tgt, const char *pat, int N, int L, int Lp,
+                      float *rowstat, float *loss2, bool reset);
+void launch_post_backward(hipStream_t s, int kind, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err);
+void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N);
 // multiclass error injection + softmax Jacobian + delta copy + bias column sums in one pass (Lp <= 256)
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum);
@@ -99,8 +105,6 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/, bool reset);
 void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
 // sse
-void launch_sse_eval(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *loss2, bool reset);
-void launch_sse_backward(hipStream_t s, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err);
 // UpdateWeightFn over a flat range
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]

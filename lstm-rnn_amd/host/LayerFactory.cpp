@@ -18,15 +18,18 @@ layers::Layer *LayerFactory::createLayer(cn_ctx *ctx, const std::string &layerTy
     if (layerType == "softmax") return new SoftmaxLayer(ctx, layerChild, weightsSection, *precedingLayer);
     if (layerType == "lstm") return new LstmLayer(ctx, layerChild, weightsSection, *precedingLayer, false);
     if (layerType == "blstm") return new LstmLayer(ctx, layerChild, weightsSection, *precedingLayer, true);
-    if (layerType == "sse" || layerType == "multiclass_classification") {
+    if (layerType == "sse" || layerType == "weightedsse" || layerType == "rmse" || layerType == "ce" || layerType == "wf" ||
+        layerType == "binary_classification" || layerType == "multiclass_classification") {
         if (!precedingLayer->isTrainable())                                                      // LayerFactory.cu:68-70
             throw std::runtime_error("Cannot add post output layer after a non trainable layer");
         if (layerType == "sse") return new SsePostOutputLayer(ctx, layerChild, *precedingLayer);
+        if (layerType == "weightedsse") return new WeightedSsePostOutputLayer(ctx, layerChild, *precedingLayer);
+        if (layerType == "rmse") return new RmsePostOutputLayer(ctx, layerChild, *precedingLayer);
+        if (layerType == "ce") return new CePostOutputLayer(ctx, layerChild, *precedingLayer);
+        if (layerType == "wf") return new SseMaskPostOutputLayer(ctx, layerChild, *precedingLayer);
+        if (layerType == "binary_classification") return new BinaryClassificationLayer(ctx, layerChild, *precedingLayer);
         return new MulticlassClassificationLayer(ctx, layerChild, *precedingLayer);
     }
-    if (layerType == "weightedsse" || layerType == "rmse" || layerType == "ce" || layerType == "wf" ||
-        layerType == "binary_classification")
-        throw std::runtime_error("Layer type '" + layerType + "' is not implemented on the MI355X path yet");
     throw std::runtime_error("Unknown layer type '" + layerType + "'");                          // LayerFactory.cu:86
 }
 

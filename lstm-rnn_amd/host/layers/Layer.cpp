@@ -181,5 +181,22 @@ int MulticlassClassificationLayer::countCorrectClassifications()
     return c;
 }
 
+#define CN_POST_LAYER(CLASS, KIND, TYPE)                                                                         \
+    CLASS::CLASS(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer)                              \
+        : PostOutputLayer(ctx, layerChild, KIND, precedingLayer) {}                                              \
+    const std::string &CLASS::type() const { static const std::string s(TYPE); return s; }
+CN_POST_LAYER(WeightedSsePostOutputLayer, CN_LAYER_WEIGHTEDSSE, "weightedsse")
+CN_POST_LAYER(SseMaskPostOutputLayer, CN_LAYER_SSE_MASK, "wf")
+CN_POST_LAYER(CePostOutputLayer, CN_LAYER_CE, "ce")
+CN_POST_LAYER(RmsePostOutputLayer, CN_LAYER_RMSE, "rmse")
+CN_POST_LAYER(BinaryClassificationLayer, CN_LAYER_BINARY_CLASSIFICATION, "binary_classification")
+#undef CN_POST_LAYER
+int BinaryClassificationLayer::countCorrectClassifications()
+{
+    float e = 0; int c = 0;
+    hipCheck(cn_loss_eval(m_handle, &e, &c), m_ctx);
+    return c;
+}
+
 }  // namespace layers
 }  // namespace currennt_hip

@@ -144,5 +144,33 @@ public:
     int countCorrectClassifications();
 };
 
+// The remaining post output layers of LayerFactory.cu:52-87; each is a thin handle on the C ABI kind.
+class WeightedSsePostOutputLayer : public PostOutputLayer {   // layers/WeightedSsePostOutputLayer.{hpp,cu}; size = 2 x output layer
+public:
+    WeightedSsePostOutputLayer(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer);
+    const std::string &type() const;
+};
+class SseMaskPostOutputLayer : public PostOutputLayer {       // layers/SseMaskPostOutputLayer.{hpp,cu} ("wf"); size = 2 x output layer
+public:
+    SseMaskPostOutputLayer(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer);
+    const std::string &type() const;
+};
+class CePostOutputLayer : public PostOutputLayer {            // layers/CePostOutputLayer.{hpp,cu}
+public:
+    CePostOutputLayer(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer);
+    const std::string &type() const;
+};
+class RmsePostOutputLayer : public PostOutputLayer {          // layers/RmsePostOutputLayer.{hpp,cu}
+public:
+    RmsePostOutputLayer(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer);
+    const std::string &type() const;
+};
+class BinaryClassificationLayer : public PostOutputLayer {    // layers/BinaryClassificationLayer.{hpp,cu}
+public:
+    BinaryClassificationLayer(cn_ctx *ctx, const json::Value &layerChild, Layer &precedingLayer);
+    const std::string &type() const;
+    int countCorrectClassifications();
+};
+
 }  // namespace layers
 }  // namespace currennt_hip

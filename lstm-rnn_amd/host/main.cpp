@@ -193,7 +193,8 @@ int trainerMain(const Configuration &config)                                    
         printLayers(neuralNetwork);
         printf("\n");
 
-        const bool classificationTask = dynamic_cast<layers::MulticlassClassificationLayer *>(&neuralNetwork.postOutputLayer()) != 0;
+        const bool classificationTask = dynamic_cast<layers::MulticlassClassificationLayer *>(&neuralNetwork.postOutputLayer()) != 0 ||
+                                        dynamic_cast<layers::BinaryClassificationLayer *>(&neuralNetwork.postOutputLayer()) != 0;   // main.cpp:165-166
 
         if (config.trainingMode()) {
             printf("Creating the optimizer... ");

@@ -43,7 +43,8 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     real_t error = 0;
     *classError = (real_t)ds.totalTimesteps();
     const std::vector<std::shared_ptr<layers::Layer> > &ls = m_neuralNetwork.layers();
-    const bool classification = dynamic_cast<layers::MulticlassClassificationLayer *>(&m_neuralNetwork.postOutputLayer()) != 0;
+    const bool classification = dynamic_cast<layers::MulticlassClassificationLayer *>(&m_neuralNetwork.postOutputLayer()) != 0 ||
+                                dynamic_cast<layers::BinaryClassificationLayer *>(&m_neuralNetwork.postOutputLayer()) != 0;   // Optimizer.cu:52-55
 
     data_sets::DataSetFraction frac;
     bool firstFraction = true;

@@ -14,7 +14,7 @@ from . import binding as B
 
 _TRAINABLE = ("lstm", "blstm", "softmax", "feedforward_tanh", "feedforward_logistic",
               "feedforward_identity")
-_POST = ("sse", "multiclass_classification")
+_POST = ("sse", "multiclass_classification", "weightedsse", "wf", "ce", "rmse", "binary_classification")
 
 
 class Layer:

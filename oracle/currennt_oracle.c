@@ -744,6 +744,110 @@ void orc_sse_backward(int L, int N, const char *patTypes, const real_t *targets,
     }
 }
 
+/* post output layer kinds shared with the python wrapper */
+enum { POST_SSE = 0, POST_WEIGHTEDSSE = 1, POST_SSE_MASK = 2, POST_CE = 3, POST_RMSE = 4, POST_BINARY = 5 };
+
+/*
+ * calculateError() of the remaining post output layers.  L = size of the OUTPUT layer; targets hold
+ * L values per pattern, or 2L interleaved (target, weight|filter input) pairs for weightedsse / wf.
+ *   weightedsse : WeightedSsePostOutputLayer.cu:44-62, :108-127   0.5 * sum ((y - t) * w)^2
+ *   wf/sse_mask : SseMaskPostOutputLayer.cu:44-62, :108-127       0.5 * sum (y * f - t)^2
+ *   ce          : CePostOutputLayer.cu:44-71, :118-136            sum t * log(max(min,t) / max(min,y))
+ *   rmse        : RmsePostOutputLayer.cu:44-70, :112-121          sum_rows sqrt(sum_j (y-t)^2 / L)
+ *   binary      : BinaryClassificationLayer.cu:48-67, :157-173    sum -log(t > 0 ? act : 1 - act)
+ */
+real_t orc_post_error(int kind, int L, int N, const char *patTypes, const real_t *targets, const real_t *outputs)
+{
+    real_t s = 0;
+    if (kind == POST_RMSE) {
+        for (int patIdx = 0; patIdx < N; ++patIdx) {
+            if (patTypes[patIdx] == PATTYPE_NONE) continue;
+            real_t sum = 0;
+            for (int i = 0; i < L; ++i) {
+                real_t diff = outputs[(size_t)patIdx * L + i] - targets[(size_t)patIdx * L + i];
+                sum += diff * diff;
+            }
+            s += sqrtf(sum / L);
+        }
+        return s;
+    }
+    for (int index = 0; index < N * L; ++index) {
+        if (patTypes[index / L] == PATTYPE_NONE) continue;
+        real_t output = outputs[index];
+        if (kind == POST_SSE) {
+            real_t diff = targets[index] - output; s += diff * diff;
+        } else if (kind == POST_WEIGHTEDSSE) {
+            real_t diff = (output - targets[index * 2]) * targets[index * 2 + 1]; s += diff * diff;
+        } else if (kind == POST_SSE_MASK) {
+            real_t diff = output * targets[index * 2 + 1] - targets[index * 2]; s += diff * diff;
+        } else if (kind == POST_CE) {
+            real_t target = targets[index];
+            real_t ftarget = (NL_MIN > target ? NL_MIN : target);
+            real_t o = (NL_MIN > output ? NL_MIN : output);
+            s += target * logf(ftarget / o);
+        } else {   /* POST_BINARY, L == 1 */
+            real_t act = (output > NL_MIN ? output : NL_MIN);
+            real_t targetProb = (targets[index] > 0 ? act : 1 - act);
+            s += -logf(targetProb);
+        }
+    }
+    if (kind == POST_SSE || kind == POST_WEIGHTEDSSE || kind == POST_SSE_MASK) s = (real_t)0.5 * s;
+    return s;
+}
+
+/* BinaryClassificationLayer<Cpu>::countCorrectClassifications, .cu:71-88,118-133 */
+int orc_binary_correct(int N, const char *patTypes, const real_t *targets, const real_t *outputs)
+{
+    int c = 0;
+    for (int i = 0; i < N; ++i) {
+        int tgtClass = targets[i] > (real_t)0.5, estClass = outputs[i] > (real_t)0.5;
+        c += (patTypes[i] != PATTYPE_NONE) && (tgtClass == estClass);
+    }
+    return c;
+}
+
+/*
+ * computeBackwardPass() of the same layers (error written into the output layer's outputErrors):
+ *   weightedsse .cu:64-88   wf .cu:64-88   ce .cu:73-96 (clipped to +-100)   rmse .cu:72-93 (rmse * (y - t))
+ *   binary .cu:90-113 (dummy slots are left untouched by the reference; 0 here)
+ */
+void orc_post_backward(int kind, int L, int N, const char *patTypes, const real_t *targets,
+                       const real_t *outputs, real_t *outErr)
+{
+    for (int patIdx = 0; patIdx < N; ++patIdx) {
+        int real = patTypes[patIdx] != PATTYPE_NONE;
+        real_t rmse = 0;
+        if (kind == POST_RMSE && real) {
+            real_t sum = 0;
+            for (int i = 0; i < L; ++i) {
+                real_t diff = outputs[(size_t)patIdx * L + i] - targets[(size_t)patIdx * L + i];
+                sum += diff * diff;
+            }
+            rmse = sqrtf(sum / L);
+        }
+        for (int i = 0; i < L; ++i) {
+            size_t index = (size_t)patIdx * L + i;
+            real_t y = outputs[index], e = 0;
+            if (real) {
+                if (kind == POST_SSE) e = y - targets[index];
+                else if (kind == POST_WEIGHTEDSSE) e = (y - targets[index * 2]) * targets[index * 2 + 1];
+                else if (kind == POST_SSE_MASK) e = (y * targets[index * 2 + 1] - targets[index * 2]) * targets[index * 2 + 1];
+                else if (kind == POST_CE) {
+                    real_t a = (NL_MIN > y ? NL_MIN : y);
+                    real_t b = -targets[index] / a;
+                    e = (b < -100 ? -100 : (b > 100 ? 100 : b));
+                } else if (kind == POST_RMSE) e = rmse * (y - targets[index]);
+                else {
+                    real_t act = (y > NL_MIN ? y : NL_MIN);
+                    real_t targetProb = (targets[index] > 0 ? act : 1 - act);
+                    e = (targets[index] > 0 ? -(1 / targetProb) : (1 / targetProb));
+                }
+            }
+            outErr[index] = e;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* optimizer step                                                             */
 /* ------------------------------------------------------------------------- */

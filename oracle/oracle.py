@@ -23,6 +23,7 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
 
 ACT = {"feedforward_tanh": 0, "feedforward_logistic": 1, "feedforward_identity": 2}
+POST = {"sse": 0, "weightedsse": 1, "wf": 2, "sse_mask": 2, "ce": 3, "rmse": 4, "binary_classification": 5}
 
 
 def build():
@@ -62,6 +63,11 @@ def lib():
     L.orc_sse_error.restype = cf
     L.orc_sse_backward.argtypes = [ci, ci, i8p, f32p, f32p, f32p]
     L.orc_sgd_update.argtypes = [ci, cf, cf, f32p, f32p, f32p]
+    L.orc_post_error.argtypes = [ci, ci, ci, i8p, f32p, f32p]
+    L.orc_post_error.restype = cf
+    L.orc_binary_correct.argtypes = [ci, i8p, f32p, f32p]
+    L.orc_binary_correct.restype = ci
+    L.orc_post_backward.argtypes = [ci, ci, ci, i8p, f32p, f32p, f32p]
     _lib = L
     return L
 
@@ -85,7 +91,7 @@ class _Layer:
         self.PS, self.maxT = PS, maxT
         self.bias = float(desc.get("bias", 0.0))
         self.trainable = self.type in ("lstm", "blstm", "softmax") or self.type in ACT
-        self.post = self.type in ("multiclass_classification", "sse")
+        self.post = self.type == "multiclass_classification" or self.type in POST
         n = PS * maxT * self.size
         # PostOutputLayer writes into the preceding layer's outputErrors (PostOutputLayer.cpp:43-47)
         self.outputs = np.zeros(n, np.float32) if not self.post else None
@@ -151,6 +157,8 @@ class OracleNetwork:
         post = self.layers[-1]
         if post.type == "multiclass_classification":
             self.targetClasses = np.ascontiguousarray(frac["targetClasses"], np.int32)
+        elif post.type == "binary_classification":      # BinaryClassificationLayer.cu:146-154
+            self.targets = np.ascontiguousarray(frac["targetClasses"], np.float32).reshape(-1)
         else:
             self.targets = np.ascontiguousarray(frac["targets"], np.float32).reshape(-1)
 
@@ -176,10 +184,12 @@ class OracleNetwork:
         post, out = self.layers[-1], self.layers[-2]
         if post.type == "multiclass_classification":
             return float(L.orc_mcc_error(post.size, self.N, self.targetClasses, out.outputs))
-        return float(L.orc_sse_error(post.size, self.N, self.patTypes, self.targets, out.outputs))
+        return float(L.orc_post_error(POST[post.type], out.size, self.N, self.patTypes, self.targets, out.outputs))
 
     def count_correct_classifications(self):
         post, out = self.layers[-1], self.layers[-2]
+        if post.type == "binary_classification":
+            return int(lib().orc_binary_correct(self.N, self.patTypes, self.targets, out.outputs))
         return int(lib().orc_mcc_correct(post.size, self.N, self.targetClasses, out.outputs))
 
     # -- NeuralNetwork::computeBackwardPass (NeuralNetwork.cpp:175-184), reverse order
@@ -189,8 +199,8 @@ class OracleNetwork:
         if post.type == "multiclass_classification":
             L.orc_mcc_backward(post.size, self.N, self.targetClasses, out.outputs, out.outputErrors)
         else:
-            L.orc_sse_backward(post.size, self.N, self.patTypes, self.targets,
-                               out.outputs, out.outputErrors)
+            L.orc_post_backward(POST[post.type], out.size, self.N, self.patTypes, self.targets,
+                                out.outputs, out.outputErrors)
         for lay in reversed(self.layers[1:-1]):
             P, x = lay.prev.size, lay.prev.outputs
             # only a trainable preceding layer receives errors (LstmLayer.cu:991-992)

@@ -144,6 +144,58 @@ def test_partial_fraction_and_sse(pkg, orc):
             assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 2e-4, lay.name
 
 
+@pytest.mark.parametrize("post,out_type", [("weightedsse", "feedforward_identity"), ("wf", "feedforward_tanh"),
+                                           ("ce", "softmax"), ("rmse", "feedforward_identity"),
+                                           ("binary_classification", "feedforward_logistic")])
+def test_remaining_post_output_layers(pkg, orc, post, out_type):
+    """the post output layers of LayerFactory.cu:52-87 besides sse / multiclass.
+    Error, class count, injected output errors and every weight gradient against the oracle, with
+    ragged sequences and an unused parallel slot."""
+    rng = np.random.RandomState(31)
+    P, PS = 5, 4
+    L = 1 if post == "binary_classification" else 6
+    W = 2 * L if post in ("weightedsse", "wf") else L
+    layers = [{"name": "input", "type": "input", "size": P},
+              {"name": "lstm_0", "type": "blstm", "size": 12, "bias": 1.0},
+              {"name": "output", "type": out_type, "size": L, "bias": 1.0},
+              {"name": "postoutput", "type": post, "size": W}]
+    weights = random_weights(layers, rng, 0.5)
+    lengths = [11, 7, 9]
+    xs = [rng.randn(n, P).astype(np.float32) for n in lengths]
+    if post == "binary_classification":
+        ts = [rng.randint(0, 2, n).astype(np.int32) for n in lengths]
+        frac = pkg.make_fraction(xs, ts, PS, classification=True)
+    else:
+        if post == "ce":          # a target distribution with exact zeros (exercises max(FLT_MIN, t))
+            ts = []
+            for n in lengths:
+                t = rng.rand(n, L).astype(np.float32); t[:, 0] = 0; ts.append(t / t.sum(1, keepdims=True))
+        else:
+            ts = [rng.randn(n, W).astype(np.float32) for n in lengths]
+        frac = pkg.make_fraction(xs, ts, PS, classification=False)
+    ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    ref.load_sequences(frac); ref.compute_forward_pass()
+    e_ref = ref.calculate_error(); ref.compute_backward_pass()
+    with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=0) as net:
+        net.load_sequences(frac); net.compute_forward_pass()
+        e, c = net.error_and_correct()
+        net.compute_backward_pass()
+        real = real_mask(frac)
+        assert abs(e - e_ref) <= 1e-5 * max(1.0, abs(e_ref)), (e, e_ref)
+        if post == "binary_classification":
+            assert c == ref.count_correct_classifications()
+        else:
+            assert c == -1
+        out = net.layer("output")
+        oe = out.output_errors().reshape(-1, L)
+        oer = ref.layer("output").outputErrors[:net.N * L].reshape(-1, L)
+        if out_type != "softmax":            # softmax rewrites its outputErrors in place during backward
+            assert rel_err(oe[real], oer[real]) < 1e-5
+            assert np.all(oe[~real] == 0)
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 2e-4, lay.name
+
+
 def test_sgd_momentum_steps(pkg, orc):
     """Three fractions of stochastic training: post-update weights track the oracle (Q10)."""
     rng = np.random.RandomState(10)

@@ -86,3 +86,73 @@ def test_autograd_matches_oracle(pkg, orc):
                                       for d in range(2 if lay.type == "blstm" else 1)])).max() < 1.0 \
             if lay.type in ("lstm", "blstm") else True            # no delta reached the +-1 clip
         assert np.abs(g - gr).max() < 2e-4 * max(1.0, np.abs(g).max()), (lay.name, np.abs(g - gr).max())
+
+
+def _post_loss64(kind, y, t, L):
+    """fp64 statement of calculateError() of the post output layers (formulas of the layer headers)."""
+    if kind == "sse":
+        return 0.5 * ((t - y) ** 2).sum()
+    if kind == "weightedsse":
+        tt = t.reshape(-1, L, 2)
+        return 0.5 * (((y - tt[..., 0]) * tt[..., 1]) ** 2).sum()
+    if kind == "wf":
+        tt = t.reshape(-1, L, 2)
+        return 0.5 * ((y * tt[..., 1] - tt[..., 0]) ** 2).sum()
+    if kind == "ce":
+        tiny = torch.tensor(np.finfo(np.float32).tiny, dtype=torch.float64)
+        return (t * torch.log(torch.maximum(t, tiny) / torch.maximum(y, tiny))).sum()
+    if kind == "rmse":
+        return torch.sqrt(((y - t) ** 2).sum(1) / L).sum()
+    p = torch.where(t > 0, y, 1 - y)
+    return (-torch.log(p)).sum()
+
+
+def test_post_output_layers_against_fp64_autograd(orc):
+    """orc_post_error / orc_post_backward against an fp64 autograd statement of the same losses.  Two
+    layers are documented exceptions where the reference does not inject the derivative of its error:
+    rmse injects rmse * (y - t) (RmsePostOutputLayer.cu:72-93) and weightedsse injects (y - t) * w, one
+    factor w short of the derivative (WeightedSsePostOutputLayer.cu:66-91)."""
+    import ctypes  # noqa: F401
+    rng = np.random.RandomState(4)
+    N, L = 23, 5
+    pat = np.ones(N, np.int8); pat[[3, 17]] = 0
+    lib = orc.lib()
+    for kind in ("sse", "weightedsse", "wf", "ce", "rmse", "binary_classification"):
+        Lk = 1 if kind == "binary_classification" else L
+        W = 2 * Lk if kind in ("weightedsse", "wf") else Lk
+        if kind in ("ce", "binary_classification"):
+            y = rng.uniform(0.05, 0.95, (N, Lk)).astype(np.float32)
+        else:
+            y = rng.randn(N, Lk).astype(np.float32)
+        if kind == "ce":
+            t = rng.rand(N, W).astype(np.float32); t[:, 1] = 0
+        elif kind == "binary_classification":
+            t = rng.randint(0, 2, (N, W)).astype(np.float32)
+        else:
+            t = rng.randn(N, W).astype(np.float32)
+        k = orc.POST[kind]
+        e = lib.orc_post_error(k, Lk, N, pat, t.reshape(-1), y.reshape(-1))
+        err = np.full(N * Lk, 7.0, np.float32)
+        lib.orc_post_backward(k, Lk, N, pat, t.reshape(-1), y.reshape(-1), err)
+        err = err.reshape(N, Lk)
+        real = pat != 0
+        y64 = torch.tensor(y[real].astype(np.float64), requires_grad=True)
+        t64 = torch.tensor(t[real].astype(np.float64))
+        loss = _post_loss64(kind, y64, t64, Lk)
+        assert abs(e - loss.item()) <= 2e-6 * max(1.0, abs(loss.item())), kind
+        assert np.all(err[~real] == 0), kind
+        if kind == "rmse":
+            rm = np.sqrt(((y[real] - t[real]).astype(np.float64) ** 2).sum(1, keepdims=True) / Lk)
+            want = rm * (y[real] - t[real])
+        elif kind == "weightedsse":
+            tt = t[real].astype(np.float64).reshape(-1, Lk, 2)
+            want = (y[real] - tt[..., 0]) * tt[..., 1]
+        else:
+            loss.backward()
+            want = y64.grad.numpy()
+        assert np.abs(err[real] - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), kind
+    # ce clips the injected error to +-100 (CePostOutputLayer.cu:90)
+    y = np.full((1, 2), 1e-6, np.float32); t = np.array([[1.0, 0.0]], np.float32)
+    err = np.zeros(2, np.float32)
+    lib.orc_post_backward(orc.POST["ce"], 2, 1, np.ones(1, np.int8), t.reshape(-1), y.reshape(-1), err)
+    assert err[0] == -100.0 and err[1] == 0.0
