@@ -10,15 +10,19 @@ import numpy as np
 PATTYPE_NONE, PATTYPE_FIRST, PATTYPE_NORMAL, PATTYPE_LAST = 0, 1, 2, 3
 
 
-def make_fraction(inputs, targets, parallel_sequences, classification=True, output_size=None):
+def make_fraction(inputs, targets, parallel_sequences, classification=True, output_size=None,
+                  context_left=0, context_right=0, output_lag=0):
     """inputs: list of [len_i][P] float arrays; targets: list of [len_i] int arrays (classification)
-    or [len_i][L] float arrays.  Returns the dict layout used by NeuralNetwork.load_sequences."""
+    or [len_i][L] float arrays.  Returns the dict layout used by NeuralNetwork.load_sequences.
+    context_left/right splice neighbouring frames into each input pattern (edge frames repeated) and
+    output_lag delays the targets (class 0 / value 1.0 before the lag), DataSet.cpp:302-305,346-397."""
     PS = int(parallel_sequences)
     if not inputs or len(inputs) > PS:
         raise ValueError("need 1..parallel_sequences sequences")
     lengths = [int(x.shape[0]) for x in inputs]
     T, Tmin = max(lengths), min(lengths)                       # DataSet.cpp:316-319
-    P = int(inputs[0].shape[1])
+    P0 = int(inputs[0].shape[1])
+    P = P0 * (context_left + context_right + 1)
     x = np.zeros((T, PS, P), np.float32)                       # :330
     pat = np.full((T, PS), PATTYPE_NONE, np.int8)              # :331
     frac = {"T": T, "Tmin": Tmin, "PS": PS, "numSeqs": len(inputs), "seqLengths": lengths}
@@ -28,11 +32,16 @@ def make_fraction(inputs, targets, parallel_sequences, classification=True, outp
         L = int(output_size if output_size is not None else targets[0].shape[1])
         tg = np.zeros((T, PS, L), np.float32)
     for i, (xi, ti, n) in enumerate(zip(inputs, targets, lengths)):
-        x[:n, i, :] = xi                                       # :346-366 (no context splicing)
+        for k, off in enumerate(range(-context_left, context_right + 1)):      # :346-366
+            src = np.clip(np.arange(n) + off, 0, n - 1)
+            x[:n, i, k * P0:(k + 1) * P0] = np.asarray(xi)[src]
+        lag = min(int(output_lag), n)
         if classification:
-            tc[:n, i] = ti                                     # :372-380 (output lag 0)
+            tc[:lag, i] = 0                                    # :372-380
+            tc[lag:n, i] = np.asarray(ti)[:n - lag]
         else:
-            tg[:n, i, :] = ti                                  # :383-397
+            tg[:lag, i, :] = 1.0                               # :383-397
+            tg[lag:n, i, :] = np.asarray(ti)[:n - lag]
         pat[:n, i] = PATTYPE_NORMAL                            # :400-409
         pat[0, i] = PATTYPE_FIRST
         if n > 1:

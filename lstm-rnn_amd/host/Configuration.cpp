@@ -50,6 +50,7 @@ const char *Configuration::usage()
 
 void Configuration::apply(const std::string &key, const std::string &v)
 {
+    if (key != "continue" && v.find_first_of(";\"\\") == std::string::npos) m_serializedOptions += key + "=" + v + ";";
     if (key == "network") m_networkFile = v;
     else if (key == "cuda") (void)toBool(key, v);                       // accepted for compatibility; this build always runs on the MI355X
     else if (key == "list_devices") m_listDevices = toBool(key, v);
@@ -99,11 +100,16 @@ void Configuration::apply(const std::string &key, const std::string &v)
     }
     else if (key == "device") m_device = atoi(v.c_str());
     else if (key == "dump_fractions") m_dumpFractions = toBool(key, v);
-    else if (key == "input_noise_sigma" || key == "weight_noise_sigma" || key == "input_left_context" || key == "input_right_context" ||
-             key == "output_time_lag") {
-        if (atof(v.c_str()) != 0) throw std::runtime_error("Option '" + key + "' is not supported by this build (only 0)");
-    }
-    else if (key == "cache_path" || key == "autosave" || key == "autosave_best" || key == "autosave_prefix") { /* accepted, unused */ }
+    else if (key == "input_noise_sigma") m_inputNoiseSigma = (real_t)atof(v.c_str());
+    else if (key == "weight_noise_sigma") m_weightNoiseSigma = (real_t)atof(v.c_str());
+    else if (key == "input_left_context") m_inputLeftContext = atoi(v.c_str());
+    else if (key == "input_right_context") m_inputRightContext = atoi(v.c_str());
+    else if (key == "output_time_lag") m_outputTimeLag = atoi(v.c_str());
+    else if (key == "autosave") m_autosave = toBool(key, v);
+    else if (key == "autosave_best") m_autosaveBest = toBool(key, v);
+    else if (key == "autosave_prefix") m_autosavePrefix = v;
+    else if (key == "continue") m_continueFile = v;
+    else if (key == "cache_path") { /* accepted, unused: sequences are kept in RAM instead of a cache file */ }
     else throw std::runtime_error("Error while parsing the command line and/or options file: unknown option '" + key + "'");
 }
 
@@ -135,6 +141,27 @@ Configuration::Configuration(int argc, const char *argv[])
             apply(trim(line.substr(0, eq)), trim(line.substr(eq + 1)));
         }
     }
+    // --continue: the options stored in the autosave file come first (Configuration.cpp:236-248)
+    for (size_t i = 0; i < cli.size(); ++i)
+        if (cli[i].first == "continue") {
+            std::ifstream f(cli[i].second.c_str());
+            if (!f.good()) throw std::runtime_error("Error while restoring configuration from autosave file: cannot open '" + cli[i].second + "'");
+            std::stringstream ss; ss << f.rdbuf();
+            const std::string text = ss.str(), tag = "\"configuration\"";
+            size_t p = text.find(tag);
+            if (p != std::string::npos && (p = text.find('"', text.find(':', p + tag.size()))) != std::string::npos) {
+                size_t e = text.find('"', p + 1);
+                std::vector<std::string> kv;
+                std::string cur;
+                for (size_t k = p + 1; k <= e && e != std::string::npos; ++k) {
+                    if (k == e || text[k] == ';') { if (!cur.empty()) kv.push_back(cur); cur.clear(); } else cur += text[k];
+                }
+                for (size_t k = 0; k < kv.size(); ++k) {
+                    size_t eq = kv[k].find('=');
+                    if (eq != std::string::npos && kv[k].substr(0, eq) != "continue") apply(kv[k].substr(0, eq), kv[k].substr(eq + 1));
+                }
+            }
+        }
     for (size_t i = 0; i < cli.size(); ++i) apply(cli[i].first, cli[i].second);   // command line wins
     if (m_parallelSequences < 1) throw std::runtime_error("Error while parsing the command line and/or options file: parallel_sequences must be >= 1");
 }

@@ -55,10 +55,26 @@ public:
     int device() const { return m_device; }
     bool help() const { return m_help; }
     bool dumpFractions() const { return m_dumpFractions; }
+    // data/noise options of Configuration.cpp:139-146,171-176
+    real_t inputNoiseSigma() const { return m_inputNoiseSigma; }
+    real_t weightNoiseSigma() const { return m_weightNoiseSigma; }
+    int inputLeftContext() const { return m_inputLeftContext; }
+    int inputRightContext() const { return m_inputRightContext; }
+    int outputTimeLag() const { return m_outputTimeLag; }
+    // autosave options of Configuration.cpp:159-164
+    bool autosave() const { return m_autosave; }
+    bool autosaveBest() const { return m_autosaveBest; }
+    const std::string &autosavePrefix() const { return m_autosavePrefix; }
+    const std::string &continueFile() const { return m_continueFile; }
+    // "key=value;..." of every option given (the reference serialises its boost variables map, Configuration.cpp:44-67)
+    const std::string &serializedOptions() const { return m_serializedOptions; }
     static const char *usage();
 
 private:
-    bool m_dumpFractions = false;
+    bool m_dumpFractions = false, m_autosave = false, m_autosaveBest = false;
+    real_t m_inputNoiseSigma = 0, m_weightNoiseSigma = 0;
+    int m_inputLeftContext = 0, m_inputRightContext = 0, m_outputTimeLag = 0;
+    std::string m_autosavePrefix, m_continueFile, m_serializedOptions;
     bool m_help = false, m_trainingMode = false, m_hybridOnlineBatch = false, m_shuffleFractions = false,
          m_shuffleSequences = false, m_listDevices = false, m_revertStd = true, m_weightsNormal = false;
     int m_parallelSequences = 1, m_maxEpochs = -1, m_maxEpochsNoBest = 20, m_validateEvery = 1, m_testEvery = 1,

@@ -11,12 +11,19 @@ namespace data_sets {
 
 DataSet::DataSet() {}
 
+DataSet::~DataSet()
+{
+    if (m_prefetch.valid()) m_prefetch.wait();
+}
+
 DataSet::DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fraction, int truncSeqLength,
-                 bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed)
+                 bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed, const Augment &augment)
     : m_fractionShuffling(fracShuf), m_sequenceShuffling(seqShuf), m_parallelSequences(parSeq),
       m_minSeqLength(std::numeric_limits<int>::max()), m_maxSeqLength(std::numeric_limits<int>::min()),
-      m_rngState(randomSeed ? randomSeed : 5489u)
+      m_rngState(randomSeed ? randomSeed : 5489u), m_augment(augment), m_noiseGen(randomSeed)
 {
+    if (augment.contextLeft < 0 || augment.contextRight < 0 || augment.outputLag < 0)
+        throw std::runtime_error("Negative input context / output time lag");
     if (fraction <= 0 || fraction > 1) throw std::runtime_error("Invalid fraction");        // DataSet.cpp:457-458
     bool firstFile = true;
     for (size_t fi = 0; fi < ncfiles.size(); ++fi) {
@@ -115,11 +122,13 @@ void DataSet::shuffleFractions()
     for (size_t i = 0; i < fractions.size(); ++i) m_sequences.insert(m_sequences.end(), fractions[i].begin(), fractions[i].end());
 }
 
-void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac) const
+void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac)
 {
     const int PS = m_parallelSequences;
+    const int ctxL = m_augment.contextLeft, ctxR = m_augment.contextRight, lag = m_augment.outputLag;   // :302-305
+    const int P = m_inputPatternSize, Pf = P * (ctxL + ctxR + 1);
     *frac = DataSetFraction();
-    frac->m_inputPatternSize = m_inputPatternSize;
+    frac->m_inputPatternSize = Pf;
     frac->m_outputPatternSize = m_outputPatternSize;
     frac->m_maxSeqLength = std::numeric_limits<int>::min();
     frac->m_minSeqLength = std::numeric_limits<int>::max();
@@ -131,28 +140,42 @@ void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac) const
         frac->m_seqInfo.push_back(si);
     }
     const size_t slots = (size_t)frac->m_maxSeqLength * PS;
-    frac->m_inputs.assign(slots * m_inputPatternSize, 0.0f);                                   // :330-336
+    frac->m_inputs.assign(slots * Pf, 0.0f);                                                   // :330-336
     frac->m_patTypes.assign(slots, (char)PATTYPE_NONE);
     if (m_isClassificationData) frac->m_targetClasses.assign(slots, -1);
     else frac->m_outputs.assign(slots * m_outputPatternSize, 0.0f);
+    std::vector<float> noisy;
     for (int i = 0; i < PS; ++i) {
         if (firstSeqIdx + i >= (int)m_sequences.size()) continue;
         const sequence_t &seq = m_sequences[firstSeqIdx + i];
+        const float *src = m_inputData.data() + seq.inputsBegin;
+        if (m_augment.noiseDeviation) {                                                        // _addNoise, :250-265
+            // the reference draws from boost::mt19937 + boost::normal_distribution (absent here);
+            // std::mt19937 seeded from --random_seed keeps runs reproducible per seed
+            std::normal_distribution<real_t> dist((real_t)0, m_augment.noiseDeviation);
+            noisy.assign(src, src + (size_t)seq.length * P);
+            for (size_t k = 0; k < noisy.size(); ++k) noisy[k] += dist(m_noiseGen);
+            src = noisy.data();
+        }
         for (int t = 0; t < seq.length; ++t) {
             const size_t slot = (size_t)t * PS + i;
-            std::copy(m_inputData.begin() + seq.inputsBegin + (size_t)t * m_inputPatternSize,
-                      m_inputData.begin() + seq.inputsBegin + (size_t)(t + 1) * m_inputPatternSize,
-                      frac->m_inputs.begin() + slot * m_inputPatternSize);                      // :346-366
-            if (m_isClassificationData) frac->m_targetClasses[slot] = m_classData[seq.targetsBegin + t];   // :372-380
-            else std::copy(m_targetData.begin() + seq.targetsBegin + (size_t)t * m_outputPatternSize,
-                           m_targetData.begin() + seq.targetsBegin + (size_t)(t + 1) * m_outputPatternSize,
-                           frac->m_outputs.begin() + slot * m_outputPatternSize);                // :383-397
+            for (int off = -ctxL, k = 0; off <= ctxR; ++off, ++k) {                            // :346-366, edge frames are repeated
+                const int ts = std::min(std::max(t + off, 0), seq.length - 1);
+                std::copy(src + (size_t)ts * P, src + (size_t)(ts + 1) * P, frac->m_inputs.begin() + slot * Pf + (size_t)k * P);
+            }
+            if (m_isClassificationData)                                                        // :372-380, class 0 before the lag
+                frac->m_targetClasses[slot] = t >= lag ? m_classData[seq.targetsBegin + (t - lag)] : 0;
+            else if (t >= lag)                                                                 // :383-397, 1.0 before the lag
+                std::copy(m_targetData.begin() + seq.targetsBegin + (size_t)(t - lag) * m_outputPatternSize,
+                          m_targetData.begin() + seq.targetsBegin + (size_t)(t - lag + 1) * m_outputPatternSize,
+                          frac->m_outputs.begin() + slot * m_outputPatternSize);
+            else std::fill_n(frac->m_outputs.begin() + slot * m_outputPatternSize, m_outputPatternSize, 1.0f);
             frac->m_patTypes[slot] = (char)(t == 0 ? PATTYPE_FIRST : (t == seq.length - 1 ? PATTYPE_LAST : PATTYPE_NORMAL));   // :400-407
         }
     }
 }
 
-bool DataSet::getNextFraction(DataSetFraction *frac)
+bool DataSet::produceNext(DataSetFraction *frac)
 {
     if (m_curFirstSeqIdx == -1 || m_curFirstSeqIdx == 0) {       // start of an epoch: _makeFirstFractionTask, :416-427
         if (m_curFirstSeqIdx == -1) m_curFirstSeqIdx = 0;
@@ -166,6 +189,20 @@ bool DataSet::getNextFraction(DataSetFraction *frac)
     }
     m_curFirstSeqIdx = 0;                                        // :660-662
     return false;
+}
+
+bool DataSet::getNextFraction(DataSetFraction *frac)
+{
+    // :632-668: take the fraction the worker prepared and start the worker on the one after it.  After the
+    // last fraction the worker's task only rewinds (returns false); the next epoch's shuffles run when that
+    // epoch's first fraction is asked for, as in the reference.
+    if (!m_prefetch.valid()) m_prefetch = std::async(std::launch::async, [this] { return produceNext(&m_next); });
+    const bool ok = m_prefetch.get();
+    if (ok) {
+        std::swap(*frac, m_next);
+        m_prefetch = std::async(std::launch::async, [this] { return produceNext(&m_next); });
+    }
+    return ok;
 }
 
 }  // namespace data_sets

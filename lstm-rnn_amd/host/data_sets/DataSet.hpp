@@ -3,6 +3,8 @@
 // libnetcdf and a /tmp cache file; sequences here are kept in RAM).
 #pragma once
 
+#include <future>
+#include <random>
 #include <string>
 #include <vector>
 
@@ -36,14 +38,22 @@ private:
     Hip::int_vector m_targetClasses;
 };
 
+// what the reference pulls from Configuration::instance() inside _makeFractionTask / _addNoise
+// (DataSet.cpp:252-265,302-305): Gaussian input noise, context splicing, output time lag
+struct Augment { real_t noiseDeviation = 0; int contextLeft = 0, contextRight = 0, outputLag = 0; };
+
 class DataSet {
 public:
+    typedef data_sets::Augment Augment;
     struct sequence_t { int originalSeqIdx; int length; std::string seqTag; size_t inputsBegin; size_t targetsBegin; };
 
     DataSet();                                              // empty set (DataSet.cpp:429-442)
     // DataSet.cpp:443-606; `sortByLength` = Configuration::trainingMode() there (:603-605)
     DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fraction, int truncSeqLength,
-            bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed);
+            bool fracShuf, bool seqShuf, bool sortByLength, unsigned randomSeed, const Augment &augment = Augment());
+    ~DataSet();
+    DataSet(const DataSet &) = delete;
+    DataSet &operator=(const DataSet &) = delete;
 
     bool isClassificationData() const { return m_isClassificationData; }
     bool empty() const { return m_totalTimesteps == 0; }
@@ -53,7 +63,8 @@ public:
     int totalTimesteps() const { return m_totalTimesteps; }
     int minSeqLength() const { return m_minSeqLength; }
     int maxSeqLength() const { return m_maxSeqLength; }
-    int inputPatternSize() const { return m_inputPatternSize; }
+    int inputPatternSize() const { return m_inputPatternSize; }                        // per frame, before context splicing
+    int fractionInputPatternSize() const { return m_inputPatternSize * (m_augment.contextLeft + m_augment.contextRight + 1); }
     int outputPatternSize() const { return m_outputPatternSize; }
     const Hip::real_vector &outputMeans() const { return m_outputMeans; }
     const Hip::real_vector &outputStdevs() const { return m_outputStdevs; }
@@ -67,7 +78,15 @@ private:
     Hip::int_vector m_classData;
     std::vector<sequence_t> m_sequences;
 
-    void makeFraction(int firstSeqIdx, DataSetFraction *frac) const;   // _makeFractionTask, DataSet.cpp:300-414
+    Augment m_augment;
+    std::mt19937 m_noiseGen;
+    // one fraction is packed ahead on a worker thread while the GPU runs the current one
+    // (the reference's boost::thread hand-over, DataSet.cpp:589,632-668)
+    std::future<bool> m_prefetch;
+    DataSetFraction m_next;
+    bool produceNext(DataSetFraction *frac);
+
+    void makeFraction(int firstSeqIdx, DataSetFraction *frac);        // _makeFractionTask, DataSet.cpp:300-414
     void shuffleSequences();                                          // :226-230
     void shuffleFractions();                                          // :232-250
     unsigned nextRandom(unsigned n);

@@ -25,12 +25,15 @@ enum data_set_type { DATA_SET_TRAINING, DATA_SET_VALIDATION, DATA_SET_TEST, DATA
 std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, data_set_type dsType)   // main.cpp:574-640
 {
     std::string type; std::vector<std::string> filenames; real_t fraction = 1; bool fracShuf = false, seqShuf = false; int truncSeqLength = 0;
+    data_sets::DataSet::Augment augment;            // context and lag apply to every set (DataSet.cpp:302-305), noise to two (main.cpp:593,613)
+    augment.contextLeft = config.inputLeftContext(); augment.contextRight = config.inputRightContext(); augment.outputLag = config.outputTimeLag();
     switch (dsType) {
     case DATA_SET_TRAINING: type = "training set"; filenames = config.trainingFiles(); fraction = config.trainingFraction();
-        fracShuf = config.shuffleFractions(); seqShuf = config.shuffleSequences(); truncSeqLength = config.truncateSeqLength(); break;
+        fracShuf = config.shuffleFractions(); seqShuf = config.shuffleSequences(); truncSeqLength = config.truncateSeqLength();
+        augment.noiseDeviation = config.inputNoiseSigma(); break;
     case DATA_SET_VALIDATION: type = "validation set"; filenames = config.validationFiles(); fraction = config.validationFraction(); break;
     case DATA_SET_TEST: type = "test set"; filenames = config.testFiles(); fraction = config.testFraction(); break;
-    default: type = "feed forward input set"; filenames = config.feedForwardInputFiles(); break;
+    default: type = "feed forward input set"; filenames = config.feedForwardInputFiles(); augment.noiseDeviation = config.inputNoiseSigma(); break;
     }
     printf("Loading %s ", type.c_str());
     for (size_t i = 0; i < filenames.size(); ++i) printf("'%s' ", filenames[i].c_str());
@@ -38,7 +41,7 @@ std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, dat
     fflush(stdout);
     if (filenames.empty()) throw std::runtime_error("No " + type + " file given");
     std::shared_ptr<data_sets::DataSet> ds = std::make_shared<data_sets::DataSet>(
-        filenames, config.parallelSequences(), fraction, truncSeqLength, fracShuf, seqShuf, config.trainingMode(), config.randomSeed());
+        filenames, config.parallelSequences(), fraction, truncSeqLength, fracShuf, seqShuf, config.trainingMode(), config.randomSeed(), augment);
     printf("done.\n");
     printf("Loaded fraction:  %d%%\n", (int)(fraction * 100));
     printf("Sequences:        %d\n", ds->totalSequences());
@@ -66,6 +69,33 @@ void saveNetwork(const NeuralNetwork &nn, const std::string &filename)          
     nn.exportLayers(&doc);
     nn.exportWeights(&doc);
     doc.writeFile(filename);
+}
+
+std::string replaceAll(std::string s, const std::string &from, const std::string &to)
+{
+    for (size_t p = 0; (p = s.find(from, p)) != std::string::npos; p += to.size()) s.replace(p, from.size(), to);
+    return s;
+}
+
+// "<prefix>_epochNNN.autosave": options, progress rows, network, weights and optimizer state (main.cpp:701-742)
+void saveState(const Configuration &config, const NeuralNetwork &nn, const optimizers::Optimizer &optimizer, const std::string &infoRows)
+{
+    json::Value doc(json::Value::Object);
+    doc.addMember("configuration", json::Value(config.serializedOptions()));
+    doc.addMember("info_rows", json::Value(replaceAll(infoRows, "\n", ";;;")));
+    nn.exportLayers(&doc);
+    nn.exportWeights(&doc);
+    optimizer.exportState(&doc);
+    char epoch[32]; snprintf(epoch, sizeof(epoch), "epoch%03d.autosave", optimizer.currentEpoch());
+    const std::string &prefix = config.autosavePrefix();
+    doc.writeFile(prefix + (prefix.empty() ? "" : "_") + epoch);
+}
+
+void restoreState(const json::Value &doc, optimizers::Optimizer *optimizer, std::string *infoRows)   // main.cpp:744-758
+{
+    if (!doc.hasMember("info_rows")) throw std::runtime_error("Missing value 'info_rows'");
+    *infoRows = replaceAll(doc["info_rows"].getString(), ";;;", "\n");
+    optimizer->importState(doc);
 }
 
 std::string printfRow(const char *format, ...)                                                  // main.cpp:760-775
@@ -141,9 +171,10 @@ void feedForward(const Configuration &config, NeuralNetwork &nn, data_sets::Data
 int trainerMain(const Configuration &config)                                                    // main.cpp:97-498
 {
     try {
-        printf("Reading network from '%s'... ", config.networkFile().c_str());
+        const std::string networkFile = config.continueFile().empty() ? config.networkFile() : config.continueFile();   // main.cpp:102
+        printf("Reading network from '%s'... ", networkFile.c_str());
         fflush(stdout);
-        json::Value netDoc = json::Value::parseFile(config.networkFile());
+        json::Value netDoc = json::Value::parseFile(networkFile);
         printf("done.\n\n");
 
         std::shared_ptr<data_sets::DataSet> trainingSet = std::make_shared<data_sets::DataSet>(), validationSet = trainingSet,
@@ -178,7 +209,10 @@ int trainerMain(const Configuration &config)                                    
 
         printf("Creating the neural network... ");
         fflush(stdout);
-        const int inputSize = config.trainingMode() ? trainingSet->inputPatternSize() : -1;      // main.cpp:146-148
+        // main.cpp:146-148 overrides the input layer size with the training set's pattern size; with context
+        // splicing the fractions carry (left + right + 1) frames per pattern, so that is the size used here
+        // (the reference passes the unspliced size and then fails in InputLayer::loadSequences).
+        const int inputSize = config.trainingMode() ? trainingSet->fractionInputPatternSize() : -1;
         NeuralNetwork::WeightsInit wi = { config.weightsDistributionIsNormal(), config.weightsDistributionUniformMin(),
                                           config.weightsDistributionUniformMax(), config.weightsDistributionNormalSigma(),
                                           config.weightsDistributionNormalMean(), config.randomSeed() };
@@ -210,32 +244,53 @@ int trainerMain(const Configuration &config)                                    
             printf("Test error every:          %d\n", config.testEvery());
             printf("Learning rate:             %g\n", (double)config.learningRate());
             printf("Momentum:                  %g\n\n", (double)config.momentum());
+            optimizer.setWeightNoise(config.weightNoiseSigma(), config.randomSeed());
+
+            std::string infoRows;
+            if (!config.continueFile().empty()) {                                               // main.cpp:198-204
+                printf("Restoring state from '%s'... ", config.continueFile().c_str());
+                fflush(stdout);
+                restoreState(netDoc, &optimizer, &infoRows);
+                printf("done.\n\n");
+            }
 
             printf("Starting training...\n\n");
             printf(" Epoch | Duration |  Training error  | Validation error |    Test error    | New best \n");
             printf("-------+----------+------------------+------------------+------------------+----------\n");
+            std::cout << infoRows;
             bool finished = false;
             while (!finished) {
                 const char *errFormat = (classificationTask ? "%6.2lf%%%10.3lf |" : "%17.3lf |");
                 const char *errSpace = "                  |";
-                printfRow(" %5d | ", optimizer.currentEpoch() + 1);
+                infoRows += printfRow(" %5d | ", optimizer.currentEpoch() + 1);
                 auto t0 = std::chrono::steady_clock::now();
                 finished = optimizer.train();
                 double duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-                printfRow("%8.1lf |", duration);
-                if (classificationTask) printfRow(errFormat, (double)optimizer.curTrainingClassError() * 100.0, (double)optimizer.curTrainingError());
-                else printfRow(errFormat, (double)optimizer.curTrainingError());
+                infoRows += printfRow("%8.1lf |", duration);
+                if (classificationTask) infoRows += printfRow(errFormat, (double)optimizer.curTrainingClassError() * 100.0, (double)optimizer.curTrainingError());
+                else infoRows += printfRow(errFormat, (double)optimizer.curTrainingError());
                 const bool validated = !validationSet->empty() && optimizer.currentEpoch() % config.validateEvery() == 0;
                 if (validated) {
-                    if (classificationTask) printfRow(errFormat, (double)optimizer.curValidationClassError() * 100.0, (double)optimizer.curValidationError());
-                    else printfRow(errFormat, (double)optimizer.curValidationError());
-                } else printfRow("%s", errSpace);
+                    if (classificationTask) infoRows += printfRow(errFormat, (double)optimizer.curValidationClassError() * 100.0, (double)optimizer.curValidationError());
+                    else infoRows += printfRow(errFormat, (double)optimizer.curValidationError());
+                } else infoRows += printfRow("%s", errSpace);
                 if (!testSet->empty() && optimizer.currentEpoch() % config.testEvery() == 0) {
-                    if (classificationTask) printfRow(errFormat, (double)optimizer.curTestClassError() * 100.0, (double)optimizer.curTestError());
-                    else printfRow(errFormat, (double)optimizer.curTestError());
-                } else printfRow("%s", errSpace);
-                if (validated) printfRow(optimizer.epochsSinceLowestValidationError() == 0 ? "  yes   \n" : "  no    \n");
-                else printfRow("        \n");
+                    if (classificationTask) infoRows += printfRow(errFormat, (double)optimizer.curTestClassError() * 100.0, (double)optimizer.curTestError());
+                    else infoRows += printfRow(errFormat, (double)optimizer.curTestError());
+                } else infoRows += printfRow("%s", errSpace);
+                if (validated) {
+                    const bool best = optimizer.epochsSinceLowestValidationError() == 0;
+                    infoRows += printfRow(best ? "  yes   \n" : "  no    \n");
+                    if (best && config.autosaveBest()) {                                         // main.cpp:254-268
+                        std::string base = config.autosavePrefix();
+                        if (base.empty()) {
+                            size_t pos = config.networkFile().find_last_of('.');
+                            base = (pos != std::string::npos && pos > 0) ? config.networkFile().substr(0, pos) : config.networkFile();
+                        }
+                        saveNetwork(neuralNetwork, base + ".best.jsn");
+                    }
+                } else infoRows += printfRow("        \n");
+                if (config.autosave()) saveState(config, neuralNetwork, optimizer, infoRows);  // main.cpp:275-277
             }
             printf("\n");
             if (optimizer.epochsSinceLowestValidationError() == config.maxEpochsNoBest())

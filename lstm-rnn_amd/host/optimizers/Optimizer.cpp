@@ -57,7 +57,29 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
         if (classification) *classError -= (real_t)correct;
 
         if (calcWeightUpdates) {
+            // weight noise: the forward pass above used the clean weights, the backward pass runs on noisy ones
+            // and the clean weights come back before the update (Optimizer.cu:58-68, :82-84).  The noise is
+            // drawn on the host like the reference's (TrainableLayer.cu:188-209), std::mt19937 instead of boost's.
+            std::vector<Hip::real_vector> origWeights(ls.size());
+            if (m_weightNoiseSigma > 0) {
+                std::normal_distribution<real_t> dist(0.0f, m_weightNoiseSigma);
+                for (size_t i = 1; i + 1 < ls.size(); ++i) {
+                    layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+                    if (!layer) continue;
+                    origWeights[i] = layer->weights();
+                    Hip::real_vector noisy = origWeights[i];
+                    for (size_t k = 0; k < noisy.size(); ++k) noisy[k] += dist(m_noiseGen);
+                    layer->setWeights(noisy);
+                }
+            }
             m_neuralNetwork.computeBackwardPass();
+            if (m_weightNoiseSigma > 0) {
+                hipCheck(cn_ctx_join(m_neuralNetwork.context()), m_neuralNetwork.context());   // gradient GEMMs still read the noisy operands
+                for (size_t i = 1; i + 1 < ls.size(); ++i) {
+                    layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+                    if (layer) layer->setWeights(origWeights[i]);
+                }
+            }
             if (m_hybridOnlineBatch) {
                 _updateWeights();                                           // Optimizer.cu:88-89
             } else {
@@ -103,6 +125,91 @@ bool Optimizer::train()
         }
     }
     return m_finished;
+}
+
+void Optimizer::_exportWeights(json::Value *jsonDoc, const char *arrayName, const std::vector<Hip::real_vector> &weights)
+{
+    json::Value weightsArray(json::Value::Array);
+    for (size_t i = 0; i < weights.size(); ++i) {
+        json::Value v(json::Value::Array);
+        v.reserve(weights[i].size());
+        for (size_t j = 0; j < weights[i].size(); ++j) v.pushBack(json::Value((double)weights[i][j]));
+        weightsArray.pushBack(v);
+    }
+    jsonDoc->addMember(arrayName, weightsArray);
+}
+void Optimizer::_importWeights(const json::Value &jsonDoc, const char *arrayName, std::vector<Hip::real_vector> *weights)
+{
+    if (!jsonDoc.hasMember(arrayName) || !jsonDoc[arrayName].isArray())
+        throw std::runtime_error(std::string("Array '") + arrayName + "' is missing or has the wrong type");
+    const json::Value &arr = jsonDoc[arrayName];
+    if (arr.size() != weights->size()) throw std::runtime_error(std::string("Array '") + arrayName + "' has a wrong size");
+    for (size_t i = 0; i < arr.size(); ++i) {
+        if (!arr[i].isArray()) throw std::runtime_error(std::string("Object in '") + arrayName + "' is not an array");
+        if (arr[i].size() != (*weights)[i].size()) throw std::runtime_error(std::string("Subarray in '") + arrayName + "' has a wrong size");
+        for (size_t j = 0; j < arr[i].size(); ++j) (*weights)[i][j] = (real_t)arr[i][j].getDouble();
+    }
+}
+
+void Optimizer::exportState(json::Value *jsonDoc) const
+{
+    jsonDoc->addMember("optimizer_finished", json::Value(m_finished));
+    jsonDoc->addMember("optimizer_cur_epoch", json::Value(m_curEpoch));
+    jsonDoc->addMember("optimizer_epochs_since_lowest_error", json::Value(m_epochsSinceLowestError));
+    jsonDoc->addMember("optimizer_lowest_validation_error", json::Value((double)m_lowestValidationError));
+    jsonDoc->addMember("optimizer_cur_training_error", json::Value((double)m_curTrainingError));
+    jsonDoc->addMember("optimizer_cur_validation_error", json::Value((double)m_curValidationError));
+    jsonDoc->addMember("optimizer_cur_test_error", json::Value((double)m_curTestError));
+    jsonDoc->addMember("optimizer_cur_training_class_error", json::Value((double)m_curTrainingClassError));
+    jsonDoc->addMember("optimizer_cur_validation_class_error", json::Value((double)m_curValidationClassError));
+    jsonDoc->addMember("optimizer_cur_test_class_error", json::Value((double)m_curTestClassError));
+    _exportWeights(jsonDoc, "optimizer_best_weights", m_bestWeights);
+}
+void Optimizer::importState(const json::Value &jsonDoc)
+{
+    m_finished = jsonDoc["optimizer_finished"].getBool();
+    m_curEpoch = jsonDoc["optimizer_cur_epoch"].getInt();
+    m_epochsSinceLowestError = jsonDoc["optimizer_epochs_since_lowest_error"].getInt();
+    m_lowestValidationError = (real_t)jsonDoc["optimizer_lowest_validation_error"].getDouble();
+    m_curTrainingError = (real_t)jsonDoc["optimizer_cur_training_error"].getDouble();
+    m_curValidationError = (real_t)jsonDoc["optimizer_cur_validation_error"].getDouble();
+    m_curTestError = (real_t)jsonDoc["optimizer_cur_test_error"].getDouble();
+    m_curTrainingClassError = (real_t)jsonDoc["optimizer_cur_training_class_error"].getDouble();
+    m_curValidationClassError = (real_t)jsonDoc["optimizer_cur_validation_class_error"].getDouble();
+    m_curTestClassError = (real_t)jsonDoc["optimizer_cur_test_class_error"].getDouble();
+    _importWeights(jsonDoc, "optimizer_best_weights", &m_bestWeights);
+}
+
+// the momentum state lives on the device (CN_BUF_WEIGHT_DELTAS); autosave moves it through the host
+void SteepestDescentOptimizer::exportState(json::Value *jsonDoc) const
+{
+    Optimizer::exportState(jsonDoc);
+    NeuralNetwork &nn = const_cast<SteepestDescentOptimizer *>(this)->_neuralNetwork();
+    const std::vector<std::shared_ptr<layers::Layer> > &ls = nn.layers();
+    std::vector<Hip::real_vector> deltas(ls.size());
+    for (size_t i = 1; i + 1 < ls.size(); ++i) {
+        layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+        if (!layer) continue;
+        deltas[i].resize(layer->weightCount());
+        hipCheck(cn_layer_read(layer->handle(), CN_BUF_WEIGHT_DELTAS, 0, deltas[i].data(), deltas[i].size()), nn.context());
+    }
+    _exportWeights(jsonDoc, "steepest_descent_optimizer_weight_deltas", deltas);
+}
+void SteepestDescentOptimizer::importState(const json::Value &jsonDoc)
+{
+    Optimizer::importState(jsonDoc);
+    NeuralNetwork &nn = _neuralNetwork();
+    const std::vector<std::shared_ptr<layers::Layer> > &ls = nn.layers();
+    std::vector<Hip::real_vector> deltas(ls.size());
+    for (size_t i = 1; i + 1 < ls.size(); ++i) {
+        layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+        if (layer) deltas[i].resize(layer->weightCount());
+    }
+    _importWeights(jsonDoc, "steepest_descent_optimizer_weight_deltas", &deltas);
+    for (size_t i = 1; i + 1 < ls.size(); ++i) {
+        layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+        if (layer) hipCheck(cn_layer_upload(layer->handle(), CN_BUF_WEIGHT_DELTAS, deltas[i].data(), deltas[i].size()), nn.context());
+    }
 }
 
 SteepestDescentOptimizer::SteepestDescentOptimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingSet,

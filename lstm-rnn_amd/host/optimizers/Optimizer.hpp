@@ -3,8 +3,10 @@
 // sequences them.
 #pragma once
 
+#include <random>
 #include <vector>
 
+#include "../Json.hpp"
 #include "../NeuralNetwork.hpp"
 #include "../data_sets/DataSet.hpp"
 
@@ -17,6 +19,12 @@ public:
               data_sets::DataSet &testSet, int maxEpochs, int maxEpochsNoBest, int validateEvery, int testEvery,
               bool hybridOnlineBatch);
     virtual ~Optimizer() {}
+
+    // Gaussian weight noise during the backward pass (Optimizer.cu:58-68,82-84; --weight_noise_sigma)
+    void setWeightNoise(real_t sigma, unsigned randomSeed) { m_weightNoiseSigma = sigma; m_noiseGen.seed(randomSeed); }
+    // autosave / --continue (Optimizer.cu:326-358)
+    virtual void exportState(json::Value *jsonDoc) const;
+    virtual void importState(const json::Value &jsonDoc);
 
     bool finished() const { return m_finished; }
     int currentEpoch() const { return m_curEpoch; }
@@ -50,7 +58,11 @@ private:
     real_t m_lowestValidationError, m_curTrainingError, m_curValidationError, m_curTestError,
            m_curValidationClassError, m_curTrainingClassError, m_curTestClassError;
     std::vector<Hip::real_vector> m_curWeightUpdates, m_bestWeights;
+    real_t m_weightNoiseSigma = 0;
+    std::mt19937 m_noiseGen;
 protected:
+    static void _exportWeights(json::Value *jsonDoc, const char *arrayName, const std::vector<Hip::real_vector> &weights);   // :106-123
+    static void _importWeights(const json::Value &jsonDoc, const char *arrayName, std::vector<Hip::real_vector> *weights);   // :125-149
     bool hybridOnlineBatch() const { return m_hybridOnlineBatch; }
 };
 
@@ -59,6 +71,8 @@ public:
     SteepestDescentOptimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingSet, data_sets::DataSet &validationSet,
                              data_sets::DataSet &testSet, int maxEpochs, int maxEpochsNoBest, int validateEvery, int testEvery,
                              real_t learningRate, real_t momentum, bool hybridOnlineBatch);
+    void exportState(json::Value *jsonDoc) const;                       // SteepestDescentOptimizer.cu:118-131
+    void importState(const json::Value &jsonDoc);
 protected:
     void _updateWeights();                                              // SteepestDescentOptimizer.cu:67-94
 private:

@@ -68,6 +68,35 @@ def test_reader_and_packer_cpu(pkg, tmp_path):
         assert int(kv["sum_targets"]) == int(f["targetClasses"][f["targetClasses"] >= 0].sum())
 
 
+def test_context_splicing_output_lag_and_input_noise_cpu(pkg, tmp_path):
+    """--input_left_context / --input_right_context / --output_time_lag (DataSet.cpp:302-305,346-397) against the
+    Python packer, and --input_noise_sigma (DataSet.cpp:250-265): reproducible per seed, changes the inputs."""
+    if not os.path.exists(BIN):
+        import __graft_entry__ as ge
+        ge.build()
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    base = [BIN, "--train", "true", "--train_file", nc, "--network", net, "--parallel_sequences", "3", "--dump_fractions", "true",
+            "--random_seed", "7"]
+    out = subprocess.run(base + ["--input_left_context", "2", "--input_right_context", "1", "--output_time_lag", "2"],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [l for l in out.stdout.splitlines() if l.startswith("FRACTION")]
+    fracs = pkg.make_fractions(xs, ts, 3, sort_by_length=True, context_left=2, context_right=1, output_lag=2)
+    assert len(rows) == len(fracs)
+    for row, f in zip(rows, fracs):
+        kv = dict(p.split("=") for p in row.split()[2:])
+        assert f["inputs"].shape[1] == 6 * 4
+        assert abs(float(kv["sum_inputs"]) - float(f["inputs"].astype(np.float64).sum())) < 1e-3
+        assert int(kv["sum_targets"]) == int(f["targetClasses"][f["targetClasses"] >= 0].sum())
+    clean = subprocess.run(base, capture_output=True, text=True, timeout=60).stdout
+    noisy1 = subprocess.run(base + ["--input_noise_sigma", "0.5"], capture_output=True, text=True, timeout=60).stdout
+    noisy2 = subprocess.run(base + ["--input_noise_sigma", "0.5"], capture_output=True, text=True, timeout=60).stdout
+    get = lambda txt: [float(dict(p.split("=") for p in l.split()[2:])["sum_inputs"]) for l in txt.splitlines() if l.startswith("FRACTION")]
+    assert get(noisy1) == get(noisy2) and get(noisy1) != get(clean)
+    n_vals = sum(len(x) for x in xs) * 6
+    assert abs(sum(get(noisy1)) - sum(get(clean))) < 6 * 0.5 * np.sqrt(n_vals)      # zero-mean noise of sigma 0.5
+
+
 def test_driver_failure_exit_code(tmp_path):
     """Errors end as "FAILED: <msg>" with exit code 2 (main.cpp:492-495)."""
     if not os.path.exists(BIN):
@@ -134,3 +163,40 @@ def test_driver_forward_pass_writers(pkg, orc, tmp_path):
     vals = np.frombuffer(raw[12:], ">f4").reshape(n, 4)
     ref.load_sequences(fracs[0]); ref.compute_forward_pass()
     assert np.abs(vals - ref.outputs()[:n, 0, :]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_driver_autosave_continue_and_weight_noise(pkg, tmp_path):
+    """--autosave writes <prefix>_epochNNN.autosave after every epoch and --continue resumes from it with the
+    optimizer state (main.cpp:198-204,275-277,701-758): resuming the epoch-1 autosave of a 3-epoch run ends
+    in the same network as the run itself.
+    --weight_noise_sigma perturbs only the backward pass (Optimizer.cu:58-84)."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    common = [BIN, "--train", "true", "--stochastic", "true", "--train_file", nc, "--val_file", nc, "--network", net,
+              "--parallel_sequences", "3", "--learning_rate", "1e-2", "--momentum", "0.9", "--random_seed", "3"]
+    straight = str(tmp_path / "straight.jsn")
+    prefix = str(tmp_path / "run")
+    out = subprocess.run(common + ["--max_epochs", "3", "--autosave", "true", "--autosave_best", "true", "--autosave_prefix", prefix,
+                                   "--save_network", straight], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    auto = prefix + "_epoch001.autosave"
+    assert os.path.exists(auto) and os.path.exists(prefix + ".best.jsn")
+    state = json.load(open(auto))
+    assert state["optimizer_cur_epoch"] == 1 and state["optimizer_finished"] is False and "steepest_descent_optimizer_weight_deltas" in state and ";;;" in state["info_rows"]
+    resumed = str(tmp_path / "resumed.jsn")
+    out = subprocess.run([BIN, "--continue", auto, "--max_epochs", "3", "--autosave", "false", "--save_network", resumed],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Restoring state from" in out.stdout
+    a, b = json.load(open(straight)), json.load(open(resumed))
+    for name, w in a["weights"].items():
+        for k in ("input", "bias", "internal"):
+            d = np.abs(np.asarray(w[k], np.float64) - np.asarray(b["weights"][name][k], np.float64))
+            assert d.size == 0 or d.max() < 2e-6, (name, k)      # the autosave text carries ~7 significant digits
+    noisy = str(tmp_path / "noisy.jsn")
+    out = subprocess.run(common + ["--max_epochs", "3", "--weight_noise_sigma", "0.01", "--save_network", noisy],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    c = json.load(open(noisy))
+    diff = max(np.abs(np.asarray(a["weights"][n]["input"]) - np.asarray(c["weights"][n]["input"])).max() for n in a["weights"])
+    assert 0 < diff < 0.05
