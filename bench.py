@@ -144,7 +144,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def run_workload(name, steps, warmup, roofline_pass):
+    def run_workload(name, steps, warmup, roofline_pass, host_pass=False):
         wl = WORKLOADS[name]
         P, C, hidden, PS = wl["P"], wl["C"], wl["hidden"], args.parallel_sequences
         layers = net_desc(P, hidden, C)
@@ -167,9 +167,12 @@ def main():
         wptr, gptr, dptr, count = net.param_arena()
         grads = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device=dev) if world > 1 else None
 
-        def step(i):
+        def step(i, from_host=False):
             f = dfr[i % nfrac]
-            net.load_sequences_resident(f)
+            if from_host:
+                net.load_sequences(fracs[i % nfrac])        # pageable host buffers through cn_fraction_load (PCIe)
+            else:
+                net.load_sequences_resident(f)
             net.compute_forward_pass()
             net.loss_accumulate()
             net.compute_backward_pass()
@@ -199,11 +202,20 @@ def main():
             net.synchronize()
             res["timing"] = net.timing_read(); res["timing_frames"] = fr2
             net.timing_enable(False)
+        if host_pass:
+            # the same steps with the fractions handed over as host buffers: PCIe-inclusive rate (never `value`)
+            barrier()
+            t0 = time.perf_counter()
+            fr3 = 0
+            for i in range(steps):
+                fr3 += step(warmup + i, from_host=True)
+            barrier()
+            res["host_frames_per_s"] = fr3 / (time.perf_counter() - t0)
         net.close()
         del keep
         return res, wl
 
-    res, wl = run_workload(args.workload, args.steps, args.warmup, not args.no_roofline_pass)
+    res, wl = run_workload(args.workload, args.steps, args.warmup, not args.no_roofline_pass, host_pass=(world == 1))
     t = torch.tensor([res["seconds"], float(res["frames"])], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,6 +247,9 @@ def main():
                        "weights": res["weights"], "update": "stochastic momentum SGD every fraction",
                        "parallelism": "dp%d over sequences" % world},
         }
+        if "host_frames_per_s" in res:
+            out["pcie_inclusive"] = {"value": res["host_frames_per_s"], "unit": "frames/s",
+                                     "note": "fractions handed over as pageable host buffers (cn_fraction_load); informational"}
         if "timing" in res:
             tm, fr = res["timing"], res["timing_frames"]
             b_fwd, b_bwd, fl_rec = rec_algorithmic(wl["hidden"])

@@ -37,6 +37,23 @@
 
 namespace cn {
 
+// In-kernel segment timing (tools/stamps.py builds a second library with -DCN_STAMP; never defined in the
+// shipped build): every wave of workgroup 0 sums s_memtime deltas per step segment.
+#ifdef CN_STAMP
+__device__ unsigned long long cn_stamp_buf[2][16][8];
+#define STAMP_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define STAMP(i) { unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define STAMP_FORCE(x) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+#define STAMP_RESET st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP_STORE(k) if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 6; ++i_) cn_stamp_buf[k][threadIdx.x >> 6][i_] = st_acc[i_]; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FORCE(x)
+#define STAMP_RESET
+#define STAMP_STORE(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // forward: a[t] = G[t] + Wrec^T y[prev(t)]; ComputeBlockOutputFn
 // ---------------------------------------------------------------------------------------------
@@ -111,20 +128,22 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     // Prefetches are unconditional (time index clamped) so the staged registers are plain load
     // results: no select against an old value, no wait at the loop back edge.
     f32x4 preA[UG][RPL], preB[UG][RPL];
-    char ptA[RPL], ptB[RPL];
-    auto prefetch = [&](int t, f32x4 (&pre)[UG][RPL], char (&pt)[RPL]) {
+    int ptA[RPL], ptB[RPL];         // pattern types, kept as whole dwords (a byte-typed stage made hipcc copy the
+                                    // freshly loaded register, which waits for the load in the middle of the step)
+    auto prefetch = [&](int t, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
         const float *actsT = p.acts + t * stepA;
         const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            pt[r] = patT[oP[r]];
+            pt[r] = (unsigned char)patT[oP[r]];
 #pragma unroll
             for (int u = 0; u < UG; ++u) pre[u][r] = *(const f32x4 *)(actsT + oA[u][r]);
         }
     };
 
-    auto step = [&](int it, f32x4 (&pre)[UG][RPL], char (&pt)[RPL]) {
+    STAMP_DECL
+    auto step = [&](int it, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
         const char *ycur = smem + (it & 1) * 16 * pitch;
         char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
@@ -136,13 +155,18 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         // pre-activation of the N-wide GEMM is added to the real rows afterwards
         f32x4 acc[UG][4];
         f32x4 g_[UG][RPL];
-        char ptc[RPL];
+        bool dummy_[RPL];
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) ptc[r] = pt[r];
+        for (int r = 0; r < RPL; ++r) dummy_[r] = check && pt[r] == 0;
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
+            // the staged values move to registers of their own (early-clobber asm copy) so that the prefetch
+            // below can land in the stage's registers again; left to the register coalescer, the stage keeps
+            // being read by the cell update, the load goes elsewhere and is copied back right behind its issue
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) g_[u][r] = pre[u][r];
+            for (int r = 0; r < RPL; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(g_[u][r][g]) : "v"(pre[u][r][g]));
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -150,12 +174,16 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         }
 
         prefetch(d ? t - 2 : t + 2, pre, pt);
+        STAMP(0)
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
         if constexpr (RES) {
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
-                const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+                u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#ifdef CN_STAMP
+                if (kc == 0) { STAMP_FORCE(a[0]) STAMP(1) }
+#endif
 #pragma unroll
                 for (int u = 0; u < UG; ++u)
 #pragma unroll
@@ -176,12 +204,13 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
             }
         }
 
+        STAMP_FORCE(acc[UG - 1][3][0]) STAMP(2)
         // cell update: C/D map of the 16x16 MFMA: col = lane&15 (unit), row = 4*(lane>>4)+reg
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                const bool dummy = check && ptc[r] == 0;
+                const bool dummy = dummy_[r];
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
                 const float ni = tanh_ref<F32>(acc[u][0][r] + g_[u][r][0]);
@@ -190,9 +219,12 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 const float cs = ni * ig + cp * fg;
                 const float og = logistic<F32>(acc[u][3][r] + g_[u][r][3] + cs * po[u]);
                 const float y = tanh_ref<F32>(cs) * og;
-                const float yo = dummy ? 0.f : y;
+                float yo = dummy ? 0.f : y;
                 const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
                 cst[u][r] = co;
+#ifdef CN_STAMP
+                if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(yo) STAMP(3) }
+#endif
                 if constexpr (F32) *(float *)(ynxt + (4 * q + r) * pitch + unit[u] * 4) = yo;
                 else *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit[u] * 2) = (__bf16)yo;
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
@@ -202,16 +234,35 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 else ((__bf16 *)p.y_op + t * stepC)[oC[u][r]] = (__bf16)yo;
             }
         }
+        STAMP(4)
         lds_barrier();
+        STAMP(5)
     };
 
     prefetch(d ? T - 1 : 0, preA, ptA);
     prefetch(d ? T - 2 : 1, preB, ptB);
     lds_barrier();
-    for (int it = 0; it < T; it += 2) {
-        step(it, preA, ptA);
-        if (it + 1 < T) step(it + 1, preB, ptB);
+    STAMP_RESET
+    // The first two steps are peeled so that the loop is entered with the same memory operations in flight
+    // as at its back edge.  Entered straight from the prologue, the compiler's s_waitcnt at the loop head
+    // has to cover the prologue's load order and becomes vmcnt(1): every other step then waits for the
+    // previous step's stores to be acknowledged (~250 cycles of a ~1500 cycle step).
+    // The loop body is exactly two steps with no branch between them (an odd last step follows the loop): a
+    // conditional second step makes the staged registers phi values, which hipcc resolves with copies right
+    // behind the prefetch loads, i.e. with waits for loads it has just issued.
+    if (T >= 2) {
+        step(0, preA, ptA);
+        step(1, preB, ptB);
+        int it = 2;
+        for (; it + 1 < T; it += 2) {
+            step(it, preA, ptA);
+            step(it + 1, preB, ptB);
+        }
+        if (it < T) step(it, preA, ptA);
+    } else {
+        step(0, preA, ptA);
     }
+    STAMP_STORE(0)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -221,7 +272,7 @@ template <int UG, int RPL> struct BwdPre {
     f32x4 a[UG][RPL];        // n, i, f, o of step t
     float e[UG][RPL];        // outputErrors of step t
     float cp[UG][RPL];       // cell state of prev(t)
-    char pt[RPL];
+    int pt[RPL];
 };
 
 template <bool F32, int HP, int UG, int RPL>
@@ -299,7 +350,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            pre.pt[r] = patT[oP[r]];
+            pre.pt[r] = (unsigned char)patT[oP[r]];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
                 pre.e[u][r] = errT[oC[u][r]];
@@ -309,6 +360,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         }
     };
 
+    STAMP_DECL
     auto step = [&](int it, BwdPre<UG, RPL> &pre) {
         const int t = d ? it : T - 1 - it;
         const char *dcur = smem + (it & 1) * 16 * pitch;
@@ -317,10 +369,11 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
 
+
         f32x4 acc[UG];
         f32x4 a_[UG][RPL];
         float cp_[UG][RPL];
-        char ptc[RPL];
+        int ptc[RPL];
 #pragma unroll
         for (int r = 0; r < RPL; ++r) ptc[r] = pre.pt[r];
 #pragma unroll
@@ -331,15 +384,33 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
             for (int r = 0; r < RPL; ++r) { cp_[u][r] = hasprev_ ? pre.cp[u][r] : 0.f; a_[u][r] = pre.a[u][r]; }
         }
         prefetch(d ? t + 2 : t - 2, pre);
+        STAMP(0)
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
         if constexpr (RES) {
+            // A-operand reads run LDS_AHEAD chunks ahead of the MFMAs that consume them.  Left alone, the
+            // scheduler issues each read one chunk ahead, so every MFMA group waits most of an LDS round trip
+            // (16 of them per step); reading everything up front costs 64 VGPRs and pushes W_rec into AGPRs.
+            constexpr int LDS_AHEAD = KCR < 4 ? KCR : 4;
+            u32x4 a[KCR];
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) a[kc] = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+#ifdef CN_STAMP
+            STAMP_FORCE(a[0][0]) STAMP(1)
+#endif
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
-                const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
 #pragma unroll
-                for (int u = 0; u < UG; ++u) mma16<F32>(acc[u], a, wreg[u][kc]);
+                for (int u = 0; u < UG; ++u) mma16<F32>(acc[u], a[kc], wreg[u][kc]);
             }
+#ifndef CN_STAMP
+            __builtin_amdgcn_sched_group_barrier(0x100, LDS_AHEAD, 0);
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) {
+                __builtin_amdgcn_sched_group_barrier(0x008, UG, 0);
+                if (kc + LDS_AHEAD < KCR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#endif
         } else {
             for (int kc = 0; kc < KC; ++kc) {
                 const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
@@ -351,6 +422,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
             }
         }
 
+        STAMP_FORCE(acc[UG - 1][0]) STAMP(2)
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
@@ -369,6 +441,9 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 float dig = ig * (1.0f - ig) * ni * ec;
                 dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
                 if (dummy) { dni = dig = dfg = dog = 0.f; ec = 0.f; }                      // :224-234
+#ifdef CN_STAMP
+                if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(dog) STAMP(3) }
+#endif
                 fgn[u][r] = dummy ? 0.f : fg;
                 ecn[u][r] = ec; dign[u][r] = dig; dfgn[u][r] = dfg;
                 ccur[u][r] = cp;
@@ -386,7 +461,9 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 }
             }
         }
+        STAMP(4)
         lds_barrier();
+        STAMP(5)
     };
 
 #pragma unroll
@@ -397,10 +474,21 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     prefetch(tfirst, preA);
     prefetch(d ? 1 : T - 2, preB);
     lds_barrier();
-    for (int it = 0; it < T; it += 2) {
-        step(it, preA);
-        if (it + 1 < T) step(it + 1, preB);
+    STAMP_RESET
+    // branch-free pairs of steps, first pair peeled (see the forward kernel)
+    if (T >= 2) {
+        step(0, preA);
+        step(1, preB);
+        int it = 2;
+        for (; it + 1 < T; it += 2) {
+            step(it, preA);
+            step(it + 1, preB);
+        }
+        if (it < T) step(it, preA);
+    } else {
+        step(0, preA);
     }
+    STAMP_STORE(1)
 
     // fold the 4 sequence quads of each unit column, then one atomic per (gate, unit) and workgroup
 #pragma unroll
@@ -468,6 +556,13 @@ static void launch_rec(hipStream_t s, const LstmRec &p)
     else if (groups <= 32) launch_rpl<F32, BWD, 0, 2>(s, p, groups / 2);
     else                   launch_rpl<F32, BWD, 0, 4>(s, p, groups / 4);
 }
+
+#ifdef CN_STAMP
+extern "C" int cn_dbg_read_stamps(unsigned long long *host)      // [2][16][8]
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_stamp_buf), sizeof(cn_stamp_buf));
+}
+#endif
 
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
 {
