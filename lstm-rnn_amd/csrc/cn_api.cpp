@@ -580,6 +580,10 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
                 throw cn_error(CN_ERR_SHAPE, "Cannot create a bidirectional layer with an odd layer size");   // LstmLayer.cu:528-529
             l->H = size / l->dirs; l->Hp = pad_units(l->H); l->Lp = l->dirs * l->Hp;
             const size_t R = (size_t)l->dirs * 4 * l->Hp;
+            // the recurrent kernels address every per-frame buffer with 32-bit byte offsets from its base
+            if (maxN * R * sizeof(float) >= (1ull << 32))
+                throw cn_error(CN_ERR_SHAPE, "cn_layer_create: parallel_sequences * max_seq_length * 16 * layer size must stay below 4 GiB "
+                                             "per LSTM layer; use fewer parallel sequences");
             l->nw = size * (4 * (l->P + 1) + 4 * l->H + 3);                                            // LstmLayer.cu:525
             l->out_op = dalloc(l, maxN * l->Lp * e);
             l->err = (float *)dalloc(l, maxN * l->Lp * sizeof(float));

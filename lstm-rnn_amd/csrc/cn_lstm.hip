@@ -54,6 +54,30 @@ __device__ unsigned long long cn_stamp_buf[2][16][8];
 #define STAMP_STORE(k)
 #endif
 
+// element `elem` of an array of T at a wave-uniform base: the byte offset stays a 32-bit VGPR (saddr form)
+template <typename T> __device__ __forceinline__ T &at32(const void *base, unsigned elem)
+{
+    return *(T *)((char *)base + elem * (unsigned)sizeof(T));
+}
+
+// dtab[t][j] = (t >= Tmin && patTypes[t][s0 + j] == NONE) for the 4*RPL sequences of a workgroup.  One dword
+// (four sequences) per thread and round, so a pass of up to blockDim.x / RPL time steps is a single round
+// trip; PS and s0 are multiples of 4, the rows are dword aligned.
+template <int RPL>
+__device__ __forceinline__ void build_dummy_table(unsigned char *dtab, const char *pat, int T, int Tmin, int PS, int s0)
+{
+    for (int i = threadIdx.x; i < T * RPL; i += blockDim.x) {
+        const int tt = i / RPL, jj = i % RPL;
+        const unsigned w = *(const unsigned *)(pat + (long)tt * PS + s0 + 4 * jj);
+        unsigned f = 0;
+        if (tt >= Tmin) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) f |= (((w >> (8 * b)) & 0xffu) == 0u ? 1u : 0u) << (8 * b);
+        }
+        *(unsigned *)(dtab + 4 * i) = f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: a[t] = G[t] + Wrec^T y[prev(t)]; ComputeBlockOutputFn
 // ---------------------------------------------------------------------------------------------
@@ -177,7 +201,33 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         STAMP(0)
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
-        if constexpr (RES) {
+        if constexpr (RES && UG > 1 && KCR <= 8) {
+            // unit group after unit group: the cell update of group u only needs that group's sums, so it can
+            // run on the VALU while the MFMAs of group u+1 are in flight (one wave per SIMD in this shape)
+            u32x4 a[KCR];
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) a[kc] = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#ifdef CN_STAMP
+            STAMP_FORCE(a[0][0]) STAMP(1)
+#endif
+#pragma unroll
+            for (int u = 0; u < UG; ++u)
+#pragma unroll
+                for (int kc = 0; kc < KCR; ++kc)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mma16<F32>(acc[u][g], a[kc], wreg[u][g][kc]);
+#ifndef CN_STAMP
+            // issue order: all LDS reads, the MFMAs of group 0, then every MFMA of the later groups followed by
+            // three VALU instructions (the cell update of the group before it)
+            __builtin_amdgcn_sched_group_barrier(0x100, KCR, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * KCR, 0);
+#pragma unroll
+            for (int i = 0; i < 4 * KCR * (UG - 1); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            }
+#endif
+        } else if constexpr (RES) {
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
                 u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
@@ -272,7 +322,6 @@ template <int UG, int RPL> struct BwdPre {
     f32x4 a[UG][RPL];        // n, i, f, o of step t
     float e[UG][RPL];        // outputErrors of step t
     float cp[UG][RPL];       // cell state of prev(t)
-    int pt[RPL];
 };
 
 template <bool F32, int HP, int UG, int RPL>
@@ -294,6 +343,11 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     const long crow = (long)dirs * Hp;
 
     for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    // dummy-slot table of this workgroup's sequences, read per step from LDS (LstmLayer.cu:224-234 with
+    // checkPatType of :949,983); the forward kernel stages the pattern type through its register prefetch
+    // instead, which measured faster there (0.47 vs 0.49 us per step) and slower here
+    unsigned char *dtab = (unsigned char *)smem + 2 * 16 * pitch;
+    build_dummy_table<RPL>(dtab, p.pat, T, p.Tmin, p.PS, (blockIdx.x / p.dirs) * (4 * RPL));
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
@@ -312,18 +366,18 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         }
     }
 
-    int oP[RPL], oA[UG][RPL], oC[UG][RPL];
+    // uniform base + 32-bit offsets, as in the forward kernel
+    unsigned oA[UG][RPL], oC[UG][RPL];
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int sv = s0 + 4 * r + q;
-        oP[r] = sv;
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
-            oA[u][r] = sv * (int)arow + (d * Hp + unit[u]) * 4;
-            oC[u][r] = sv * (int)crow + d * Hp + unit[u];
+            oA[u][r] = (unsigned)(sv * (int)arow + (d * Hp + unit[u]) * 4);          // elements into an acts / delta row block
+            oC[u][r] = (unsigned)(sv * (int)crow + d * Hp + unit[u]);                // elements into a cell / err row block
         }
     }
-    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned stepA = (unsigned)PS * (unsigned)arow, stepC = (unsigned)PS * (unsigned)crow;   // elements per time step
 
     // carried across steps (values of the step processed just before = next(t) in time)
     float fgn[UG][RPL], ecn[UG][RPL], dign[UG][RPL], dfgn[UG][RPL], ccur[UG][RPL];
@@ -345,17 +399,15 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);         // unconditional, clamped (see the forward kernel)
         const int tprev = d ? t + 1 : t - 1;          // prev(t) in the forward processing order
         const bool hasprev = tprev >= 0 && tprev < T; // lastCall, LstmLayer.cu:947,981
-        const float *actsT = p.acts + t * stepA, *errT = p.err + t * stepC;
-        const float *cellP = p.cell + (hasprev ? tprev : t) * stepC;
-        const char *patT = p.pat + (long)t * PS;
+        const unsigned bA = (unsigned)t * stepA, bC = (unsigned)t * stepC;
+        const unsigned bCp = (unsigned)(hasprev ? tprev : t) * stepC;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            pre.pt[r] = (unsigned char)patT[oP[r]];
 #pragma unroll
             for (int u = 0; u < UG; ++u) {
-                pre.e[u][r] = errT[oC[u][r]];
-                pre.a[u][r] = *(const f32x4 *)(actsT + oA[u][r]);
-                pre.cp[u][r] = cellP[oC[u][r]];      // raw; masked with lastCall when consumed (no wait here)
+                pre.e[u][r] = at32<float>(p.err, bC + oC[u][r]);
+                pre.a[u][r] = *(const f32x4 *)&at32<float>(p.acts, bA + oA[u][r]);
+                pre.cp[u][r] = at32<float>(p.cell, bCp + oC[u][r]);     // raw; masked with lastCall when consumed (no wait here)
             }
         }
     };
@@ -365,17 +417,17 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         const int t = d ? it : T - 1 - it;
         const char *dcur = smem + (it & 1) * 16 * pitch;
         char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
-        const bool check = t >= p.Tmin;
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
+        const unsigned bD = (unsigned)t * stepA;
 
 
         f32x4 acc[UG];
         f32x4 a_[UG][RPL];
         float cp_[UG][RPL];
-        int ptc[RPL];
+        unsigned char dmy[RPL];                      // dummy-slot flags of this step (LDS table, see the forward kernel)
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) ptc[r] = pre.pt[r];
+        for (int r = 0; r < RPL; ++r) dmy[r] = dtab[t * (4 * RPL) + 4 * r + q];
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
@@ -427,7 +479,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
             for (int r = 0; r < RPL; ++r) {
-                const bool dummy = check && ptc[r] == 0;
+                const bool dummy = dmy[r] != 0;
                 // ComputeBlockErrorsFn, LstmLayer.cu:236-285
                 const float e = acc[u][r];
                 const float ni = a_[u][r][0], ig = a_[u][r][1], fg = a_[u][r][2], og = a_[u][r][3];
@@ -453,11 +505,11 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 if constexpr (F32) {
                     const f32x4 dv = {dni, dig, dfg, dog};
                     *(f32x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 16) = dv;
-                    *(f32x4 *)((float *)p.delta_op + t * stepA + oA[u][r]) = dv;
+                    *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
                 } else {
                     const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
                     *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 8) = dv;
-                    *(bf16x4 *)((__bf16 *)p.delta_op + t * stepA + oA[u][r]) = dv;
+                    *(bf16x4 *)&at32<__bf16>(p.delta_op, bD + oA[u][r]) = dv;
                 }
             }
         }
@@ -470,7 +522,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     for (int r = 0; r < RPL; ++r)
 #pragma unroll
         for (int u = 0; u < UG; ++u)
-            ccur[u][r] = (p.cell + tfirst * stepC)[oC[u][r]];
+            ccur[u][r] = at32<float>(p.cell, (unsigned)tfirst * stepC + oC[u][r]);
     prefetch(tfirst, preA);
     prefetch(d ? 1 : T - 2, preB);
     lds_barrier();
@@ -517,7 +569,7 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
     const int ELT = F32 ? 4 : 2;
     const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
     const int pitch = (BWD ? 4 : 1) * p.Hp * ELT + 16;
-    const size_t lds = 2 * 16 * (size_t)pitch;
+    const size_t lds = 2 * 16 * (size_t)pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
     auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -548,6 +600,7 @@ static void launch_rec(hipStream_t s, const LstmRec &p)
         // 128 KB per step through the 256 B/clk LDS port (as long as the MFMAs themselves); 4 waves owning two
         // unit groups each halve that traffic at the same MFMA and VALU work per SIMD
         if (BWD && !F32 && !getenv("CN_BWD_UG1")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);
+        else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);   // measured slower: 0.63 vs 0.47 us per step
         else launch_rpl<F32, BWD, 128, 1>(s, p, 8);
         return;
     default: break;
