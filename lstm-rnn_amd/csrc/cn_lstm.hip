@@ -92,7 +92,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     constexpr int ELT = F32 ? 4 : 2;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
-    const int pitch = Hp * ELT + 16;                 // LDS row pitch of the y tile (bytes)
+    const int pitch = lds_pitch(Hp * ELT);           // LDS row pitch of the y tile (bytes)
     const int KC = Hp * ELT / 64;                    // 64-byte K chunks
     constexpr int KCR = RES ? HP * ELT / 64 : 1;
     const int nw = blockDim.x >> 6;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     constexpr int ELT = F32 ? 4 : 2;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
-    const int pitch = 4 * Hp * ELT + 16;             // LDS row pitch of the delta tile, k = 4*unit + gate
+    const int pitch = lds_pitch(4 * Hp * ELT);       // LDS row pitch of the delta tile, k = 4*unit + gate
     const int KC = 4 * Hp * ELT / 64;
     constexpr int KCR = RES ? 4 * HP * ELT / 64 : 1;
     const int nw = blockDim.x >> 6;
@@ -568,7 +568,7 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
 {
     const int ELT = F32 ? 4 : 2;
     const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
-    const int pitch = (BWD ? 4 : 1) * p.Hp * ELT + 16;
+    const int pitch = lds_pitch((BWD ? 4 : 1) * p.Hp * ELT);
     const size_t lds = 2 * 16 * (size_t)pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
     auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
     static bool attr_set = false;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CS = HP / UPC, NT = UPC * 4, KC = HP / 32;
-    constexpr int pitch = HP * 2 + 16;
+    constexpr int pitch = lds_pitch(HP * 2);
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CS = HP / UPC, NT = UPC * 4, KC = 4 * HP / 32;
-    constexpr int pitch = 4 * HP * 2 + 16;           // delta tile row: k = 4*unit + gate
+    constexpr int pitch = lds_pitch(4 * HP * 2);     // delta tile row: k = 4*unit + gate
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
@@ -341,7 +341,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     constexpr int CS = HP / UPC, NT = UPC * 4;
     const int nclusters = p.dirs * (p.PS / (4 * RPL));
     const int grid = (nclusters + 7) / 8 * 8 * CS;
-    const size_t lds = 2 * 16 * (size_t)((BWD ? 4 : 1) * HP * 2 + 16);
+    const size_t lds = 2 * 16 * (size_t)lds_pitch((BWD ? 4 : 1) * HP * 2);
     const size_t xbytes = (size_t)nclusters * 2 * CS * RPL * (BWD ? 2 : 1) * NT * sizeof(u64);
     (void)hipMemsetAsync(p.xch, 0, xbytes, s);       // tags restart at 1 every launch
     auto kern = BWD ? lstm_bwd_cluster_kernel<HP, UPC, RPL> : lstm_fwd_cluster_kernel<HP, UPC, RPL>;

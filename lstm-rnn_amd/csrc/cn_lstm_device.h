@@ -48,6 +48,15 @@ __device__ __forceinline__ void mma16(f32x4 &acc, const u32x4 &a, const u32x4 &b
     }
 }
 
+// Row pitch of an MFMA A-operand tile in LDS (16 rows read as ds_read_b128 at row*pitch + 16*(lane>>4)).
+// ds_read_b128 is served in groups of 16 lanes ({0-3,12-15,20-27}, ...) that mix rows of two k-quarters,
+// so it is conflict-free exactly when pitch/16 = 2 (mod 4); a pitch of row + 16 B is a 2-way conflict on
+// every read (SQ_LDS_BANK_CONFLICT = 4 cycles per read, measured).
+__host__ __device__ constexpr int lds_pitch(int row_bytes)
+{
+    return row_bytes + 16 * ((2 - (row_bytes / 16) % 4 + 4) % 4);
+}
+
 // workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
 // stay in flight across it (a __syncthreads() would drain vmcnt every step)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
