@@ -141,23 +141,38 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
         __syncthreads();
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane owns
+    // single dwords of 16 different rows, and stored straight from the registers the tile leaves the CU as 64
+    // dword stores per lane (2.3 TB/s of output at best, measured with K = 64).  The tile is transposed through
+    // the operand LDS instead (free after the last k step: 128 rows x 528 B) and written as whole 512-byte rows,
+    // 16 B per lane; bias and activation are applied on the way out, where a thread's four columns are fixed.
+    constexpr int EP = NT_BN * 4 + 16;                 // staging row pitch (bytes)
+    static_assert(NT_BM * EP <= NT_LDS_BYTES, "epilogue staging does not fit the operand buffers");
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + fr;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= p.M) continue;
-                float v = act_apply(p.act, acc[i][j][r] + bv);
-                if (p.C) p.C[(long)m * p.ldc + n] = v;
-                if (p.C2) {
-                    if constexpr (F32) ((float *)p.C2)[(long)m * p.ldc2 + n] = v;
-                    else ((__bf16 *)p.C2)[(long)m * p.ldc2 + n] = (__bf16)v;
+            for (int r = 0; r < 16; ++r)
+                *(float *)(smem + (wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EP + (wn * 64 + j * 32 + fr) * 4) = acc[i][j][r];
+    __syncthreads();
+    const int c4 = tid & 31, n = n0 + c4 * 4;
+    if (n < p.N) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = (tid >> 5) + 8 * k, m = m0 + row;
+            if (m >= p.M) break;
+            f32x4 v = *(const f32x4 *)(smem + row * EP + c4 * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e] + bv[e]);
+            if (p.C) *(f32x4 *)(p.C + (long)m * p.ldc + n) = v;
+            if (p.C2) {
+                if constexpr (F32) *(f32x4 *)((float *)p.C2 + (long)m * p.ldc2 + n) = v;
+                else {
+                    const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    *(bf16x4 *)((__bf16 *)p.C2 + (long)m * p.ldc2 + n) = h;
                 }
             }
         }

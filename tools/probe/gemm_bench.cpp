@@ -1,0 +1,59 @@
+// Times launch_gemm_nt / launch_gemm_tn on the shapes of the headline workload (bf16 operands, random data).
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe/gemm_bench.cpp lstm-rnn_amd/csrc/cn_gemm.o -o tools/probe/gemm_bench
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../lstm-rnn_amd/csrc/cn_internal.h"
+
+using namespace cn;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static void *rnd(size_t n16)   // n16 bf16 values, random small
+{
+    std::vector<unsigned short> h(n16);
+    for (size_t i = 0; i < n16; ++i) { float f = (rand() % 2001 - 1000) / 1000.0f; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+    void *d; CK(hipMalloc(&d, n16 * 2)); CK(hipMemcpy(d, h.data(), n16 * 2, hipMemcpyHostToDevice));
+    return d;
+}
+
+int main()
+{
+    struct S { int M, N, K; const char *what; } nt[] = {
+        {15600, 1024, 256, "input projection layer 2/3 (acts)"}, {15600, 1024, 64, "input projection layer 1"},
+        {15600, 256, 1024, "error to preceding layer (a7)"}, {15600, 192, 256, "softmax projection"}, {15600, 256, 192, "softmax E_prev"}};
+    hipStream_t s; CK(hipStreamCreate(&s));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto &c : nt) {
+        void *A = rnd((size_t)c.M * c.K), *B = rnd((size_t)c.N * c.K);
+        float *C, *bias; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMalloc((void **)&bias, c.N * 4)); CK(hipMemset(bias, 0, c.N * 4));
+        GemmNT g{}; g.A = A; g.lda = c.K; g.B = B; g.ldb = c.K; g.C = C; g.ldc = c.N; g.bias = bias; g.act = ACT_IDENTITY; g.M = c.M; g.N = c.N; g.K = c.K;
+        for (int i = 0; i < 3; ++i) launch_gemm_nt(s, false, g);
+        CK(hipEventRecord(e0, s));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch_gemm_nt(s, false, g);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double us = ms * 1e3 / reps, bytes = (double)c.M * c.N * 4 + (double)c.M * c.K * 2 + (double)c.N * c.K * 2, fl = 2.0 * c.M * c.N * c.K;
+        printf("gemm_nt M=%5d N=%4d K=%4d  %7.1f us  %6.0f GB/s (compulsory bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias));
+    }
+    struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}};
+    for (auto &c : tn) {
+        void *A = rnd((size_t)c.K * c.M), *B = rnd((size_t)c.K * c.N);
+        float *C; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMemset(C, 0, (size_t)c.M * c.N * 4));
+        GemmTN g{}; g.A = A; g.lda = c.M; g.B = B; g.ldb = c.N; g.C = C; g.ldc = c.N; g.M = c.M; g.N = c.N; g.K = c.K;
+        for (int i = 0; i < 3; ++i) launch_gemm_tn(s, false, g);
+        CK(hipEventRecord(e0, s));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch_gemm_tn(s, false, g);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double us = ms * 1e3 / reps, bytes = (double)c.K * (c.M + c.N) * 2, fl = 2.0 * c.M * c.N * c.K;
+        printf("gemm_tn M=%5d N=%4d K=%5d  %7.1f us  %6.0f GB/s (operand bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
+        CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
+    }
+    return 0;
+}
