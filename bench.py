@@ -131,7 +131,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = ge.load_package()
@@ -164,6 +164,8 @@ def main():
             dfr.append({"T": f["T"], "Tmin": f["Tmin"], "numSeqs": f["numSeqs"], "inputPatternSize": P,
                         "outputPatternSize": C, "inputs": x.data_ptr(), "patTypes": pt.data_ptr(),
                         "targetClasses": tc.data_ptr(), "frames": pkg.fraction.real_frames(f)})
+        overlap_allreduce = (world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1") and \
+            os.environ.get("CN_BENCH_FLAT_ALLREDUCE") != "1" and dist.is_initialized()
         wptr, gptr, dptr, count = net.param_arena()
         grads = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device=dev) if world > 1 else None
 
@@ -175,10 +177,14 @@ def main():
                 net.load_sequences_resident(f)
             net.compute_forward_pass()
             net.loss_accumulate()
-            net.compute_backward_pass()
-            if world > 1:
-                net.join()                                  # gradient GEMMs run on the library's side stream
-                dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+            if overlap_allreduce:
+                # per-layer all-reduce issued as the layers finish, beside the backward pass of the layers below
+                net.compute_backward_pass_allreduce(dist, torch)
+            else:
+                net.compute_backward_pass()
+                if world > 1:
+                    net.join()                              # gradient GEMMs run on the library's side stream
+                    dist.all_reduce(grads, op=dist.ReduceOp.SUM)
             net.update_weights_fused(args.lr, args.momentum)
             return f["frames"]
 
@@ -247,6 +253,7 @@ def main():
                        "weights": res["weights"], "update": "stochastic momentum SGD every fraction",
                        "parallelism": "dp%d over sequences" % world},
         }
+        out["check"] = {"error_sum": res["error_sum"], "allreduce": "per-layer, overlapped" if (world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1") and os.environ.get("CN_BENCH_FLAT_ALLREDUCE") != "1" else ("flat" if world > 1 else "none")}
         if "host_frames_per_s" in res:
             out["pcie_inclusive"] = {"value": res["host_frames_per_s"], "unit": "frames/s",
                                      "note": "fractions handed over as pageable host buffers (cn_fraction_load); informational"}

@@ -116,6 +116,10 @@ int  cn_ctx_synchronize(cn_ctx *ctx);                                   /* [sync
  * ANOTHER library (e.g. RCCL through torch.distributed) reads weightUpdates on the ctx stream: it makes the
  * ctx stream wait (device-side, no host sync) for the side stream. */
 int  cn_ctx_join(cn_ctx *ctx);
+/* The same for the weightUpdates of ONE layer: the context's stream waits for that layer's gradient work only.
+ * Lets a data-parallel caller all-reduce the gradient of layer k+1 while layer k is still in its backward
+ * pass (SURVEY.md 8e "Overlap": bucket = layer).  No-op when nothing is pending for the layer.   [async] */
+int  cn_layer_join(cn_layer *layer);
 /* message of the last failed call on this thread (ctx may be NULL for creation failures) */
 const char *cn_last_error(cn_ctx *ctx);
 /* "gfx950" etc. of the bound device; version string of the library */

@@ -522,6 +522,21 @@ int cn_ctx_join(cn_ctx *ctx)
     return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); join_side(ctx); });
 }
 
+int cn_layer_join(cn_layer *layer)
+{
+    if (!layer) { g_last_error = "cn_layer_join: layer is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        for (size_t i = 0; i < c->pending_joins.size(); ++i)
+            if (c->pending_joins[i] == layer->ev_join) {
+                HIP_CHECK(hipStreamWaitEvent(c->stream, layer->ev_join, 0));
+                c->pending_joins.erase(c->pending_joins.begin() + i);
+                break;
+            }
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // layers
 // ---------------------------------------------------------------------------------------------

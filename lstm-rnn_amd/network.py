@@ -66,6 +66,16 @@ class Layer:
     def weight_updates(self):
         return self._read("weightUpdates", self.weight_count)
 
+    def weight_updates_tensor(self, torch):
+        """The layer's weightUpdates in HBM as a torch tensor aliasing the library's memory (no copy)."""
+        if getattr(self, "_wu_tensor", None) is None:
+            from .parallel import DeviceArray
+            ptr = self.net.lib.cn_layer_device_ptr(self.handle, B.BUF["weightUpdates"])
+            if not ptr:
+                raise RuntimeError("layer '%s' has no weightUpdates in device memory" % self.name)
+            self._wu_tensor = torch.as_tensor(DeviceArray(ptr, self.weight_count), device="cuda:%d" % self.net.device)
+        return self._wu_tensor
+
     def internal(self, which, direction=0):
         """LSTM per-direction internal vector by its reference name (LstmLayer.hpp:88-100)."""
         return self._read(which, self.net.N * self.H, direction).reshape(self.net.T, self.net.PS, self.H)
@@ -88,6 +98,7 @@ class NeuralNetwork:
         self.parallel_sequences, self.max_seq_length = int(parallel_sequences), int(max_seq_length)
         self.PS = self.parallel_sequences
         self.precision = precision
+        self.device = int(device)
         ctx = C.c_void_p()
         B.check(self.lib.cn_ctx_create(device, precision, stream, C.byref(ctx)))
         self.ctx = ctx
@@ -228,6 +239,28 @@ class NeuralNetwork:
     def compute_backward_pass(self):                                                   # NeuralNetwork.cpp:175-184
         for lay in reversed(self.layers):
             B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
+
+    def compute_backward_pass_allreduce(self, dist, torch):
+        """Backward pass with the data-parallel gradient exchange folded in (SURVEY.md 8e "Overlap"): once the
+        backward pass of layer k is enqueued, the weightUpdates of layer k+1 (whose gradient GEMMs run on the
+        library's side stream) are all-reduced asynchronously, so the exchange of one layer runs beside the
+        recurrent kernels of the layers below it.  Returns after every reduction has been ordered before the
+        context's stream; follow with update_weights_fused()."""
+        works, pending = [], None
+        def reduce(lay):
+            B.check(self.lib.cn_layer_join(lay.handle), self.ctx)
+            works.append(dist.all_reduce(lay.weight_updates_tensor(torch), op=dist.ReduceOp.SUM, async_op=True))
+        for lay in reversed(self.layers):
+            B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
+            if pending is not None:
+                reduce(pending)
+                pending = None
+            if lay.trainable:
+                pending = lay
+        if pending is not None:
+            reduce(pending)
+        for w in works:
+            w.wait()
 
     def _loss(self):
         err, cor = C.c_float(), C.c_int()

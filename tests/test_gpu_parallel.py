@@ -49,6 +49,26 @@ def test_bench_under_torchrun_one_rank():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["unit"] == "frames/s" and d["scaling"] == "weak"
 
 
+def test_bench_per_layer_allreduce_path_matches_plain_path():
+    """The overlapped per-layer all-reduce path of bench.py (cn_layer_join + async RCCL all-reduce per layer),
+    forced on with one rank where the reduction is the identity: same accumulated error as the plain path."""
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--parallel-sequences", "8",
+            "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+    sums = {}
+    for mode in ("plain", "overlap"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if mode == "overlap":
+            env["CN_BENCH_FORCE_ALLREDUCE"] = "1"
+        out = subprocess.run(base + ["--master-port", str(29650 + os.getpid() % 200 + (mode == "overlap"))] + args,
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        sums[mode] = d["check"]
+    assert sums["overlap"]["allreduce"].startswith("per-layer") and sums["plain"]["allreduce"] == "none"
+    assert abs(sums["overlap"]["error_sum"] - sums["plain"]["error_sum"]) <= 1e-3 * abs(sums["plain"]["error_sum"])
+
+
 def test_rccl_allreduce_on_aliased_arena():
     """RCCL (torch.distributed backend nccl, one rank) all-reduces the aliased weightUpdates arena in place."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
