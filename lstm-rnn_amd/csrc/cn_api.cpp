@@ -55,6 +55,7 @@ struct cn_ctx {
     bool own_stream = false;
     // side stream: weight-gradient GEMMs run beside the next layer's (latency-bound, 26-CU) recurrent kernel
     hipStream_t side = nullptr;
+    hipEvent_t ev_sgd = nullptr;
     std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet
     bool overlap = true;
     bool f32 = true;
@@ -133,6 +134,8 @@ struct cn_layer {
     float *dWin = nullptr, *dWrec = nullptr, *dbias = nullptr, *dpeep = nullptr;
 
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pack = nullptr;         // operand copies rebuilt on the side stream after cn_sgd_update_all
+    bool pack_pending = false;
 
     std::vector<void *> owned;            // device allocations to free
 
@@ -262,8 +265,12 @@ void finalize(cn_ctx *c)
 
 void repack(cn_layer *l)
 {
-    if (!l->dirty) return;
     cn_ctx *c = l->ctx;
+    if (l->pack_pending) {       // rebuilt on the side stream after the last update (cn_sgd_update_all)
+        HIP_CHECK(hipStreamWaitEvent(c->stream, l->ev_pack, 0));
+        l->pack_pending = false;
+    }
+    if (!l->dirty) return;
     Timed tm(c, KC_OTHER);
     if (l->lstm) launch_lstm_pack(c->stream, c->f32, lstm_geom(l), l->bias, l->w, l->Win, l->WinT, l->Wrec, l->WrecT, l->bias_p, l->peep_p);
     else         launch_ff_pack(c->stream, c->f32, ff_geom(l), l->bias, l->w, l->Win, l->WinT, l->bias_p);
@@ -490,10 +497,12 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+        if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
         std::vector<cn_layer *> ls = ctx->layers;
         for (cn_layer *l : ls) {
             for (void *p : l->owned) hipFree(p);
             if (l->ev_fork) { hipEventDestroy(l->ev_fork); hipEventDestroy(l->ev_join); }
+            if (l->ev_pack) hipEventDestroy(l->ev_pack);
             delete l;
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
@@ -722,6 +731,20 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         const size_t PS = ctx->PS, PSp = ctx->PSp;
         const size_t N = (size_t)T * PSp;
         Timed tm(ctx, KC_OTHER);
+        if (resident) {      // everything is in HBM already: one kernel re-lays it out
+            const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
+            if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
+            if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
+            launch_fraction_load(ctx->stream, ctx->f32, T, (int)PS, (int)PSp, f->pat_types, ctx->d_pat,
+                                 cls ? f->target_classes : nullptr, ctx->d_tcls,
+                                 (post_output && !cls) ? f->targets : nullptr, post_output ? post_output->targets : nullptr,
+                                 post_output ? post_output->size : 0, f->inputs, input->size, input->out_op, input->Lp);
+            if (post_output && post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
+                launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
+            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+            ctx->loaded = true;
+            return;
+        }
         // strided copies [T][PS] -> [T][PSp]: pad slots keep their permanent NONE / -1 / 0 contents
         HIP_CHECK(hipMemcpy2DAsync(ctx->d_pat, PSp, f->pat_types, PS, PS, T, kind, ctx->stream));
         const size_t irow = (size_t)input->size * sizeof(float);
@@ -1052,6 +1075,27 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         Timed tm(ctx, KC_OTHER);
         launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum);
         for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
+        // The operand copies of the new weights are rebuilt right away: the first trainable layer's on this stream
+        // (its forward pass is next), the others on the side stream, beside the next fraction's load and the first
+        // layer's forward pass; each layer's forward pass waits for its own copy (repack()).
+        if (ctx->overlap) {
+            if (!ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(ctx->ev_sgd, ctx->stream));
+            HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_sgd, 0));
+            bool first = true;
+            for (cn_layer *l : ctx->layers) {
+                if (!l->trainable) continue;
+                if (first) { first = false; continue; }
+                if (!l->ev_pack) HIP_CHECK(hipEventCreateWithFlags(&l->ev_pack, hipEventDisableTiming));
+                {
+                    Timed tp(ctx, KC_OTHER, ctx->side);
+                    if (l->lstm) launch_lstm_pack(ctx->side, ctx->f32, lstm_geom(l), l->bias, l->w, l->Win, l->WinT, l->Wrec, l->WrecT, l->bias_p, l->peep_p);
+                    else         launch_ff_pack(ctx->side, ctx->f32, ff_geom(l), l->bias, l->w, l->Win, l->WinT, l->bias_p);
+                }
+                HIP_CHECK(hipEventRecord(l->ev_pack, ctx->side));
+                l->dirty = false; l->pack_pending = true;
+            }
+        }
     });
 }
 

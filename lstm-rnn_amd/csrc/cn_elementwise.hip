@@ -202,6 +202,42 @@ void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P,
     else     hipLaunchKernelGGL(pad_convert_kernel<false>, dim3(blocks), dim3(256), 0, s, src, N, P, dst, Pp);
 }
 
+// One launch for a fraction that is already in HBM (cn_fraction_load_resident): patTypes, target classes or
+// target rows and the input patterns go from the caller's [T][PS] layout to the padded [T][PSp] device layout,
+// the inputs converted to the operand type on the way (instead of three strided copies + pad_convert).
+template <bool F32>
+__global__ void fraction_load_kernel(int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
+                                     const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp)
+{
+    const long N = (long)T * PSp;
+    const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nth = (long)gridDim.x * blockDim.x;
+    for (long n = tid; n < N; n += nth) {
+        const long t = n / PSp; const int sl = n % PSp;
+        const bool real = sl < PS;
+        dpat[n] = real ? pat[t * PS + sl] : 0;
+        if (tcls) dtcls[n] = real ? tcls[t * PS + sl] : -1;
+    }
+    if (tgt)
+        for (long idx = tid; idx < N * W; idx += nth) {
+            const long n = idx / W; const int j = idx % W;
+            const long t = n / PSp; const int sl = n % PSp;
+            dtgt[idx] = sl < PS ? tgt[(t * PS + sl) * W + j] : 0.f;
+        }
+    for (long idx = tid; idx < N * Pp; idx += nth) {
+        const long n = idx / Pp; const int c = idx % Pp;
+        const long t = n / PSp; const int sl = n % PSp;
+        st_op<F32>(dst, idx, (sl < PS && c < P) ? in[(t * PS + sl) * P + c] : 0.f);
+    }
+}
+void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
+                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp)
+{
+    long total = (long)T * PSp * Pp; if (total <= 0) return;
+    int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
+    if (f32) hipLaunchKernelGGL(fraction_load_kernel<true>, dim3(blocks), dim3(256), 0, s, T, PS, PSp, pat, dpat, tcls, dtcls, tgt, dtgt, W, in, P, dst, Pp);
+    else     hipLaunchKernelGGL(fraction_load_kernel<false>, dim3(blocks), dim3(256), 0, s, T, PS, PSp, pat, dpat, tcls, dtcls, tgt, dtgt, W, in, P, dst, Pp);
+}
+
 template <bool BF16>
 __global__ void unpad_kernel(const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp)
 {

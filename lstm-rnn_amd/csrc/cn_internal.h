@@ -81,6 +81,8 @@ void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const 
 void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu);
 
 // inputs [N][P] fp32 (reference layout) -> [N][Pp] op, zero padded
+void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
+                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp);
 void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P, void *dst, int Pp);
 // delta = act'(y) * err (in place on err, all N slots: FeedForwardLayer.cu:72-79), op copy for the GEMMs
 void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *err, void *delta_op, int N, int L, int Lp);
