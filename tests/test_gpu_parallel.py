@@ -74,3 +74,37 @@ def test_rccl_allreduce_on_aliased_arena():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_one_rank.py")], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("post", ["multiclass_classification", "sse"])
+def test_resident_fraction_load_matches_host_load(pkg, post):
+    """cn_fraction_load_resident (one re-layout kernel, device pointers) against cn_fraction_load (host buffers):
+    same outputs, error and gradients, with parallel_sequences = 6 padded to 8 on the device."""
+    import torch
+    rng = np.random.RandomState(12)
+    P, C, PS = 5, 4, 6
+    layers = net_desc(P, [("blstm", 12)], C, post=post)
+    weights = random_weights(layers, rng, 0.4)
+    if post == "sse":
+        xs, ts = random_sequences(rng, [9, 7, 4, 6, 9], P, L=C)
+        frac = pkg.make_fraction(xs, ts, PS, classification=False)
+    else:
+        xs, ts = random_sequences(rng, [9, 7, 4, 6, 9], P, C=C)
+        frac = pkg.make_fraction(xs, ts, PS)
+    res = {}
+    for mode in ("host", "resident"):
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_F32) as net:
+            if mode == "host":
+                net.load_sequences(frac)
+            else:
+                keep = {k: torch.from_numpy(np.ascontiguousarray(frac[k])).cuda() for k in ("inputs", "patTypes", "targetClasses", "targets") if k in frac}
+                d = {"T": frac["T"], "Tmin": frac["Tmin"], "numSeqs": frac["numSeqs"], "inputPatternSize": P, "outputPatternSize": C}
+                d.update({k: v.data_ptr() for k, v in keep.items()})
+                net.load_sequences_resident(d)
+            net.compute_forward_pass()
+            e, c = net.error_and_correct()
+            net.compute_backward_pass()
+            res[mode] = (net.outputs().copy(), e, c, [l.weight_updates() for l in net.trainable_layers()])
+    assert np.array_equal(res["host"][0], res["resident"][0]) and res["host"][1] == res["resident"][1] and res["host"][2] == res["resident"][2]
+    for a, b in zip(res["host"][3], res["resident"][3]):
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
