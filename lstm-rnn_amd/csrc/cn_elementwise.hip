@@ -370,6 +370,43 @@ __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int 
         return;
     }
     float *r = y + row * Lp;
+    if (L <= 256) {
+        // the whole row in registers: one read and one write of the posteriors (same arithmetic and order)
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; v[k] = j < L ? r[j] : 0.f; }
+        const int tc = rowstat ? tcls[row] : -1;
+        float mx = NL_MIN, mn = NL_MAX;                  // :61-62 (max starts at FLT_MIN, quirk Q3)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (lane + 64 * k < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
+        mx = wave_max(mx); mn = wave_min(mn);
+        const float offset = 0.5f * (mn + mx);           // :74
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (lane + 64 * k < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
+        sum = wave_sum(sum);
+        float best = 0.f, ptv = 0.f; int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = lane + 64 * k;
+            if (j < L) {
+                const float w = v[k] / sum; r[j] = w;    // :152
+                if (w > best) { best = w; bi = j; }
+                if (j == tc) ptv = w;
+            }
+        }
+        if (rowstat) {
+            ptv = wave_sum(ptv);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (best <= 0.f) bi = 0;
+            if (lane == 0) rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
+        }
+        return;
+    }
     float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
     for (int j = lane; j < L; j += 64) { float v = r[j]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
     mx = wave_max(mx); mn = wave_min(mn);
@@ -450,24 +487,48 @@ template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                                        float *err, void *delta_op, float *colsum)
 {
+    // One row is a chain of dependent loads (target class -> its posterior -> the row), so a wave works on RB
+    // rows at a time to keep RB chains in flight.  The column sums end in one atomic per column and WORKGROUP:
+    // they are same-address atomics, so the grid stays at one workgroup per CU (2048 workgroups: 50 us).
+    constexpr int RB = 4;
     __shared__ float part[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
-        const int tc = tcls[row];
-        const bool real = pat[row] != 0;
-        const float *yr = y + row * Lp;
-        float et = 0.f, off = 0.f;
-        if (real && tc >= 0) { const float pt_ = yr[tc]; et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
+    for (long row0 = ((long)blockIdx.x * 4 + wv) * RB; row0 < N; row0 += (long)gridDim.x * 4 * RB) {
+        int tc[RB]; bool real[RB]; float et[RB], off[RB], pt_[RB];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = lane + 64 * k;
-            if (j >= Lp) break;
-            float dl = 0.f;
-            if (real && j < L) dl = yr[j] * ((j == tc ? et : 0.f) - off);
-            err[row * Lp + j] = dl;
-            if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
-            cs[k] += dl;
+        for (int b = 0; b < RB; ++b) {
+            const long row = row0 + b < N ? row0 + b : N - 1;
+            tc[b] = tcls[row]; real[b] = pat[row] != 0 && row0 + b < N;
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const long row = row0 + b < N ? row0 + b : N - 1;
+            pt_[b] = y[row * Lp + (tc[b] >= 0 ? tc[b] : 0)];
+        }
+        float yv[RB][4];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const long row = row0 + b < N ? row0 + b : N - 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; yv[b][k] = j < Lp ? y[row * Lp + j] : 0.f; }
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            et[b] = 0.f; off[b] = 0.f;
+            if (real[b] && tc[b] >= 0) { et[b] = -(1.0f / fmaxf(NL_MIN, pt_[b])); off[b] = pt_[b] * et[b]; }
+            if (row0 + b >= N) continue;
+            const long row = row0 + b;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = lane + 64 * k;
+                if (j >= Lp) break;
+                float dl = 0.f;
+                if (real[b] && j < L) dl = yv[b][k] * ((j == tc[b] ? et[b] : 0.f) - off[b]);
+                err[row * Lp + j] = dl;
+                if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
+                cs[k] += dl;
+            }
         }
     }
 #pragma unroll
@@ -479,7 +540,7 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
                             float *err, void *delta_op, float *colsum)
 {
     if (N <= 0) return;
-    int blocks = (N + 3) / 4; if (blocks > 512) blocks = 512;
+    int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
     if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
     else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
 }
