@@ -77,6 +77,15 @@ struct cn_ctx {
     float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
     cn_layer *rowstat_of = nullptr;
 
+    // host fractions (cn_fraction_load): packed into pinned memory, uploaded on a copy stream into one of two
+    // device staging areas while the previous fraction still computes, re-laid out by fraction_load_kernel
+    hipStream_t copy = nullptr;
+    char *h_stage[2] = {nullptr, nullptr}, *d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};
+    unsigned upload_idx = 0;
+
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
     float *arena = nullptr;
@@ -498,6 +507,12 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipStreamSynchronize(ctx->stream);
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
+        if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
+            if (ctx->d_stage[i]) hipFree(ctx->d_stage[i]);
+            if (ctx->ev_up[i]) { hipEventDestroy(ctx->ev_up[i]); hipEventDestroy(ctx->ev_free[i]); }
+        }
         std::vector<cn_layer *> ls = ctx->layers;
         for (cn_layer *l : ls) {
             for (void *p : l->owned) hipFree(p);
@@ -745,7 +760,61 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             ctx->loaded = true;
             return;
         }
-        // strided copies [T][PS] -> [T][PSp]: pad slots keep their permanent NONE / -1 / 0 contents
+        if (ctx->overlap) {
+            // Host buffers: pack [patTypes | classes or targets | inputs] into pinned memory, ONE contiguous upload
+            // on the copy stream (it runs while the previous fraction still computes: the staging areas alternate),
+            // then the same re-layout kernel as the resident path.  (Strided 2-D copies from pageable memory cost
+            // one transfer per time step: 3.5 ms per fraction of 2.3 MB, twice the whole training step.)
+            const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
+            if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
+            if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
+            const size_t rows = (size_t)T * PS;
+            const size_t W = post_output ? (size_t)post_output->size : 0;
+            const size_t b_pat = (rows + 15) & ~(size_t)15;
+            const size_t b_tgt = !post_output ? 0 : (cls ? rows * sizeof(int) : rows * W * sizeof(float));
+            const size_t b_tgt_al = (b_tgt + 15) & ~(size_t)15;
+            const size_t b_in = rows * (size_t)input->size * sizeof(float);
+            const size_t need = b_pat + b_tgt_al + b_in;
+            if (need > ctx->stage_bytes || !ctx->h_stage[0]) {
+                HIP_CHECK(hipDeviceSynchronize());
+                for (int i = 0; i < 2; ++i) {
+                    if (ctx->h_stage[i]) HIP_CHECK(hipHostFree(ctx->h_stage[i]));
+                    if (ctx->d_stage[i]) HIP_CHECK(hipFree(ctx->d_stage[i]));
+                    ctx->stage_used[i] = false;
+                }
+                const size_t maxrows = (size_t)ctx->maxT * PS;
+                size_t cap = ((maxrows + 15) & ~(size_t)15) + ((maxrows * std::max(W * sizeof(float), sizeof(int)) + 15) & ~(size_t)15) + maxrows * (size_t)input->size * sizeof(float);
+                if (cap < need) cap = need;
+                for (int i = 0; i < 2; ++i) {
+                    HIP_CHECK(hipHostMalloc((void **)&ctx->h_stage[i], cap, hipHostMallocDefault));
+                    HIP_CHECK(hipMalloc((void **)&ctx->d_stage[i], cap));
+                    if (!ctx->ev_up[i]) { HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
+                }
+                if (!ctx->copy) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+                ctx->stage_bytes = cap;
+            }
+            const int slot = (int)(ctx->upload_idx++ & 1u);
+            if (ctx->stage_used[slot]) HIP_CHECK(hipEventSynchronize(ctx->ev_free[slot]));    // the re-layout kernel two fractions ago has read it
+            char *h = ctx->h_stage[slot], *dv = ctx->d_stage[slot];
+            memcpy(h, f->pat_types, rows);
+            if (post_output) memcpy(h + b_pat, cls ? (const void *)f->target_classes : (const void *)f->targets, b_tgt);
+            memcpy(h + b_pat + b_tgt_al, f->inputs, b_in);
+            HIP_CHECK(hipMemcpyAsync(dv, h, need, hipMemcpyHostToDevice, ctx->copy));
+            HIP_CHECK(hipEventRecord(ctx->ev_up[slot], ctx->copy));
+            HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_up[slot], 0));
+            launch_fraction_load(ctx->stream, ctx->f32, T, (int)PS, (int)PSp, dv, ctx->d_pat,
+                                 cls ? (const int *)(dv + b_pat) : nullptr, ctx->d_tcls,
+                                 (post_output && !cls) ? (const float *)(dv + b_pat) : nullptr, post_output ? post_output->targets : nullptr,
+                                 (int)W, (const float *)(dv + b_pat + b_tgt_al), input->size, input->out_op, input->Lp);
+            HIP_CHECK(hipEventRecord(ctx->ev_free[slot], ctx->stream));
+            ctx->stage_used[slot] = true;
+            if (post_output && post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
+                launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
+            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+            ctx->loaded = true;
+            return;
+        }
+        // CN_NO_OVERLAP: strided copies [T][PS] -> [T][PSp]: pad slots keep their permanent NONE / -1 / 0 contents
         HIP_CHECK(hipMemcpy2DAsync(ctx->d_pat, PSp, f->pat_types, PS, PS, T, kind, ctx->stream));
         const size_t irow = (size_t)input->size * sizeof(float);
         HIP_CHECK(hipMemcpy2DAsync(input->stage_in, PSp * irow, f->inputs, PS * irow, PS * irow, T, kind, ctx->stream));
@@ -983,7 +1052,8 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
         const int R = layer->dirs * 4 * layer->Hp, Hp = layer->Hp, H = layer->H;
         switch (which) {
         case CN_BUF_OUTPUTS:
-            if (layer->kind == CN_LAYER_INPUT) launch_unpad(c->stream, false, layer->stage_in, layer->size, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
+            if (layer->kind == CN_LAYER_INPUT)        // the operand copy of the inputs (bf16 mode: rounded to bf16)
+                launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else if (layer->lstm)
                 for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
             else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
