@@ -673,10 +673,10 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             if (!preceding->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: a post output layer needs a trainable preceding layer");
             if (preceding->lstm) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: post output layers directly after an LSTM layer are not supported");
             const bool paired = kind == CN_LAYER_WEIGHTEDSSE || kind == CN_LAYER_SSE_MASK;
-            // PostOutputLayer.cpp:58-59; the weighted layers take (target, weight) pairs: PostOutputLayer.cpp:52-56
+            // PostOutputLayer.cpp:58-59; the weighted layers take (target, weight) pairs: WeightedSsePostOutputLayer.cu:103, SseMaskPostOutputLayer.cu:103
             if (paired ? size != 2 * preceding->size : size != preceding->size)
                 throw cn_error(CN_ERR_SHAPE, "Size mismatch: " + std::to_string(size) + " vs. " + std::to_string(preceding->size));
-            if (kind == CN_LAYER_BINARY_CLASSIFICATION && size != 1)                                      // BinaryClassificationLayer.cu:139-140
+            if (kind == CN_LAYER_BINARY_CLASSIFICATION && size != 1)                                      // BinaryClassificationLayer.cu:123-124
                 throw cn_error(CN_ERR_SHAPE, "The binary classification post output layer cannot be used for an output layer size != 1");
             if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && size == 1)                                  // MulticlassClassificationLayer.cu:146-147
                 throw cn_error(CN_ERR_SHAPE, "The multiclass classification post output layer cannot be used for an output layer size of 1");

@@ -610,9 +610,9 @@ void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, 
 // post output layers other than multiclass_classification (sse: SsePostOutputLayer.cu:39-88; the rest is
 // SURVEY section 8 row f4).  L = size of the output layer, y pitch Lp;
 // targets hold L values per pattern, or 2L interleaved (target, weight | filter input) pairs.
-//   weightedsse  WeightedSsePostOutputLayer.cu:44-88     wf   SseMaskPostOutputLayer.cu:44-88
-//   ce           CePostOutputLayer.cu:44-96              rmse RmsePostOutputLayer.cu:44-93
-//   binary_classification  BinaryClassificationLayer.cu:48-113
+//   weightedsse  WeightedSsePostOutputLayer.cu:40-93, :119-167    wf   SseMaskPostOutputLayer.cu:40-93, :119-167
+//   ce           CePostOutputLayer.cu:43-99, :125-168    rmse RmsePostOutputLayer.cu:40-97, :125-172
+//   binary_classification  BinaryClassificationLayer.cu:44-111, :132-207
 // One wave per pattern; the per-pattern term lands in rowstat[N] = {term, correct} and is summed
 // in a fixed order by rowstat_reduce_kernel (reproducible, no float atomics).
 // ---------------------------------------------------------------------------------------------
@@ -694,7 +694,7 @@ void launch_post_backward(hipStream_t s, int kind, const float *y, const float *
     POST_DISPATCH(post_backward_kernel, y, tgt, pat, N, L, Lp, err)
 }
 
-// BinaryClassificationLayer.cu:146-154: the targets are the target classes copied as floats
+// BinaryClassificationLayer.cu:157-164: the targets are the target classes copied as floats
 __global__ void classes_to_targets_kernel(const int *tcls, float *tgt, int N)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -750,11 +750,11 @@ enum { POST_SSE = 0, POST_WEIGHTEDSSE = 1, POST_SSE_MASK = 2, POST_CE = 3, POST_
 /*
  * calculateError() of the remaining post output layers.  L = size of the OUTPUT layer; targets hold
  * L values per pattern, or 2L interleaved (target, weight|filter input) pairs for weightedsse / wf.
- *   weightedsse : WeightedSsePostOutputLayer.cu:44-62, :108-127   0.5 * sum ((y - t) * w)^2
- *   wf/sse_mask : SseMaskPostOutputLayer.cu:44-62, :108-127       0.5 * sum (y * f - t)^2
- *   ce          : CePostOutputLayer.cu:44-71, :118-136            sum t * log(max(min,t) / max(min,y))
- *   rmse        : RmsePostOutputLayer.cu:44-70, :112-121          sum_rows sqrt(sum_j (y-t)^2 / L)
- *   binary      : BinaryClassificationLayer.cu:48-67, :157-173    sum -log(t > 0 ? act : 1 - act)
+ *   weightedsse : WeightedSsePostOutputLayer.cu:40-64, :119-139   0.5 * sum ((y - t) * w)^2
+ *   wf/sse_mask : SseMaskPostOutputLayer.cu:40-64, :119-139       0.5 * sum (y * f - t)^2
+ *   ce          : CePostOutputLayer.cu:43-71, :125-143            sum t * log(max(min,t) / max(min,y))
+ *   rmse        : RmsePostOutputLayer.cu:40-71, :125-152          sum_rows sqrt(sum_j (y-t)^2 / L)
+ *   binary      : BinaryClassificationLayer.cu:44-67, :166-183    sum -log(t > 0 ? act : 1 - act)
  */
 real_t orc_post_error(int kind, int L, int N, const char *patTypes, const real_t *targets, const real_t *outputs)
 {
@@ -795,7 +795,7 @@ real_t orc_post_error(int kind, int L, int N, const char *patTypes, const real_t
     return s;
 }
 
-/* BinaryClassificationLayer<Cpu>::countCorrectClassifications, .cu:71-88,118-133 */
+/* BinaryClassificationLayer<Cpu>::countCorrectClassifications, .cu:69-85, :132-154 */
 int orc_binary_correct(int N, const char *patTypes, const real_t *targets, const real_t *outputs)
 {
     int c = 0;
@@ -808,7 +808,8 @@ int orc_binary_correct(int N, const char *patTypes, const real_t *targets, const
 
 /*
  * computeBackwardPass() of the same layers (error written into the output layer's outputErrors):
- *   weightedsse .cu:64-88   wf .cu:64-88   ce .cu:73-96 (clipped to +-100)   rmse .cu:72-93 (rmse * (y - t))
+ *   weightedsse .cu:66-93, :146-167   wf .cu:66-93, :146-167   ce .cu:73-99, :150-170 (clipped to +-100)
+ *   rmse .cu:73-97, :154-174 (rmse * (y - t))   binary .cu:87-111, :190-207
  *   binary .cu:90-113 (dummy slots are left untouched by the reference; 0 here)
  */
 void orc_post_backward(int kind, int L, int N, const char *patTypes, const real_t *targets,

@@ -157,7 +157,7 @@ class OracleNetwork:
         post = self.layers[-1]
         if post.type == "multiclass_classification":
             self.targetClasses = np.ascontiguousarray(frac["targetClasses"], np.int32)
-        elif post.type == "binary_classification":      # BinaryClassificationLayer.cu:146-154
+        elif post.type == "binary_classification":      # BinaryClassificationLayer.cu:157-164
             self.targets = np.ascontiguousarray(frac["targetClasses"], np.float32).reshape(-1)
         else:
             self.targets = np.ascontiguousarray(frac["targets"], np.float32).reshape(-1)

@@ -110,8 +110,8 @@ def _post_loss64(kind, y, t, L):
 def test_post_output_layers_against_fp64_autograd(orc):
     """orc_post_error / orc_post_backward against an fp64 autograd statement of the same losses.  Two
     layers are documented exceptions where the reference does not inject the derivative of its error:
-    rmse injects rmse * (y - t) (RmsePostOutputLayer.cu:72-93) and weightedsse injects (y - t) * w, one
-    factor w short of the derivative (WeightedSsePostOutputLayer.cu:66-91)."""
+    rmse injects rmse * (y - t) (RmsePostOutputLayer.cu:73-97) and weightedsse injects (y - t) * w, one
+    factor w short of the derivative (WeightedSsePostOutputLayer.cu:66-93)."""
     import ctypes  # noqa: F401
     rng = np.random.RandomState(4)
     N, L = 23, 5
@@ -151,7 +151,7 @@ def test_post_output_layers_against_fp64_autograd(orc):
             loss.backward()
             want = y64.grad.numpy()
         assert np.abs(err[real] - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), kind
-    # ce clips the injected error to +-100 (CePostOutputLayer.cu:90)
+    # ce clips the injected error to +-100 (CePostOutputLayer.cu:95)
     y = np.full((1, 2), 1e-6, np.float32); t = np.array([[1.0, 0.0]], np.float32)
     err = np.zeros(2, np.float32)
     lib.orc_post_backward(orc.POST["ce"], 2, 1, np.ones(1, np.int8), t.reshape(-1), y.reshape(-1), err)
