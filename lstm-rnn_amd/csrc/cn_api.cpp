@@ -55,6 +55,10 @@ struct cn_ctx {
     bool own_stream = false;
     // side stream: weight-gradient GEMMs run beside the next layer's (latency-bound, 26-CU) recurrent kernel
     hipStream_t side = nullptr;
+    // CU-masked twin of the side stream: gradient GEMMs that run beside a recurrent kernel have its whole duration
+    // to finish, and at full speed their memory traffic stalls the latency-bound recurrent kernel (291 vs 229 us
+    // per backward launch); on a subset of the CUs they run longer but draw less bandwidth
+    hipStream_t side_slow = nullptr;
     hipEvent_t ev_sgd = nullptr;
     std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet
     bool overlap = true;
@@ -194,15 +198,18 @@ template <typename F> void on_side(cn_layer *l, F &&f)
     if (!c->overlap) { f(c->stream); return; }
     if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
     HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
-    HIP_CHECK(hipStreamWaitEvent(c->side, l->ev_fork, 0));
-    f(c->side);
-    HIP_CHECK(hipEventRecord(l->ev_join, c->side));
+    // a recurrent kernel follows on the main stream when the preceding layer is an LSTM layer: slow lane
+    hipStream_t st = (c->side_slow && l->prev && l->prev->lstm) ? c->side_slow : c->side;
+    HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
+    f(st);
+    HIP_CHECK(hipEventRecord(l->ev_join, st));
     c->pending_joins.push_back(l->ev_join);
 }
 void timing_collect(cn_ctx *c)
 {
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->side) HIP_CHECK(hipStreamSynchronize(c->side));
+    if (c->side_slow) HIP_CHECK(hipStreamSynchronize(c->side_slow));
     for (int k = 0; k < KC_COUNT; ++k) {
         for (auto &sp : c->spans[k]) {
             float ms = 0.f;
@@ -486,6 +493,17 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        {
+            int ncu = 0;
+            if (const char *e = getenv("CN_SIDE_CUS")) ncu = atoi(e);
+            if (ncu > 0 && ncu < prop.multiProcessorCount) {
+                const int total = prop.multiProcessorCount;
+                std::vector<uint32_t> mask((total + 31) / 32, 0u);
+                for (int i = 0; i < total; ++i)
+                    if ((long)(i + 1) * ncu / total != (long)i * ncu / total) mask[i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&c->side_slow, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); c->side_slow = nullptr; }
+            }
+        }
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
@@ -506,6 +524,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+        if (ctx->side_slow) { hipStreamSynchronize(ctx->side_slow); hipStreamDestroy(ctx->side_slow); }
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
         if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }
         for (int i = 0; i < 2; ++i) {

@@ -428,12 +428,25 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         unsigned char dmy[RPL];                      // dummy-slot flags of this step (LDS table, see the forward kernel)
 #pragma unroll
         for (int r = 0; r < RPL; ++r) dmy[r] = dtab[t * (4 * RPL) + 4 * r + q];
+        // The stage moves to registers of its own through early-clobber asm copies (as in the forward kernel), so
+        // the prefetch below lands in the stage registers again.  Left to the register coalescer the loads went
+        // elsewhere and were copied back at the loop latch behind `s_waitcnt vmcnt(3)`, i.e. every second step
+        // waited for loads issued half a step earlier: free when they hit the Infinity Cache (the top layer,
+        // 217 us per launch), ~300 cycles from HBM (252 us), more beside the gradient GEMMs (291 us).
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[u][r] = (r < RPL) ? pre.e[u][r < RPL ? r : 0] : 0.f;     // err enters as the MFMA C operand
+            for (int r = 0; r < RPL; ++r) {
+                float e_, c_;
+                asm volatile("v_mov_b32 %0, %1" : "=&v"(e_) : "v"(pre.e[u][r]));
+                asm volatile("v_mov_b32 %0, %1" : "=&v"(c_) : "v"(pre.cp[u][r]));
 #pragma unroll
-            for (int r = 0; r < RPL; ++r) { cp_[u][r] = hasprev_ ? pre.cp[u][r] : 0.f; a_[u][r] = pre.a[u][r]; }
+                for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(a_[u][r][g]) : "v"(pre.a[u][r][g]));
+                acc[u][r] = e_;                                                             // err enters as the MFMA C operand
+                cp_[u][r] = hasprev_ ? c_ : 0.f;
+            }
+#pragma unroll
+            for (int r = RPL; r < 4; ++r) acc[u][r] = 0.f;
         }
         prefetch(d ? t + 2 : t - 2, pre);
         STAMP(0)
@@ -576,7 +589,13 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds, s, p);
+    // When the grid leaves CUs free (one workgroup per CU at most), each workgroup claims the CU's whole LDS so that
+    // no workgroup of a concurrently running kernel (the gradient GEMMs of the side stream) can be placed beside
+    // it: sharing its SIMDs' issue slots with GEMM waves cost the latency-bound recurrent kernel 27 % (291 vs
+    // 229 us per backward launch in the step timeline); the GEMMs lose 26 of 256 CUs instead.
+    size_t lds_claim = lds;
+    if (p.dirs * nsg <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    hipLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, p);
 }
 
 template <bool F32, bool BWD, int HP, int UG>
