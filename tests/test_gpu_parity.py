@@ -279,3 +279,28 @@ def test_cluster_kernel_matches_streaming_kernel(pkg, orc):
     assert np.abs(y1 - ref.outputs()).max() < 3e-2
     for a, lay in zip(g1, ref.trainable_layers()):
         assert rel_err(a, lay.weightUpdates) < 6e-2, lay.name
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 6])
+@pytest.mark.parametrize("PS", [3, 520, 1100])
+def test_short_sequences_and_sequences_per_lane(pkg, orc, T, PS):
+    """Loop structure of the recurrent kernels (peeled first pair, branch-free pairs, odd last step) for
+    T = 1, 2, 3, 6 and the three sequences-per-lane shapes: PS = 3 -> 1, 520 -> 2, 1100 -> 4 sequences per lane
+    (chosen so that the workgroups still fit the chip).  Every second sequence is one frame shorter."""
+    rng = np.random.RandomState(100 + T + PS)
+    P, C = 4, 3
+    layers = net_desc(P, [("blstm", 20)], C)
+    weights = random_weights(layers, rng, 0.5)
+    lengths = [max(1, T - (i % 2)) for i in range(PS)]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS)
+    with net:
+        real = real_mask(frac)
+        y = net.outputs().reshape(-1, C)[real]
+        yr = ref.outputs().reshape(-1, C)[real]
+        assert np.abs(y - yr).max() < POSTERIOR_TOL
+        assert abs(e - e_ref) <= 1e-4 * max(1.0, abs(e_ref)) and c == c_ref
+        for lay in net.trainable_layers():
+            g, gr = lay.weight_updates(), ref.layer(lay.name).weightUpdates
+            assert rel_err(g, gr) < 2e-4, (lay.name, rel_err(g, gr))
