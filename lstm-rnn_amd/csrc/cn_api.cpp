@@ -367,10 +367,11 @@ void lstm_backward(cn_layer *l)
     on_side(l, [&](hipStream_t st) {
         {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
             Timed tm(c, KC_GEMM_GRAD, st);
+            GemmTN gs[3]; int ng = 0;
             GemmTN g{};
             g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
-            launch_gemm_tn(st, c->f32, g);
+            gs[ng++] = g;
             // K9 recurrent weights: dWrec[(j,g)][i] = sum_t delta[t][(j,g)] y[prev(t)][i]
             if (N > PS) {
                 for (int d = 0; d < l->dirs; ++d) {
@@ -381,9 +382,10 @@ void lstm_backward(cn_layer *l)
                     else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
                     r.lda = R; r.ldb = l->Lp;
                     r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
-                    launch_gemm_tn(st, c->f32, r);
+                    gs[ng++] = r;
                 }
             }
+            launch_gemm_tn_group(st, c->f32, gs, ng);      // the three products side by side in one launch
         }
         {
             Timed tm(c, KC_OTHER, st);

@@ -209,17 +209,33 @@ template <bool F32, int BT> struct TnGeom {
     static constexpr int WT = BT / 64;                     // 32x32 MFMA tiles per wave and dimension
 };
 
+// Up to TN_GROUP independent products in one launch (the three weight-gradient products of an LSTM layer): each
+// of them alone is bound by the latency of its short per-workgroup K loops and by its split-K atomics, not by
+// bandwidth, so side by side they take about as long as the largest one.
+constexpr int TN_GROUP = 3;
+struct GemmTNGroup {
+    GemmTN p[TN_GROUP];
+    int tiles_n[TN_GROUP], ntiles[TN_GROUP], kchunk[TN_GROUP], first_block[TN_GROUP + 1];
+};
+
 template <bool F32, int BT>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int ntiles, int kchunk)
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = TnGeom<F32, BT>;
     constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD, WT = G::WT;
     constexpr int CH = 16 / ELT;
 
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP; ++i) if ((int)blockIdx.x >= grp.first_block[i]) gi = i;
+    const GemmTN &p = grp.p[gi];
+    const int tiles_n = grp.tiles_n[gi], ntiles = grp.ntiles[gi], kchunk = grp.kchunk[gi];
+    const int bid = blockIdx.x - grp.first_block[gi];
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const int tile = bid % ntiles, split = bid / ntiles;
     const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
@@ -333,20 +349,31 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTN p, int tiles_n, int
 }
 
 template <bool F32, int BT>
-static void launch_tn(hipStream_t s, const GemmTN &g)
+static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
-    const int tiles_m = (g.M + BT - 1) / BT, tiles_n = (g.N + BT - 1) / BT, ntiles = tiles_m * tiles_n;
-    // K splits: enough workgroups (~4 per CU) to hide the latency of the short per-workgroup K loops, but every
-    // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
-    // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
-    long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
-    int splits = (1024 + ntiles - 1) / ntiles;
-    int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
-    if (splits > maxsplit) splits = maxsplit;
-    if (splits > cap_atomic) splits = (int)cap_atomic;
-    if (splits < 1) splits = 1;
-    int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
-    splits = (g.K + kchunk - 1) / kchunk;
+    GemmTNGroup grp{};
+    int blocks = 0;
+    for (int i = 0; i < TN_GROUP; ++i) {
+        grp.first_block[i] = blocks;
+        if (i >= n) { grp.first_block[i] = 0x7fffffff; continue; }
+        const GemmTN &g = gs[i];
+        const int tiles_m = (g.M + BT - 1) / BT, tiles_n = (g.N + BT - 1) / BT, ntiles = tiles_m * tiles_n;
+        // K splits: enough workgroups (~4 per CU) to hide the latency of the short per-workgroup K loops, but every
+        // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
+        // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
+        long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
+        int splits = (1024 + ntiles - 1) / ntiles;
+        int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
+        if (splits > maxsplit) splits = maxsplit;
+        if (splits > cap_atomic) splits = (int)cap_atomic;
+        if (splits < 1) splits = 1;
+        int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
+        splits = (g.K + kchunk - 1) / kchunk;
+        grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk;
+        blocks += ntiles * splits;
+    }
+    grp.first_block[TN_GROUP] = blocks;
+    if (blocks == 0) return;
     auto kern = gemm_tn_kernel<F32, BT>;
     constexpr int lds = TnGeom<F32, BT>::LDS;
     static bool attr_set = false;
@@ -354,17 +381,32 @@ static void launch_tn(hipStream_t s, const GemmTN &g)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(ntiles * splits), dim3(256), lds, s, g, tiles_n, ntiles, kchunk);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, grp);
+}
+
+static bool tn_big_tiles(const GemmTN &g)
+{
+    // weight matrices of this workload are small (<= 1024 x 256): 64 x 64 tiles give the grid enough workgroups
+    // without deep K splits; 128 x 128 tiles take over once the output alone fills the chip
+    return (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 2048;
 }
 
 void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
 {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    // weight matrices of this workload are small (<= 1024 x 256): 64 x 64 tiles give the grid enough workgroups
-    // without deep K splits; 128 x 128 tiles take over once the output alone fills the chip
-    const long tiles64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-    if (tiles64 >= 2048) { if (f32) launch_tn<true, 128>(s, g); else launch_tn<false, 128>(s, g); }
-    else                 { if (f32) launch_tn<true, 64>(s, g);  else launch_tn<false, 64>(s, g); }
+    if (tn_big_tiles(g)) { if (f32) launch_tn<true, 128>(s, &g, 1); else launch_tn<false, 128>(s, &g, 1); }
+    else                 { if (f32) launch_tn<true, 64>(s, &g, 1);  else launch_tn<false, 64>(s, &g, 1); }
+}
+
+void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n)
+{
+    GemmTN small[TN_GROUP]; int ns = 0;
+    for (int i = 0; i < n; ++i) {
+        if (gs[i].M <= 0 || gs[i].N <= 0 || gs[i].K <= 0) continue;
+        if (tn_big_tiles(gs[i]) || ns == TN_GROUP) launch_gemm_tn(s, f32, gs[i]);      // (not grouped)
+        else small[ns++] = gs[i];
+    }
+    if (ns) { if (f32) launch_tn<true, 64>(s, small, ns); else launch_tn<false, 64>(s, small, ns); }
 }
 
 }  // namespace cn

@@ -37,6 +37,7 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
 };
 void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g);
 void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g);
+void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n);      // up to 3 small products in one launch
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------
 struct LstmRec {
