@@ -615,10 +615,11 @@ static void launch_rec(hipStream_t s, const LstmRec &p)
     case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4); return;
     case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6); return;
     case 128:
-        // backward, bf16: every wave reads the whole 16 x 4Hp delta tile from LDS each step, so 8 waves move
-        // 128 KB per step through the 256 B/clk LDS port (as long as the MFMAs themselves); 4 waves owning two
-        // unit groups each halve that traffic at the same MFMA and VALU work per SIMD
-        if (BWD && !F32 && !getenv("CN_BWD_UG1")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);
+        // 8 waves x 1 unit group (two waves per SIMD overlap each other's MFMA, VALU and scalar issue).  For the
+        // backward kernel 4 waves x 2 unit groups (half the LDS operand reads: every wave reads the whole
+        // 16 x 4Hp delta tile) used to win by 4 %; since the stage copies removed the latch stall it loses:
+        // 0.64 vs 0.56 us per step (CN_BWD_UG2 keeps it selectable)
+        if (BWD && !F32 && getenv("CN_BWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);
         else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);   // measured slower: 0.63 vs 0.47 us per step
         else launch_rpl<F32, BWD, 128, 1>(s, p, 8);
         return;
