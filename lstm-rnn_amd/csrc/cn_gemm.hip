@@ -353,6 +353,8 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
     GemmTNGroup grp{};
     int blocks = 0;
+    long all_tiles = 0;
+    for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + BT - 1) / BT) * ((gs[i].N + BT - 1) / BT);
     for (int i = 0; i < TN_GROUP; ++i) {
         grp.first_block[i] = blocks;
         if (i >= n) { grp.first_block[i] = 0x7fffffff; continue; }
@@ -361,8 +363,9 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         // K splits: enough workgroups (~4 per CU) to hide the latency of the short per-workgroup K loops, but every
         // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
         // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
+        // (a group shares the ~1024 workgroups: its products run side by side, and their atomics add up)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
-        int splits = (1024 + ntiles - 1) / ntiles;
+        int splits = (int)((1024 + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
         if (splits > maxsplit) splits = maxsplit;
         if (splits > cap_atomic) splits = (int)cap_atomic;
