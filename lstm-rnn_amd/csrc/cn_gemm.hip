@@ -16,6 +16,8 @@
 // Operand type: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32).
 #include "cn_internal.h"
 
+#include <cstdlib>
+
 namespace cn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -365,7 +367,8 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
         // (a group shares the ~1024 workgroups: its products run side by side, and their atomics add up)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
-        int splits = (int)((1024 + all_tiles - 1) / all_tiles);
+        static const int target = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 1024;
+        int splits = (int)((target + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
         if (splits > maxsplit) splits = maxsplit;
         if (splits > cap_atomic) splits = (int)cap_atomic;
