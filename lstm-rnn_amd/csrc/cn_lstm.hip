@@ -505,7 +505,9 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 float dfg = fg * (1.0f - fg) * cp * ec;                                     // cp = 0 at lastCall
                 float dig = ig * (1.0f - ig) * ni * ec;
                 dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
-                if (dummy) { dni = dig = dfg = dog = 0.f; ec = 0.f; }                      // :224-234
+                // :224-234, as selects: a branch here splits the step into basic blocks and fences the scheduler in
+                dni = dummy ? 0.f : dni; dig = dummy ? 0.f : dig; dfg = dummy ? 0.f : dfg; dog = dummy ? 0.f : dog;
+                ec = dummy ? 0.f : ec;
 #ifdef CN_STAMP
                 if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(dog) STAMP(3) }
 #endif

@@ -278,7 +278,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             float dfg = fg * (1.0f - fg) * cp * ec;
             float dig = ig * (1.0f - ig) * ni * ec;
             dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
-            if (dummy) { dni = dig = dfg = dog = 0.f; ec = 0.f; }
+            dni = dummy ? 0.f : dni; dig = dummy ? 0.f : dig; dfg = dummy ? 0.f : dfg; dog = dummy ? 0.f : dog;
+            ec = dummy ? 0.f : ec;      // selects, not a branch (see cn_lstm.hip)
             fgn[r] = dummy ? 0.f : fg;
             ecn[r] = ec; dign[r] = dig; dfgn[r] = dfg;
             ccur[r] = cp;
