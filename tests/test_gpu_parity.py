@@ -304,3 +304,36 @@ def test_short_sequences_and_sequences_per_lane(pkg, orc, T, PS):
         for lay in net.trainable_layers():
             g, gr = lay.weight_updates(), ref.layer(lay.name).weightUpdates
             assert rel_err(g, gr) < 2e-4, (lay.name, rel_err(g, gr))
+
+
+def test_bf16_mode_trains_like_fp32_mode(pkg):
+    """Sixty momentum-SGD steps on a learnable task (the class is a function of the current and the previous
+    input frame) in both precision modes: the error falls by more than a third in each and the two trajectories
+    end within 5 % of each other."""
+    rng = np.random.RandomState(21)
+    P, C, PS, T = 8, 4, 12, 24
+    layers = net_desc(P, [("blstm", 32)], C)
+    weights = random_weights(layers, rng, 0.1)
+    proj = rng.randn(2 * P, C)
+    fracs = []
+    for _ in range(4):
+        xs = [rng.randn(T - (i % 3), P).astype(np.float32) for i in range(PS)]
+        ts = []
+        for x in xs:
+            prev = np.vstack([np.zeros((1, P), np.float32), x[:-1]])
+            ts.append(np.argmax(np.hstack([x, prev]) @ proj, axis=1).astype(np.int32))
+        fracs.append(pkg.make_fraction(xs, ts, PS))
+    curves = {}
+    for prec in (pkg.PREC_F32, pkg.PREC_BF16):
+        with pkg.NeuralNetwork(layers, weights, PS, T, precision=prec) as net:
+            errs = []
+            for step in range(60):
+                net.load_sequences(fracs[step % 4]); net.compute_forward_pass()
+                errs.append(net.error_and_correct()[0])
+                net.compute_backward_pass(); net.update_weights(2e-3, 0.9)
+            curves[prec] = errs
+    for prec, errs in curves.items():
+        first, last = np.mean(errs[:4]), np.mean(errs[-4:])
+        assert np.all(np.isfinite(errs)) and last < 0.67 * first, (prec, first, last)
+    a, b = np.mean(curves[pkg.PREC_F32][-4:]), np.mean(curves[pkg.PREC_BF16][-4:])
+    assert abs(a - b) < 0.05 * a, (a, b)
