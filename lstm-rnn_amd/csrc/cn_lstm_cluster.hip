@@ -73,13 +73,19 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
 
+    // K chunks in the order they are used: first the KCO chunks of this member's own units (their y is in LDS as soon
+    // as the step starts), then the partners' (which have to cross L2 first).  kch[j] is the chunk behind wreg[.][j].
+    constexpr int KCO = KC / CS;
     u32x4 wreg[4][KC];
+    int kch[KC];
     const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) kch[j] = ((member + j / KCO) % CS) * KCO + j % KCO;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-            wreg[g][kc] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kc * 64 + q * 16);
+        for (int j = 0; j < KC; ++j)
+            wreg[g][j] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kch[j] * 64 + q * 16);
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
 
     int oP[RPL], oA[RPL], oC[RPL];
@@ -122,13 +128,35 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
+        // own units' part of the recurrent product: needs nothing from the partners
+#pragma unroll
+        for (int j = 0; j < KCO; ++j) {
+            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][j]);
+        }
+        // y[t-1] of the partners' units: published at the end of their previous step, so its trip through L2 has been
+        // running beside the products above (it used to be waited for at the end of the step, on the critical path)
+        if (it > 0) {
+            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * NT);
+#pragma unroll
+            for (int m = 0; m < CS; ++m) {
+                if (m == member) continue;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const unsigned v = consume(xprev + (long)m * (RPL * NT) + r * NT + tid, it, p.fault);
+                    *(unsigned short *)(const_cast<char *>(ycur) + (4 * q + r) * pitch + (((m - member + CS) % CS) * UPC + lunit) * 2) = (unsigned short)v;
+                }
+            }
+            lds_barrier();
+        }
+        // (the poll above drains vmcnt: the prefetch is issued behind it so that it has a whole step to land)
         prefetch(d ? t - 2 : t + 2, pre, pt);
-
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+        for (int j = KCO; j < KC; ++j) {
+            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][kc]);
+            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][j]);
         }
 
 #pragma unroll
@@ -146,24 +174,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const __bf16 yb = (__bf16)(dummy ? 0.f : y);
             cst[r] = co;
             // hand y[t] of this unit to the partners first (it is on their critical path), then keep it here
-            if (it + 1 < T) publish(xslot + (long)member * (RPL * NT) + r * NT + tid, it + 1, __builtin_bit_cast(unsigned short, yb));
-            *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit * 2) = yb;
+            publish(xslot + (long)member * (RPL * NT) + r * NT + tid, it + 1, __builtin_bit_cast(unsigned short, yb));
+            *(__bf16 *)(ynxt + (4 * q + r) * pitch + lunit * 2) = yb;       // the tile is member-relative: own units first
             const f32x4 av = {ni, ig, fg, og};
             *(f32x4 *)(actsT + oA[r]) = av;
             cellT[oC[r]] = co;
             yT[oC[r]] = yb;
-        }
-        // y[t] of the partners' units
-        if (it + 1 < T) {
-#pragma unroll
-            for (int m = 0; m < CS; ++m) {
-                if (m == member) continue;
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const unsigned v = consume(xslot + (long)m * (RPL * NT) + r * NT + tid, it + 1, p.fault);
-                    *(unsigned short *)(ynxt + (4 * q + r) * pitch + (m * UPC + lunit) * 2) = (unsigned short)v;
-                }
-            }
         }
         lds_barrier();
     };
@@ -200,10 +216,14 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
 
+    constexpr int KCO = KC / CS;       // own units' K chunks first, see the forward kernel
     u32x4 wreg[KC];
+    int kch[KC];
     const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
 #pragma unroll
-    for (int kc = 0; kc < KC; ++kc) wreg[kc] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kc * 64 + q * 16);
+    for (int j = 0; j < KC; ++j) kch[j] = ((member + j / KCO) % CS) * KCO + j % KCO;
+#pragma unroll
+    for (int j = 0; j < KC; ++j) wreg[j] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kch[j] * 64 + q * 16);
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
 
     int oP[RPL], oA[RPL], oC[RPL];
@@ -255,12 +275,32 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         for (int r = 0; r < 4; ++r) acc[r] = (r < RPL) ? pre.e[r < RPL ? r : 0] : 0.f;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) { ptc[r] = pre.pt[r]; cp_[r] = hasprev_ ? pre.cp[r] : 0.f; a_[r] = pre.a[r]; }
-        prefetch(d ? t + 2 : t - 2, pre);
-
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc) {
-            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
-            mma16<false>(acc, a, wreg[kc]);
+        for (int j = 0; j < KCO; ++j) {
+            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
+            mma16<false>(acc, a, wreg[j]);
+        }
+        if (it > 0) {      // the partners' deltas of the previous step
+            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * 2 * NT);
+#pragma unroll
+            for (int m = 0; m < CS; ++m) {
+                if (m == member) continue;
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const u64 *theirs = xprev + (long)m * (RPL * 2 * NT) + (r * 2) * NT + tid;
+                    const unsigned lo = consume(theirs, it, p.fault);
+                    const unsigned hi = consume(theirs + NT, it, p.fault);
+                    uint2 v = make_uint2(lo, hi);
+                    *(uint2 *)(const_cast<char *>(dcur) + (4 * q + r) * pitch + (((m - member + CS) % CS) * UPC + lunit) * 8) = v;
+                }
+            }
+            lds_barrier();
+        }
+        prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt), see the forward kernel
+#pragma unroll
+        for (int j = KCO; j < KC; ++j) {
+            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
+            mma16<false>(acc, a, wreg[j]);
         }
 
 #pragma unroll
@@ -287,27 +327,13 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             spi += cp * dig; spf += cp * dfg; spo += cs * dog;
             const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
             const u64 bits = __builtin_bit_cast(u64, dv);
-            if (it + 1 < T) {
+            {
                 u64 *mine = xslot + (long)member * (RPL * 2 * NT) + (r * 2) * NT + tid;
                 publish(mine, it + 1, (unsigned)bits);
                 publish(mine + NT, it + 1, (unsigned)(bits >> 32));
             }
-            *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit * 8) = dv;
+            *(bf16x4 *)(dnxt + (4 * q + r) * pitch + lunit * 8) = dv;        // member-relative tile: own units first
             *(bf16x4 *)(deltaT + oA[r]) = dv;
-        }
-        if (it + 1 < T) {
-#pragma unroll
-            for (int m = 0; m < CS; ++m) {
-                if (m == member) continue;
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const u64 *theirs = xslot + (long)m * (RPL * 2 * NT) + (r * 2) * NT + tid;
-                    const unsigned lo = consume(theirs, it + 1, p.fault);
-                    const unsigned hi = consume(theirs + NT, it + 1, p.fault);
-                    uint2 v = make_uint2(lo, hi);
-                    *(uint2 *)(dnxt + (4 * q + r) * pitch + (m * UPC + lunit) * 8) = v;
-                }
-            }
         }
         lds_barrier();
     };
