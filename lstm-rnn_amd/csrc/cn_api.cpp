@@ -339,6 +339,7 @@ void lstm_forward(cn_layer *l)
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
         if (!launch_lstm_cluster(c->stream, c->f32, false, r)) launch_lstm_forward(c->stream, c->f32, r);
+        HIP_CHECK(hipGetLastError());          // e.g. a fraction too long for the workgroup's LDS tables
     }
 }
 
@@ -353,6 +354,7 @@ void lstm_backward(cn_layer *l)
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
         if (!launch_lstm_cluster(c->stream, c->f32, true, r)) launch_lstm_backward(c->stream, c->f32, r);
+        HIP_CHECK(hipGetLastError());
     }
     if (l->prev->trainable) {   // K8 (LstmLayer.cu:990-1009): one K = R product instead of 4*dirs
         Timed tm(c, KC_GEMM_WIDE);
