@@ -124,6 +124,11 @@ int  cn_layer_join(cn_layer *layer);
 const char *cn_last_error(cn_ctx *ctx);
 /* "gfx950" etc. of the bound device; version string of the library */
 const char *cn_device_arch(cn_ctx *ctx);
+/* Device enumeration for `--list_devices` (main.cpp:509-525: cudaGetDeviceCount / cudaGetDeviceProperties).
+ * cn_device_count returns the number of HIP devices (0 when there is none); cn_device_name copies the name of
+ * device `index` ("<marketing name> (<gfx arch>)") into `buf` and returns a status. */
+int  cn_device_count(void);
+int  cn_device_name(int index, char *buf, int buf_size);
 const char *cn_version(void);
 
 /* ---- layers (LayerFactory<TDevice>::createLayer, LayerFactory.hpp:49-56) -------------------- */

@@ -473,6 +473,23 @@ const char *cn_last_error(cn_ctx *) { return g_last_error.c_str(); }
 
 const char *cn_device_arch(cn_ctx *ctx) { return ctx ? ctx->arch.c_str() : ""; }
 
+int cn_device_count(void)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return count;
+}
+
+int cn_device_name(int index, char *buf, int buf_size)
+{
+    if (!buf || buf_size <= 0) { g_last_error = "cn_device_name: bad buffer"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, index));
+        snprintf(buf, (size_t)buf_size, "%s (%s)", prop.name, prop.gcnArchName);
+    });
+}
+
 int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **out)
 {
     if (!out) { g_last_error = "cn_ctx_create: out is NULL"; return CN_ERR_BAD_ARG; }

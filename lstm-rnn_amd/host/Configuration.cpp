@@ -162,6 +162,7 @@ Configuration::Configuration(int argc, const char *argv[])
                 }
             }
         }
+    if (const char *dev = getenv("CURRENNT_CUDA_DEVICE")) m_device = atoi(dev);       // main.cpp:527-531 (kept under its old name)
     for (size_t i = 0; i < cli.size(); ++i) apply(cli[i].first, cli[i].second);   // command line wins
     if (m_parallelSequences < 1) throw std::runtime_error("Error while parsing the command line and/or options file: parallel_sequences must be >= 1");
 }

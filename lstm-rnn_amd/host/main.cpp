@@ -319,6 +319,16 @@ int main(int argc, const char *argv[])
     try {
         Configuration config(argc, argv);
         if (config.help()) { fputs(Configuration::usage(), stdout); return 0; }
+        if (config.listDevices()) {                                                              // main.cpp:509-525
+            const int count = cn_device_count();
+            std::cout << count << " devices found" << std::endl;
+            for (int i = 0; i < count; ++i) {
+                char name[256];
+                if (cn_device_name(i, name, sizeof(name)) != CN_OK) { std::cerr << "FAILED: " << cn_last_error(0) << std::endl; return 2; }
+                std::cout << i << ": " << name << std::endl;
+            }
+            return 0;
+        }
         printf("Started in %s training mode.\n", config.hybridOnlineBatch() ? "hybrid online/batch" : "batch");   // Configuration.cpp:316
         printf("Computations run on the MI355X (libcurrennt_hip: %s, %s operands).\n", cn_version(),
                config.precision() == CN_PREC_BF16 ? "bf16" : "fp32");
