@@ -380,21 +380,31 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
 }
 
+// cluster shapes: Hp = 256 -> 2 CUs x 128 units (8 waves each), Hp = 512 -> 8 CUs x 64 units (4 waves each; the slice of
+// W_rec a CU keeps in registers is 4*UPC*Hp operands = 256 KB in both cases)
+static int cluster_size(int Hp) { return Hp == 256 ? 2 : (Hp == 512 ? 8 : 0); }
+
 // bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
 size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl)
 {
-    if (f32 || Hp != 256 || getenv("CN_NO_CLUSTER")) return 0;
+    const int CS = cluster_size(Hp);
+    if (f32 || CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
-    if ((nclusters + 7) / 8 * 8 * 2 > 256) return 0;           // every member must be resident (one workgroup per CU)
-    return (size_t)nclusters * 2 * 2 * rpl * 2 * 512 * sizeof(u64);
+    if ((nclusters + 7) / 8 * 8 * CS > 256) return 0;          // every member must be resident (one workgroup per CU)
+    const int NT = (Hp / CS) * 4;
+    return (size_t)nclusters * 2 * CS * rpl * 2 * NT * sizeof(u64);
 }
 
 bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p)
 {
     if (!p.xch || lstm_cluster_xch_bytes(f32, p.Hp, p.dirs, p.PS, p.rpl) == 0) return false;
-    if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
-    else if (p.rpl == 2) { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
-    else return false;
+    if (p.Hp == 256) {
+        if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
+        else                 { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
+    } else {
+        if (p.rpl == 1)      { if (bwd) launch_cluster<512, 64, 1, true>(s, p); else launch_cluster<512, 64, 1, false>(s, p); }
+        else                 { if (bwd) launch_cluster<512, 64, 2, true>(s, p); else launch_cluster<512, 64, 2, false>(s, p); }
+    }
     return true;
 }
 

@@ -245,15 +245,17 @@ def test_error_texts(pkg):
         pkg.NeuralNetwork(bad, None, 2, 4, seed=1)
 
 
-def test_cluster_kernel_matches_streaming_kernel(pkg, orc):
+@pytest.mark.parametrize("size,scale", [(500, 0.06), (1024, 0.04)])
+def test_cluster_kernel_matches_streaming_kernel(pkg, orc, size, scale):
     """H = 250 per direction (reading B: CURRENNT size 500 -> Hp = 256): in bf16 mode W_rec is split over a
-    2-CU cluster with a per-step hand-off (cn_lstm_cluster.hip).  Same arithmetic as the single-CU streaming
-    kernel, so the two agree to bf16 noise; both track the fp32 oracle loosely."""
+    2-CU cluster with a per-step hand-off (cn_lstm_cluster.hip); H = 512 (the long-utterance config, size 1024):
+    8 CUs x 64 units.  Same arithmetic as the single-CU streaming kernel, so the two agree to bf16 noise; both
+    track the fp32 oracle loosely."""
     import os
     rng = np.random.RandomState(14)
     P, C, PS = 20, 12, 10
-    layers = net_desc(P, [("blstm", 500)], C)
-    weights = random_weights(layers, rng, 0.06)
+    layers = net_desc(P, [("blstm", size)], C)
+    weights = random_weights(layers, rng, scale)
     xs, ts = random_sequences(rng, [25, 25, 24, 22, 22, 20, 17, 15, 9, 4], P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)
     res = {}
