@@ -625,6 +625,12 @@ static void launch_rec(hipStream_t s, const LstmRec &p)
         else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);   // measured slower: 0.63 vs 0.47 us per step
         else launch_rpl<F32, BWD, 128, 1>(s, p, 8);
         return;
+    case 160:     // bf16 only: 200 / 288 KB of W_rec still fit one CU's registers (10 / 12 waves, three on some SIMDs)
+        if constexpr (!F32) { launch_rpl<F32, BWD, 160, 1>(s, p, 10); return; }
+        break;
+    case 192:
+        if constexpr (!F32) { launch_rpl<F32, BWD, 192, 1>(s, p, 12); return; }
+        break;
     default: break;
     }
     if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups);

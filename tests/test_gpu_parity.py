@@ -214,13 +214,15 @@ def test_sgd_momentum_steps(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
 
 
-def test_bf16_mode_close(pkg, orc):
+@pytest.mark.parametrize("hidden", [[64, 64], [300], [384, 320]])
+def test_bf16_mode_close(pkg, orc, hidden):
     """Throughput mode (bf16 MFMA operands, fp32 accumulate/state): not a parity mode; posteriors
-    stay within 3e-2 of the fp32 oracle on a 2-layer stack and the loss within 1 %."""
+    stay within 3e-2 of the fp32 oracle on a 2-layer stack and the loss within 1 %.  Sizes 300 / 320 / 384
+    (H = 150 / 160 / 192 -> Hp = 160 / 160 / 192) run the 10- and 12-wave register-resident kernels."""
     rng = np.random.RandomState(12)
     P, C, PS = 39, 20, 8
-    layers = net_desc(P, [("blstm", 64), ("blstm", 64)], C)
-    weights = random_weights(layers, rng, 0.1)
+    layers = net_desc(P, [("blstm", h) for h in hidden], C)
+    weights = random_weights(layers, rng, 0.1 if max(hidden) <= 64 else 0.05)
     xs, ts = random_sequences(rng, [30] * PS, P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)
     ref, net, (e_ref, _), (e, _) = run_both(pkg, orc, layers, weights, frac, PS, precision=1)
