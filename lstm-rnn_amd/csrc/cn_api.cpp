@@ -659,7 +659,15 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->dirs = (kind == CN_LAYER_BLSTM) ? 2 : 1;
             if (l->dirs == 2 && size % 2 != 0)
                 throw cn_error(CN_ERR_SHAPE, "Cannot create a bidirectional layer with an odd layer size");   // LstmLayer.cu:528-529
-            l->H = size / l->dirs; l->Hp = pad_units(l->H); l->Lp = l->dirs * l->Hp;
+            l->H = size / l->dirs; l->Hp = pad_units(l->H);
+            // bf16 mode: widths between the register-resident shapes (<= 192) and a cluster shape (256, 512) are padded
+            // up to the cluster shape when the cluster fits the chip: zero units cost GEMM work and memory, streaming
+            // W_rec from L2 every time step costs an order of magnitude more
+            if (!ctx->f32 && l->Hp > 192 && l->Hp < 512 && l->Hp != 256) {
+                const int hc = l->Hp < 256 ? 256 : 512;
+                if (lstm_cluster_xch_bytes(false, hc, l->dirs, ctx->PSp, ctx->rpl) > 0) l->Hp = hc;
+            }
+            l->Lp = l->dirs * l->Hp;
             const size_t R = (size_t)l->dirs * 4 * l->Hp;
             // the recurrent kernels address every per-frame buffer with 32-bit byte offsets from its base
             if (maxN * R * sizeof(float) >= (1ull << 32))

@@ -214,11 +214,12 @@ def test_sgd_momentum_steps(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
 
 
-@pytest.mark.parametrize("hidden", [[64, 64], [300], [384, 320]])
+@pytest.mark.parametrize("hidden", [[64, 64], [300], [384, 320], [440], [600]])
 def test_bf16_mode_close(pkg, orc, hidden):
     """Throughput mode (bf16 MFMA operands, fp32 accumulate/state): not a parity mode; posteriors
     stay within 3e-2 of the fp32 oracle on a 2-layer stack and the loss within 1 %.  Sizes 300 / 320 / 384
-    (H = 150 / 160 / 192 -> Hp = 160 / 160 / 192) run the 10- and 12-wave register-resident kernels."""
+    (H = 150 / 160 / 192 -> Hp = 160 / 160 / 192) run the 10- and 12-wave register-resident kernels; 440 and 600
+    (H = 220 / 300) are padded up to the 2-CU / 8-CU cluster shapes (Hp = 256 / 512)."""
     rng = np.random.RandomState(12)
     P, C, PS = 39, 20, 8
     layers = net_desc(P, [("blstm", h) for h in hidden], C)
