@@ -427,7 +427,7 @@ void ff_backward(cn_layer *l)
     repack(l);
     {
         Timed tm(c, KC_OTHER);
-        if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 256) {
+        if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, l->err, l->delta_op, l->dbias);
         } else {
             if (l->mcc_pending) launch_mcc_backward(c->stream, l->out_f32, c->d_tcls, N, l->size, l->Lp, l->err);

@@ -433,10 +433,76 @@ __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int 
         if (lane == 0) rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
     }
 }
+// Wide rows (256 < L <= 8192, e.g. 8000 tied states): one workgroup per pattern, the row in registers (VPT values per
+// thread), block reductions through LDS -- one read and one write of the posteriors instead of three and two.
+constexpr int SMW_VPT = 32;
+__device__ __forceinline__ float block_reduce(float v, int op, float *sh)      // op 0 sum, 1 max, 2 min; 256 threads
+{
+    v = op == 0 ? wave_sum(v) : (op == 1 ? wave_max(v) : wave_min(v));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float a = sh[0], b = sh[1], c = sh[2], d = sh[3];
+    return op == 0 ? (a + b) + (c + d) : (op == 1 ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d)));
+}
+__global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const char *pat, int N, int L, int Lp, const int *tcls, float2 *rowstat)
+{
+    __shared__ float sh[4]; __shared__ float shb[4]; __shared__ int shi[4];
+    const long row = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (pat[row] == 0) {                                 // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+        if (rowstat && tid == 0) rowstat[row] = make_float2(0.f, 0.f);
+        return;
+    }
+    float *r = y + row * Lp;
+    float v[SMW_VPT];
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) { const int j = tid + 256 * k; v[k] = j < L ? r[j] : 0.f; }
+    const int tc = rowstat ? tcls[row] : -1;
+    float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) if (tid + 256 * k < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
+    mx = block_reduce(mx, 1, sh); mn = block_reduce(mn, 2, sh);
+    const float offset = 0.5f * (mn + mx);               // :74
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) if (tid + 256 * k < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
+    sum = block_reduce(sum, 0, sh);
+    float best = 0.f, ptv = 0.f; int bi = 0;
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) {
+        const int j = tid + 256 * k;
+        if (j < L) {
+            const float w = v[k] / sum; r[j] = w;        // :152
+            if (w > best) { best = w; bi = j; }          // ascending j per thread: first maximum kept
+            if (j == tc) ptv = w;
+        }
+    }
+    if (rowstat) {
+        ptv = block_reduce(ptv, 0, sh);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { shb[tid >> 6] = best; shi[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) if (shb[w] > best || (shb[w] == best && shi[w] < bi)) { best = shb[w]; bi = shi[w]; }
+            if (best <= 0.f) bi = 0;
+            rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
+        }
+    }
+}
+
 void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat)
 {
     if (N <= 0) return;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
+    if (L > 256 && L <= 256 * SMW_VPT)
+        hipLaunchKernelGGL(softmax_fwd_wide_kernel, dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
+    else
+        hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
 }
 
 // fixed-order reduction of the row statistics: loss2[0] += -sum(log p), loss2[1] (int) += #correct
@@ -536,10 +602,47 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     __syncthreads();
     for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
 }
+// The same fusion for wide rows (256 < Lp <= 8192): one workgroup walks rows blockIdx.x, blockIdx.x + grid, ...; a thread
+// owns columns tid + 256 k and keeps their sums in registers; one atomic per column and workgroup at the end.
+template <bool F32>
+__global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
+                                                                   float *err, void *delta_op, float *colsum)
+{
+    const int tid = threadIdx.x;
+    float cs[SMW_VPT];
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) cs[k] = 0.f;
+    for (long row = blockIdx.x; row < N; row += gridDim.x) {
+        const int tc = tcls[row];
+        const bool real = pat[row] != 0;
+        const float *yr = y + row * Lp;
+        float et = 0.f, off = 0.f;
+        if (real && tc >= 0) { const float pt_ = yr[tc]; et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
+#pragma unroll
+        for (int k = 0; k < SMW_VPT; ++k) {
+            const int j = tid + 256 * k;
+            if (j >= Lp) break;
+            float dl = 0.f;
+            if (real && j < L) dl = yr[j] * ((j == tc ? et : 0.f) - off);
+            err[row * Lp + j] = dl;
+            if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
+            cs[k] += dl;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SMW_VPT; ++k) { const int j = tid + 256 * k; if (j < Lp) atomicAdd(&colsum[j], cs[k]); }
+}
+
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum)
 {
     if (N <= 0) return;
+    if (Lp > 256) {
+        int blocks = N < 1024 ? N : 1024;
+        if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_wide_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
+        else     hipLaunchKernelGGL(softmax_mcc_bwd_wide_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
+        return;
+    }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
     if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
     else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);

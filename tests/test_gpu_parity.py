@@ -342,3 +342,16 @@ def test_bf16_mode_trains_like_fp32_mode(pkg):
         assert np.all(np.isfinite(errs)) and last < 0.67 * first, (prec, first, last)
     a, b = np.mean(curves[pkg.PREC_F32][-4:]), np.mean(curves[pkg.PREC_BF16][-4:])
     assert abs(a - b) < 0.05 * a, (a, b)
+
+
+def test_wide_softmax_layer(pkg, orc):
+    """Softmax layers wider than 256 classes (tied-state outputs of the LVCSR shape) take the block-per-pattern
+    kernels: posteriors, error, #correct and all gradients against the oracle."""
+    rng = np.random.RandomState(33)
+    P, C, PS = 6, 700, 5
+    layers = net_desc(P, [("lstm", 24)], C)
+    weights = random_weights(layers, rng, 0.3)
+    xs, ts = random_sequences(rng, [9, 7, 7, 4], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    net.close()
