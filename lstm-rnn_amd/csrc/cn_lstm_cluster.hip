@@ -44,6 +44,21 @@ __device__ __forceinline__ unsigned consume(const u64 *slot, unsigned epoch, int
     return (unsigned)x;
 }
 
+// two granules at once: both loads are in flight together (one L2 round trip instead of two when the data is there)
+__device__ __forceinline__ uint2 consume2(const u64 *slot0, const u64 *slot1, unsigned epoch, int *fault)
+{
+    u64 x, y;
+    int spins = 0;
+    for (;;) {
+        x = __hip_atomic_load(slot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y = __hip_atomic_load(slot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch && (unsigned)(y >> 32) == epoch) break;
+        if (++spins > (1 << 21)) { *fault = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return make_uint2((unsigned)x, (unsigned)y);
+}
+
 // block id -> (cluster, member): the CS members of a cluster are 8 ids apart
 template <int CS>
 __device__ __forceinline__ void cluster_of(int &cluster, int &member)
@@ -288,9 +303,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
                     const u64 *theirs = xprev + (long)m * (RPL * 2 * NT) + (r * 2) * NT + tid;
-                    const unsigned lo = consume(theirs, it, p.fault);
-                    const unsigned hi = consume(theirs + NT, it, p.fault);
-                    uint2 v = make_uint2(lo, hi);
+                    const uint2 v = consume2(theirs, theirs + NT, it, p.fault);
                     *(uint2 *)(const_cast<char *>(dcur) + (4 * q + r) * pitch + (((m - member + CS) % CS) * UPC + lunit) * 8) = v;
                 }
             }
