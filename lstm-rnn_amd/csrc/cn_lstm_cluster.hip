@@ -44,6 +44,25 @@ __device__ __forceinline__ unsigned consume(const u64 *slot, unsigned epoch, int
     return (unsigned)x;
 }
 
+// K granules at once: all loads are in flight together, so a member waits one L2 round trip for its partners' values
+// instead of one per granule (7 partners x RPL granules in the 8-CU shape)
+template <int K>
+__device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigned epoch, int *fault, unsigned (&val)[K])
+{
+    int spins = 0;
+    for (;;) {
+        u64 x[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { ok = ok && (unsigned)(x[i] >> 32) == epoch; val[i] = (unsigned)x[i]; }
+        if (ok) break;
+        if (++spins > (1 << 21)) { *fault = 1; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // two granules at once: both loads are in flight together (one L2 round trip instead of two when the data is there)
 __device__ __forceinline__ uint2 consume2(const u64 *slot0, const u64 *slot1, unsigned epoch, int *fault)
 {
@@ -154,15 +173,19 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         // running beside the products above (it used to be waited for at the end of the step, on the critical path)
         if (it > 0) {
             u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * NT);
+            // partner j = member + 1 + j (mod CS) sits in column block j + 1 of the member-relative tile
+            const u64 *slots[(CS - 1) * RPL];
+            unsigned vals[(CS - 1) * RPL];
 #pragma unroll
-            for (int m = 0; m < CS; ++m) {
-                if (m == member) continue;
+            for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const unsigned v = consume(xprev + (long)m * (RPL * NT) + r * NT + tid, it, p.fault);
-                    *(unsigned short *)(const_cast<char *>(ycur) + (4 * q + r) * pitch + (((m - member + CS) % CS) * UPC + lunit) * 2) = (unsigned short)v;
-                }
-            }
+                for (int r = 0; r < RPL; ++r) slots[j * RPL + r] = xprev + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
+            consume_all<(CS - 1) * RPL>(slots, it, p.fault, vals);
+#pragma unroll
+            for (int j = 0; j < CS - 1; ++j)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r)
+                    *(unsigned short *)(const_cast<char *>(ycur) + (4 * q + r) * pitch + ((j + 1) * UPC + lunit) * 2) = (unsigned short)vals[j * RPL + r];
             lds_barrier();
         }
         // (the poll above drains vmcnt: the prefetch is issued behind it so that it has a whole step to land)
@@ -297,16 +320,22 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         }
         if (it > 0) {      // the partners' deltas of the previous step
             u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * 2 * NT);
+            const u64 *slots[(CS - 1) * RPL * 2];
+            unsigned vals[(CS - 1) * RPL * 2];
 #pragma unroll
-            for (int m = 0; m < CS; ++m) {
-                if (m == member) continue;
+            for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
-                    const u64 *theirs = xprev + (long)m * (RPL * 2 * NT) + (r * 2) * NT + tid;
-                    const uint2 v = consume2(theirs, theirs + NT, it, p.fault);
-                    *(uint2 *)(const_cast<char *>(dcur) + (4 * q + r) * pitch + (((m - member + CS) % CS) * UPC + lunit) * 8) = v;
+                    const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * 2 * NT) + (r * 2) * NT + tid;
+                    slots[(j * RPL + r) * 2] = theirs; slots[(j * RPL + r) * 2 + 1] = theirs + NT;
                 }
-            }
+            consume_all<(CS - 1) * RPL * 2>(slots, it, p.fault, vals);
+#pragma unroll
+            for (int j = 0; j < CS - 1; ++j)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r)
+                    *(uint2 *)(const_cast<char *>(dcur) + (4 * q + r) * pitch + ((j + 1) * UPC + lunit) * 8) =
+                        make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
             lds_barrier();
         }
         prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt), see the forward kernel
