@@ -46,10 +46,12 @@ __device__ __forceinline__ unsigned consume(const u64 *slot, unsigned epoch, int
 
 // K granules at once: all loads are in flight together, so a member waits one L2 round trip for its partners' values
 // instead of one per granule (7 partners x RPL granules in the 8-CU shape)
+// A poll that times out (a partner never arrived: not resident, or faulted) sets the fault word AND `gaveup`: the thread
+// does not wait again, so a broken launch ends after one time-out (~1 s) instead of one per time step.
 template <int K>
-__device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigned epoch, int *fault, unsigned (&val)[K])
+__device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigned epoch, int *fault, unsigned (&val)[K], bool &gaveup)
 {
-    int spins = 0;
+    int spins = gaveup ? (1 << 21) : 0;
     for (;;) {
         u64 x[K];
 #pragma unroll
@@ -58,7 +60,7 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
 #pragma unroll
         for (int i = 0; i < K; ++i) { ok = ok && (unsigned)(x[i] >> 32) == epoch; val[i] = (unsigned)x[i]; }
         if (ok) break;
-        if (++spins > (1 << 21)) { *fault = 1; break; }
+        if (++spins > (1 << 21)) { *fault = 1; gaveup = true; break; }
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    bool gaveup = false;
 
     // K chunks in the order they are used: first the KCO chunks of this member's own units (their y is in LDS as soon
     // as the step starts), then the partners' (which have to cross L2 first).  kch[j] is the chunk behind wreg[.][j].
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) slots[j * RPL + r] = xprev + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
-            consume_all<(CS - 1) * RPL>(slots, it, p.fault, vals);
+            consume_all<(CS - 1) * RPL>(slots, it, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -253,6 +256,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    bool gaveup = false;
 
     constexpr int KCO = KC / CS;       // own units' K chunks first, see the forward kernel
     u32x4 wreg[KC];
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                     const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * 2 * NT) + (r * 2) * NT + tid;
                     slots[(j * RPL + r) * 2] = theirs; slots[(j * RPL + r) * 2 + 1] = theirs + NT;
                 }
-            consume_all<(CS - 1) * RPL * 2>(slots, it, p.fault, vals);
+            consume_all<(CS - 1) * RPL * 2>(slots, it, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
