@@ -23,7 +23,8 @@ int main()
 {
     struct S { int M, N, K; const char *what; } nt[] = {
         {15600, 1024, 256, "input projection layer 2/3 (acts)"}, {15600, 1024, 64, "input projection layer 1"},
-        {15600, 256, 1024, "error to preceding layer (a7)"}, {15600, 192, 256, "softmax projection"}, {15600, 256, 192, "softmax E_prev"}};
+        {15600, 256, 1024, "error to preceding layer (a7)"}, {15600, 192, 256, "softmax projection"}, {15600, 256, 192, "softmax E_prev"},
+        {25600, 8000, 1024, "LVCSR softmax projection"}, {25600, 1024, 8000, "LVCSR softmax E_prev"}, {25600, 2048, 1024, "LVCSR layer input projection (Hp = 256)"}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto &c : nt) {
@@ -40,7 +41,7 @@ int main()
         printf("gemm_nt M=%5d N=%4d K=%4d  %7.1f us  %6.0f GB/s (compulsory bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias));
     }
-    struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}};
+    struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"}};
     for (auto &c : tn) {
         void *A = rnd((size_t)c.K * c.M), *B = rnd((size_t)c.K * c.N);
         float *C; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMemset(C, 0, (size_t)c.M * c.N * 4));
