@@ -755,8 +755,12 @@ int cn_layer_destroy(cn_layer *layer)
     return guarded([&] {
         cn_ctx *c = layer->ctx;
         HIP_CHECK(hipSetDevice(c->device));
+        join_side(c);                                   // side-stream work of this layer may still be in flight
         HIP_CHECK(hipStreamSynchronize(c->stream));
         for (void *p : layer->owned) hipFree(p);
+        if (layer->ev_fork) { hipEventDestroy(layer->ev_fork); hipEventDestroy(layer->ev_join); }
+        if (layer->ev_pack) hipEventDestroy(layer->ev_pack);
+        if (c->rowstat_of == layer) c->rowstat_of = nullptr;
         for (size_t i = 0; i < c->layers.size(); ++i)
             if (c->layers[i] == layer) { c->layers.erase(c->layers.begin() + i); break; }
         delete layer;
