@@ -136,7 +136,6 @@ def main():
 
     pkg = ge.load_package()
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream(dev)
     prec = pkg.PREC_BF16 if args.precision == "bf16" else pkg.PREC_F32
 
     def barrier():
@@ -152,8 +151,8 @@ def main():
         rng = np.random.RandomState(1234 + rank)                   # seed = 1234 + rank
         nfrac = 4
         fracs = [synth_fraction(pkg, rng, PS, P, C, args.tmin, args.tmax) for _ in range(nfrac)]
-        net = pkg.NeuralNetwork(layers, weights, PS, args.tmax, precision=prec, device=local_rank,
-                                stream=stream.cuda_stream)
+        # (the library runs on a stream of its own; net.torch_stream() is that stream for torch / RCCL ordering)
+        net = pkg.NeuralNetwork(layers, weights, PS, args.tmax, precision=prec, device=local_rank)
         # fractions resident in HBM (torch owns the device memory)
         dfr, keep = [], []
         for f in fracs:
@@ -184,7 +183,8 @@ def main():
                 net.compute_backward_pass()
                 if world > 1:
                     net.join()                              # gradient GEMMs run on the library's side stream
-                    dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+                    with torch.cuda.stream(net.torch_stream(torch)):      # RCCL orders itself against the CURRENT torch stream
+                        dist.all_reduce(grads, op=dist.ReduceOp.SUM)
             net.update_weights_fused(args.lr, args.momentum)
             return f["frames"]
 
@@ -313,8 +313,26 @@ def cpu_baseline(pkg, wl, args):
     net.compute_backward_pass(); net.update_weights(args.lr, args.momentum)
     dt = time.perf_counter() - t0
     frames = pkg.fraction.real_frames(frac)
-    return {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "1 fraction, %d sequences U[%d,%d] (%d frames), same topology, fp32, %.1f s" % (PS, tlo, thi, frames, dt)}
+    out = {"value": frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "1 fraction, %d sequences U[%d,%d] (%d frames), same topology, fp32, %.1f s" % (PS, tlo, thi, frames, dt)}
+    # the HIP path on the same fraction and weights, checked against the oracle: the fp32
+    # parity mode (north-star tolerance: posteriors within 1e-4) and the precision the throughput above was measured in
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    parity = {}
+    for name, prec in (("f32", pkg.PREC_F32), ("bf16", pkg.PREC_BF16)):
+        if name != "f32" and name != args.precision:
+            continue
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=prec) as hip:
+            hip.load_sequences(frac); hip.compute_forward_pass(); err = hip.calculate_error()
+            hip.compute_backward_pass()
+            post = float(np.abs(hip.outputs() - net.outputs()).max())
+            grad = max(rel(l.weight_updates(), net.layer(l.name).weightUpdates) for l in hip.trainable_layers())
+            hip.update_weights(args.lr, args.momentum)
+            wmax = max(float(np.abs(l.weights() - net.layer(l.name).weights).max()) for l in hip.trainable_layers())
+            parity[name] = {"posterior_max_abs": post, "gradient_rel_l2": grad, "updated_weights_max_abs": wmax, "error": float(err)}
+    out["parity_vs_cpu"] = parity
+    return out
 
 
 if __name__ == "__main__":

@@ -120,6 +120,14 @@ int  cn_ctx_join(cn_ctx *ctx);
  * Lets a data-parallel caller all-reduce the gradient of layer k+1 while layer k is still in its backward
  * pass (SURVEY.md 8e "Overlap": bucket = layer).  No-op when nothing is pending for the layer.   [async] */
 int  cn_layer_join(cn_layer *layer);
+/* The HIP stream (hipStream_t) the context enqueues its work on: the one given to cn_ctx_create, or the
+ * library's own.  For callers that order foreign work (a collective library's stream) against it. */
+void *cn_ctx_stream(cn_ctx *ctx);
+/* The same ordering for a stream of the CALLER's choice (a HIP stream handle): `stream` waits for the gradient work
+ * of `layer` and for nothing else the context has enqueued since, so a collective issued on it can start while the
+ * context's stream is still busy with the backward pass of the layers below.  The caller orders the context's
+ * stream behind that collective before the next cn_sgd_update*.                                      [async] */
+int  cn_layer_join_stream(cn_layer *layer, void *stream);
 /* message of the last failed call on this thread (ctx may be NULL for creation failures) */
 const char *cn_last_error(cn_ctx *ctx);
 /* "gfx950" etc. of the bound device; version string of the library */

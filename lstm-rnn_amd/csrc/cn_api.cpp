@@ -59,7 +59,7 @@ struct cn_ctx {
     // to finish, and at full speed their memory traffic stalls the latency-bound recurrent kernel (291 vs 229 us
     // per backward launch); on a subset of the CUs they run longer but draw less bandwidth
     hipStream_t side_slow = nullptr;
-    hipEvent_t ev_sgd = nullptr;
+    hipEvent_t ev_sgd = nullptr, ev_ext = nullptr;
     std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet
     bool overlap = true;
     bool f32 = true;
@@ -549,6 +549,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
         if (ctx->side_slow) { hipStreamSynchronize(ctx->side_slow); hipStreamDestroy(ctx->side_slow); }
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
+        if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
         if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }
         for (int i = 0; i < 2; ++i) {
             if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
@@ -600,6 +601,26 @@ int cn_layer_join(cn_layer *layer)
                 c->pending_joins.erase(c->pending_joins.begin() + i);
                 break;
             }
+    });
+}
+
+void *cn_ctx_stream(cn_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int cn_layer_join_stream(cn_layer *layer, void *stream)
+{
+    if (!layer || !stream) { g_last_error = "cn_layer_join_stream: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        cn_ctx *c = layer->ctx;
+        HIP_CHECK(hipSetDevice(c->device));
+        hipStream_t st = (hipStream_t)stream;
+        bool pending = false;
+        for (hipEvent_t e : c->pending_joins) pending = pending || e == layer->ev_join;
+        if (pending) { HIP_CHECK(hipStreamWaitEvent(st, layer->ev_join, 0)); return; }
+        // nothing of this layer is on the side stream (CN_NO_OVERLAP, or already joined): its gradient is ordered
+        // on the context's stream
+        if (!c->ev_ext) HIP_CHECK(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(c->ev_ext, c->stream));
+        HIP_CHECK(hipStreamWaitEvent(st, c->ev_ext, 0));
     });
 }
 

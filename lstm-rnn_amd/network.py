@@ -241,26 +241,25 @@ class NeuralNetwork:
             B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
 
     def compute_backward_pass_allreduce(self, dist, torch):
-        """Backward pass with the data-parallel gradient exchange folded in (SURVEY.md 8e "Overlap"): once the
-        backward pass of layer k is enqueued, the weightUpdates of layer k+1 (whose gradient GEMMs run on the
-        library's side stream) are all-reduced asynchronously, so the exchange of one layer runs beside the
-        recurrent kernels of the layers below it.  Returns after every reduction has been ordered before the
+        """Backward pass with the data-parallel gradient exchange folded in (SURVEY.md 8e "Overlap", bucket = layer):
+        as soon as the backward pass of a layer is enqueued, its weightUpdates (whose gradient GEMMs run on the
+        library's side stream) are all-reduced asynchronously from a communication stream that waits for that
+        layer's gradient work only (cn_layer_join_stream), i.e. beside the recurrent kernels of the layers below
+        it; only the first layer's exchange is exposed.  Returns after every reduction has been ordered before the
         context's stream; follow with update_weights_fused()."""
-        works, pending = [], None
-        def reduce(lay):
-            B.check(self.lib.cn_layer_join(lay.handle), self.ctx)
-            works.append(dist.all_reduce(lay.weight_updates_tensor(torch), op=dist.ReduceOp.SUM, async_op=True))
+        if getattr(self, "_comm_stream", None) is None:
+            self._comm_stream = torch.cuda.Stream(device=self.device)
+        works = []
+        main = self.torch_stream(torch)
         for lay in reversed(self.layers):
             B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
-            if pending is not None:
-                reduce(pending)
-                pending = None
             if lay.trainable:
-                pending = lay
-        if pending is not None:
-            reduce(pending)
-        for w in works:
-            w.wait()
+                B.check(self.lib.cn_layer_join_stream(lay.handle, C.c_void_p(self._comm_stream.cuda_stream)), self.ctx)
+                with torch.cuda.stream(self._comm_stream):
+                    works.append(dist.all_reduce(lay.weight_updates_tensor(torch), op=dist.ReduceOp.SUM, async_op=True))
+        with torch.cuda.stream(main):
+            for w in works:
+                w.wait()            # orders the context's stream behind the reduction
 
     def _loss(self):
         err, cor = C.c_float(), C.c_int()
@@ -287,6 +286,15 @@ class NeuralNetwork:
     def outputs(self):
         """Output layer activations [T][PS][C] (NeuralNetwork.cpp:237-262 de-interleaves per sequence)."""
         return self.output_layer().outputs()
+
+    def torch_stream(self, torch):
+        """The context's HIP stream as a torch stream.  Collectives and tensor ops that must be ordered against the
+        library's work run under `with torch.cuda.stream(net.torch_stream(torch))` -- torch's current stream is NOT the
+        context's stream unless the caller made it so (a default-stream handle of 0 given to the constructor means
+        "library-owned stream")."""
+        if getattr(self, "_torch_stream", None) is None:
+            self._torch_stream = torch.cuda.ExternalStream(int(self.lib.cn_ctx_stream(self.ctx)), device=torch.device("cuda", self.device))
+        return self._torch_stream
 
     def join(self):
         """Order the ctx stream behind the internal side stream (before an external all-reduce)."""

@@ -69,6 +69,57 @@ def test_bench_per_layer_allreduce_path_matches_plain_path():
     assert abs(sums["overlap"]["error_sum"] - sums["plain"]["error_sum"]) <= 1e-3 * abs(sums["plain"]["error_sum"])
 
 
+def test_per_layer_exchange_is_ordered_between_gradient_and_update(pkg):
+    """Stream ordering of compute_backward_pass_allreduce (cn_layer_join_stream + a communication stream), checked
+    with a stand-in for the collective that DOUBLES each layer's weightUpdates on the communication stream (what a
+    2-rank all-reduce of equal shards does): three momentum-SGD steps must equal the plain path run with twice the
+    learning rate.  A reduction that started before the layer's gradient GEMMs had finished, or an update that did
+    not wait for it, changes the trained weights by tens of percent."""
+    import torch
+
+    class Work:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    class FakeDist:
+        class ReduceOp:
+            SUM = 0
+
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            t.mul_(2.0)                                   # on the current (= communication) stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            return Work(ev)
+
+    rng = np.random.RandomState(21)
+    P, C, PS, T = 39, 40, 24, 120
+    layers = net_desc(P, [("blstm", 250), ("blstm", 250)], C)
+    weights = random_weights(layers, rng, 0.08)
+    xs, ts = random_sequences(rng, [T - (i % 7) for i in range(PS)], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    trained = {}
+    for mode, lr in (("plain", 2e-4), ("exchange", 1e-4)):
+        with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_BF16) as net:
+            for _ in range(3):
+                net.load_sequences(frac); net.compute_forward_pass()
+                if mode == "plain":
+                    net.compute_backward_pass()
+                else:
+                    net.compute_backward_pass_allreduce(FakeDist, torch)
+                net.update_weights_fused(lr, 0.9)
+            net.synchronize()
+            trained[mode] = np.concatenate([l.weights() for l in net.trainable_layers()])
+    start = np.concatenate([np.concatenate([np.asarray(weights[l["name"]][k], np.float32) for k in ("input", "bias", "internal")])
+                            for l in layers if l["name"] in weights])
+    moved = np.linalg.norm(trained["plain"] - start)
+    assert moved > 0
+    assert np.linalg.norm(trained["exchange"] - trained["plain"]) < 1e-3 * moved
+
+
 def test_rccl_allreduce_on_aliased_arena():
     """RCCL (torch.distributed backend nccl, one rank) all-reduces the aliased weightUpdates arena in place."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))

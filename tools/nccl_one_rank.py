@@ -13,13 +13,14 @@ pkg = ge.load_package()
 rng = np.random.RandomState(4)
 layers = net_desc(5, [("blstm", 8)], 4); weights = random_weights(layers, rng, 0.3)
 xs, ts = random_sequences(rng, [7, 5, 3], 5, C=4); frac = pkg.make_fraction(xs, ts, 3)
-net = pkg.NeuralNetwork(layers, weights, 3, 7, stream=torch.cuda.current_stream().cuda_stream)
+net = pkg.NeuralNetwork(layers, weights, 3, 7)
 net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass()
 w, g, d, n = net.param_arena()
 grads = torch.as_tensor(pkg.parallel.DeviceArray(g, n), device="cuda")
 before = pkg.parallel.flatten_updates([l.weight_updates() for l in net.trainable_layers()])
 net.join()
-dist.all_reduce(grads, op=dist.ReduceOp.SUM)
+with torch.cuda.stream(net.torch_stream(torch)):        # RCCL orders itself against the current torch stream
+    dist.all_reduce(grads, op=dist.ReduceOp.SUM)
 torch.cuda.synchronize()
 after = grads.cpu().numpy()
 assert np.array_equal(before, after), "1-rank all-reduce must be the identity"
