@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -165,6 +167,29 @@ void *dalloc(cn_layer *l, size_t bytes)
     HIP_CHECK(hipMemsetAsync(p, 0, bytes, l->ctx->stream));
     l->owned.push_back(p);
     return p;
+}
+
+// ---- CU-masked stream ------------------------------------------------------------------------
+// One CU-masked stream per (device, CU count) for the life of the process, shared by every context on that device.
+// hipStreamDestroy of such a stream is not reliable on ROCm 7.2: depending on the network (seen with 2, 4, 5 and 6
+// layers of blstm1024, not with the headline topology) it never returned although hipStreamSynchronize and
+// hipStreamQuery reported the stream idle, with or without a hipDeviceSynchronize in front.  Contexts order their own
+// work on it with events, so sharing it costs at most some serialisation between contexts.
+hipStream_t masked_stream(int device, int ncu, int total)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> pool;
+    if (ncu <= 0 || ncu >= total) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = pool.find({device, ncu});
+    if (it != pool.end()) return it->second;
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int i = 0; i < total; ++i)
+        if ((long)(i + 1) * ncu / total != (long)i * ncu / total) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t st = nullptr;
+    if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+    pool[{device, ncu}] = st;
+    return st;
 }
 
 // ---- timing ---------------------------------------------------------------------------------
@@ -519,13 +544,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             // mask on few XCDs and gain nothing.  CN_SIDE_CUS=0 turns the slow lane off.
             int ncu = prop.multiProcessorCount * 5 / 16;
             if (const char *e = getenv("CN_SIDE_CUS")) ncu = atoi(e);
-            if (ncu > 0 && ncu < prop.multiProcessorCount) {
-                const int total = prop.multiProcessorCount;
-                std::vector<uint32_t> mask((total + 31) / 32, 0u);
-                for (int i = 0; i < total; ++i)
-                    if ((long)(i + 1) * ncu / total != (long)i * ncu / total) mask[i / 32] |= 1u << (i % 32);
-                if (hipExtStreamCreateWithCUMask(&c->side_slow, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); c->side_slow = nullptr; }
-            }
+            c->side_slow = masked_stream(device_id, ncu, prop.multiProcessorCount);
         }
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
@@ -547,7 +566,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
-        if (ctx->side_slow) { hipStreamSynchronize(ctx->side_slow); hipStreamDestroy(ctx->side_slow); }
+        if (ctx->side_slow) hipStreamSynchronize(ctx->side_slow);     // shared per device, never destroyed: masked_stream()
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
         if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
         if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }

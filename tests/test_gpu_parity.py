@@ -355,3 +355,32 @@ def test_wide_softmax_layer(pkg, orc):
     frac = pkg.make_fraction(xs, ts, PS)
     ref, net = check_network(pkg, orc, layers, weights, frac, PS)
     net.close()
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_destroy_deep_cluster_network(depth):
+    """BLSTM layers of size 1024 (8-CU cluster kernels; BASELINE.json's long-utterance topology has five): one training
+    step, then the context is destroyed and the process exits.  Run in a child process with a time limit: when every
+    context owned (and destroyed) its CU-masked gradient stream, hipStreamDestroy never returned for some depths
+    (cn_api.cpp: masked_stream)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "from helpers import net_desc, random_sequences, random_weights\n"
+        "pkg = ge.load_package()\n"
+        "rng = np.random.RandomState(5)\n"
+        "layers = net_desc(39, [('blstm', 1024)] * %d, 20)\n"
+        "weights = random_weights(layers, rng, 0.02)\n"
+        "xs, ts = random_sequences(rng, [12] * 16, 39, C=20)\n"
+        "frac = pkg.make_fraction(xs, ts, 16)\n"
+        "for _ in range(2):\n"
+        "    with pkg.NeuralNetwork(layers, weights, 16, 12, precision=pkg.PREC_BF16) as net:\n"
+        "        net.load_sequences(frac); net.compute_forward_pass(); e = net.calculate_error()\n"
+        "        net.compute_backward_pass(); net.update_weights_fused(1e-5, 0.9); net.synchronize()\n"
+        "        assert np.isfinite(e)\n"
+        "print('destroyed ok')\n" % (root, os.path.join(root, "tests"), depth))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and "destroyed ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
