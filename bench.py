@@ -31,6 +31,10 @@ WORKLOADS = {
     "timit_3x500_blstm_H250": dict(P=39, hidden=[("blstm", 500)] * 3, C=183),
     # BASELINE.json configs[0] topology
     "timit_1x128_lstm": dict(P=39, hidden=[("lstm", 128)], C=183),
+    # BASELINE.json configs[3]: synthetic LVCSR, 40-d fbank -> 4 x 512 BLSTM (256 per direction) -> 8000 tied states
+    "lvcsr_4x512_blstm_8000": dict(P=40, hidden=[("blstm", 512)] * 4, C=8000, PS=64, tmin=300, tmax=800),
+    # BASELINE.json configs[4]: long-utterance stress, 5 x 1024 BLSTM (512 per direction), T = 2000
+    "longutt_5x1024_blstm": dict(P=39, hidden=[("blstm", 1024)] * 5, C=183, PS=16, tmin=2000, tmax=2000),
 }
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E peak
 
@@ -111,9 +115,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="timit_3x250_blstm_H125", choices=sorted(WORKLOADS))
-    ap.add_argument("--parallel-sequences", type=int, default=50, help="per GPU (examples/*/config.cfg: 50)")
-    ap.add_argument("--tmin", type=int, default=250)
-    ap.add_argument("--tmax", type=int, default=350)
+    ap.add_argument("--parallel-sequences", type=int, default=None, help="per GPU (default: the workload's, 50 as in examples/*/config.cfg)")
+    ap.add_argument("--tmin", type=int, default=None, help="sequence lengths are U[tmin, tmax] (default: the workload's, 250..350)")
+    ap.add_argument("--tmax", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--momentum", type=float, default=0.9)
@@ -121,6 +125,10 @@ def main():
     ap.add_argument("--no-roofline-pass", action="store_true")
     ap.add_argument("--also", default="", help="comma list of extra workloads measured and reported under 'also'")
     args = ap.parse_args()
+    wl0 = WORKLOADS[args.workload]
+    if args.parallel_sequences is None: args.parallel_sequences = wl0.get("PS", 50)
+    if args.tmin is None: args.tmin = wl0.get("tmin", 250)
+    if args.tmax is None: args.tmax = max(wl0.get("tmax", 350), args.tmin)
 
     import torch
     import torch.distributed as dist
@@ -244,11 +252,12 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train frames/sec (node), 3x250 BLSTM 39->183", "value": value, "unit": "frames/s",
+            "metric": "train frames/sec (node), 3x250 BLSTM 39->183" if args.workload.startswith("timit_3x") else "train frames/sec (node), " + args.workload,
+            "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * seconds / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": args.workload, "topology": "39 -> " + " -> ".join("%s%d" % h for h in wl["hidden"]) + " -> softmax183",
+            "config": {"workload": args.workload, "topology": "%d -> " % wl["P"] + " -> ".join("%s%d" % h for h in wl["hidden"]) + " -> softmax%d" % wl["C"],
                        "parallel_sequences_per_gpu": args.parallel_sequences, "seq_len": "U[%d,%d]" % (args.tmin, args.tmax),
                        "weights": res["weights"], "update": "stochastic momentum SGD every fraction",
                        "parallelism": "dp%d over sequences" % world},
@@ -300,12 +309,16 @@ def cpu_baseline(pkg, wl, args):
     """The oracle (scalar fp32 restatement of the reference's Cpu path, 1 thread like its Thrust-host build)
     timed on a bounded sample of the same workload: one fraction of 16 sequences."""
     orc = ge.load_oracle()
-    PS = 16
     layers = net_desc(wl["P"], wl["hidden"], wl["C"])
     weights = make_weights(layers, 1234)
     rng = np.random.RandomState(99)
-    # keep the sample near 10-20 s of CPU work: ~5k frames of reading A
-    tlo, thi = (args.tmin, args.tmax) if sum(s for _, s in wl["hidden"]) <= 750 else (60, 90)
+    # keep the sample near 10 s of CPU work (the oracle runs at ~3 GFLOP/s): 16 sequences of the workload's lengths
+    # for reading A (~5k frames), fewer and shorter sequences for the larger topologies
+    PS, tlo, thi = 16, args.tmin, args.tmax
+    budget = 30e9 / flops_per_frame(wl["P"], wl["hidden"], wl["C"])          # frames
+    if PS * (tlo + thi) / 2 > budget:
+        PS = 8 if budget >= 8 * 20 else 4
+        thi = max(4, int(budget / PS * 1.15)); tlo = max(2, int(thi * 0.75))
     frac = synth_fraction(pkg, rng, PS, wl["P"], wl["C"], tlo, thi)
     net = orc.OracleNetwork(layers, weights, PS, frac["T"])
     t0 = time.perf_counter()

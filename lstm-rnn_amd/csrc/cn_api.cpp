@@ -347,6 +347,18 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.xch = c->d_xch; r.fault = c->d_fault;
 }
 
+// the single-CU recurrent kernels keep two operand tiles (and, backward, one byte per time step and sequence) in LDS
+void check_rec_lds(const cn_layer *l, bool bwd)
+{
+    const cn_ctx *c = l->ctx;
+    const size_t need = lstm_rec_lds_bytes(c->f32, bwd, l->Hp, c->rpl, c->T);
+    if (need > 160 * 1024)
+        throw cn_error(CN_ERR_SHAPE, "LSTM layer with " + std::to_string(l->H) + " units per direction, " + std::to_string(c->T) +
+                       " time steps: the recurrent " + (bwd ? "backward" : "forward") + " kernel needs " + std::to_string(need / 1024) +
+                       " KB of LDS per workgroup (160 KB available)" + (c->f32 ? "; use CN_PREC_BF16 for layers this wide" : "") +
+                       " or shorter fractions (truncate_seq)");
+}
+
 void lstm_forward(cn_layer *l)
 {
     cn_ctx *c = l->ctx;
@@ -363,8 +375,8 @@ void lstm_forward(cn_layer *l)
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, false, r)) launch_lstm_forward(c->stream, c->f32, r);
-        HIP_CHECK(hipGetLastError());          // e.g. a fraction too long for the workgroup's LDS tables
+        if (!launch_lstm_cluster(c->stream, c->f32, false, r)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
+        HIP_CHECK(hipGetLastError());
     }
 }
 
@@ -378,7 +390,7 @@ void lstm_backward(cn_layer *l)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) launch_lstm_backward(c->stream, c->f32, r);
+        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) { check_rec_lds(l, true); launch_lstm_backward(c->stream, c->f32, r); }
         HIP_CHECK(hipGetLastError());
     }
     if (l->prev->trainable) {   // K8 (LstmLayer.cu:990-1009): one K = R product instead of 4*dirs

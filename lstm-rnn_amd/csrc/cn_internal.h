@@ -61,6 +61,7 @@ struct LstmRec {
     unsigned long long *xch;      // exchange granules, zeroed per launch (nullable: cluster path off)
     int *fault;                   // set to 1 by a bounded spin that gave up
 };
+size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T);       // dynamic LDS per workgroup of the single-CU kernels
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
 void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered

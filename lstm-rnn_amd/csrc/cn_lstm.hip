@@ -98,13 +98,18 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
+    // LDS tile rows: the resident kernels keep the full 16-row MFMA operand tile; the streaming fallback (W_rec read
+    // from L2 every step, HP = 0: large layers) keeps the 4*RPL real rows plus ONE shared zero row, which is what
+    // lets a 4*Hp-wide fp32 / bf16 delta row of 8 KB (Hp = 512 fp32, Hp = 1024 bf16) fit the 160 KB LDS twice
+    constexpr int TROWS = RES ? 16 : 4 * RPL + 1;
+    [[maybe_unused]] const int rrow = RES ? c : ((c & 3) < RPL ? (c >> 2) * RPL + (c & 3) : 4 * RPL);
     const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * (4 * RPL);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * Hp;           // acts row stride (floats)
     const long crow = (long)dirs * Hp;               // cell / y row stride (elements)
 
     // zero both y tiles (y[prev] of the first processed step is 0; padding rows stay 0)
-    for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    for (int i = threadIdx.x * 4; i < 2 * TROWS * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
@@ -169,8 +174,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     STAMP_DECL
     auto step = [&](int it, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
-        const char *ycur = smem + (it & 1) * 16 * pitch;
-        char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const char *ycur = smem + (it & 1) * TROWS * pitch;
+        char *ynxt = smem + ((it + 1) & 1) * TROWS * pitch;
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
             }
         } else {
             for (int kc = 0; kc < KC; ++kc) {
-                const u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+                const u32x4 a = *(const u32x4 *)(ycur + rrow * pitch + kc * 64 + q * 16);
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
                     u32x4 b[4];
@@ -275,8 +280,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #ifdef CN_STAMP
                 if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(yo) STAMP(3) }
 #endif
-                if constexpr (F32) *(float *)(ynxt + (4 * q + r) * pitch + unit[u] * 4) = yo;
-                else *(__bf16 *)(ynxt + (4 * q + r) * pitch + unit[u] * 2) = (__bf16)yo;
+                if constexpr (F32) *(float *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 4) = yo;
+                else *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = (__bf16)yo;
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
                 *(f32x4 *)(actsT + oA[u][r]) = av;
                 cellT[oC[u][r]] = co;
@@ -337,16 +342,21 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
+    // LDS tile rows: the resident kernels keep the full 16-row MFMA operand tile; the streaming fallback (W_rec read
+    // from L2 every step, HP = 0: large layers) keeps the 4*RPL real rows plus ONE shared zero row, which is what
+    // lets a 4*Hp-wide fp32 / bf16 delta row of 8 KB (Hp = 512 fp32, Hp = 1024 bf16) fit the 160 KB LDS twice
+    constexpr int TROWS = RES ? 16 : 4 * RPL + 1;
+    [[maybe_unused]] const int rrow = RES ? c : ((c & 3) < RPL ? (c >> 2) * RPL + (c & 3) : 4 * RPL);
     const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * (4 * RPL);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * Hp;
     const long crow = (long)dirs * Hp;
 
-    for (int i = threadIdx.x * 4; i < 2 * 16 * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    for (int i = threadIdx.x * 4; i < 2 * TROWS * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
     // dummy-slot table of this workgroup's sequences, read per step from LDS (LstmLayer.cu:224-234 with
     // checkPatType of :949,983); the forward kernel stages the pattern type through its register prefetch
     // instead, which measured faster there (0.47 vs 0.49 us per step) and slower here
-    unsigned char *dtab = (unsigned char *)smem + 2 * 16 * pitch;
+    unsigned char *dtab = (unsigned char *)smem + 2 * TROWS * pitch;
     build_dummy_table<RPL>(dtab, p.pat, T, p.Tmin, p.PS, (blockIdx.x / p.dirs) * (4 * RPL));
 
     int unit[UG];
@@ -415,8 +425,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     STAMP_DECL
     auto step = [&](int it, BwdPre<UG, RPL> &pre) {
         const int t = d ? it : T - 1 - it;
-        const char *dcur = smem + (it & 1) * 16 * pitch;
-        char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const char *dcur = smem + (it & 1) * TROWS * pitch;
+        char *dnxt = smem + ((it + 1) & 1) * TROWS * pitch;
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
         const unsigned bD = (unsigned)t * stepA;
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
 #endif
         } else {
             for (int kc = 0; kc < KC; ++kc) {
-                const u32x4 a = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+                const u32x4 a = *(const u32x4 *)(dcur + rrow * pitch + kc * 64 + q * 16);
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
                     const u32x4 b = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
@@ -519,11 +529,11 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 spi[u] += cp * dig; spf[u] += cp * dfg; spo[u] += cs * dog;
                 if constexpr (F32) {
                     const f32x4 dv = {dni, dig, dfg, dog};
-                    *(f32x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 16) = dv;
+                    *(f32x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 16) = dv;
                     *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
                 } else {
                     const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
-                    *(bf16x4 *)(dnxt + (4 * q + r) * pitch + unit[u] * 8) = dv;
+                    *(bf16x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dv;
                     *(bf16x4 *)&at32<__bf16>(p.delta_op, bD + oA[u][r]) = dv;
                 }
             }
@@ -584,7 +594,7 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
     const int ELT = F32 ? 4 : 2;
     const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
     const int pitch = lds_pitch((BWD ? 4 : 1) * p.Hp * ELT);
-    const size_t lds = 2 * 16 * (size_t)pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
+    const size_t lds = 2 * (size_t)(HP ? 16 : 4 * RPL + 1) * pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
     auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -644,6 +654,16 @@ extern "C" int cn_dbg_read_stamps(unsigned long long *host)      // [2][16][8]
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_stamp_buf), sizeof(cn_stamp_buf));
 }
 #endif
+
+// dynamic LDS of one workgroup of the single-CU kernels (launch_one): two operand tiles (+ the backward kernel's
+// dummy-slot table); resident shapes are those launch_rec dispatches on
+size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T)
+{
+    const int ELT = f32 ? 4 : 2;
+    const bool resident = Hp == 32 || Hp == 64 || Hp == 96 || Hp == 128 || (!f32 && (Hp == 160 || Hp == 192));
+    const size_t pitch = (size_t)lds_pitch((bwd ? 4 : 1) * Hp * ELT);
+    return 2 * (size_t)(resident ? 16 : 4 * rpl + 1) * pitch + (bwd ? (((size_t)T * 4 * rpl + 15) & ~(size_t)15) : 0);
+}
 
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
 {

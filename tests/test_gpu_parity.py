@@ -357,6 +357,31 @@ def test_wide_softmax_layer(pkg, orc):
     net.close()
 
 
+def test_wide_layers_in_fp32_parity_mode(pkg, orc):
+    """fp32 parity mode with 512 units per direction (the long-utterance topology's layer width): W_rec does not fit
+    one CU, so the streaming kernels run with the compact operand tile (4 real rows + one zero row; a full 16-row
+    fp32 delta tile of 4 x 512 units would need 263 KB of LDS).  Same tolerances as every other fp32 parity test."""
+    rng = np.random.RandomState(33)
+    P, C, PS = 10, 6, 3
+    layers = net_desc(P, [("blstm", 1024)], C)
+    weights = random_weights(layers, rng, 0.03)
+    xs, ts = random_sequences(rng, [5, 4, 2], P, C=C)
+    check_network(pkg, orc, layers, weights, pkg.make_fraction(xs, ts, PS), PS)
+
+
+def test_layer_too_wide_for_fp32_mode_says_so(pkg):
+    """1024 units per direction in fp32 mode: the backward kernel's two delta tiles exceed the LDS; the call fails
+    with a message that names the limit instead of a bare launch error."""
+    rng = np.random.RandomState(34)
+    layers = net_desc(4, [("blstm", 2048)], 3)
+    xs, ts = random_sequences(rng, [3, 2], 4, C=3)
+    with pkg.NeuralNetwork(layers, None, 2, 3, seed=1) as net:
+        net.load_sequences(pkg.make_fraction(xs, ts, 2))
+        net.compute_forward_pass()
+        with pytest.raises(pkg.CurrenntHipError, match="KB of LDS per workgroup"):
+            net.compute_backward_pass()
+
+
 @pytest.mark.parametrize("depth", [2, 4])
 def test_destroy_deep_cluster_network(depth):
     """BLSTM layers of size 1024 (8-CU cluster kernels; BASELINE.json's long-utterance topology has five): one training
