@@ -357,6 +357,42 @@ def test_wide_softmax_layer(pkg, orc):
     net.close()
 
 
+def test_two_contexts_interleaved(pkg):
+    """Two networks alive in one process, trained alternately (they share the device's CU-masked gradient stream):
+    each ends with the weights it reaches when trained alone."""
+    rng = np.random.RandomState(41)
+    P, C, PS, T = 12, 7, 6, 25
+    specs = []
+    for hidden in ([("blstm", 64), ("blstm", 64)], [("lstm", 48), ("blstm", 96)]):
+        layers = net_desc(P, hidden, C)
+        weights = random_weights(layers, rng, 0.1)
+        xs, ts = random_sequences(rng, [T - i for i in range(PS)], P, C=C)
+        specs.append((layers, weights, pkg.make_fraction(xs, ts, PS)))
+
+    def train(nets, steps=4):
+        for _ in range(steps):
+            for net, (_, _, frac) in zip(nets, specs):
+                net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass()
+                net.update_weights_fused(1e-3, 0.9)
+        return [np.concatenate([l.weights() for l in net.trainable_layers()]) for net in nets]
+
+    solo = []
+    for spec in specs:
+        with pkg.NeuralNetwork(spec[0], spec[1], PS, T) as net:
+            for _ in range(4):
+                net.load_sequences(spec[2]); net.compute_forward_pass(); net.compute_backward_pass()
+                net.update_weights_fused(1e-3, 0.9)
+            solo.append(np.concatenate([l.weights() for l in net.trainable_layers()]))
+    nets = [pkg.NeuralNetwork(s_[0], s_[1], PS, T) for s_ in specs]
+    try:
+        both = train(nets)
+    finally:
+        for n in nets:
+            n.close()
+    for a, b in zip(solo, both):
+        assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
+
+
 def test_wide_layers_in_fp32_parity_mode(pkg, orc):
     """fp32 parity mode with 512 units per direction (the long-utterance topology's layer width): W_rec does not fit
     one CU, so the streaming kernels run with the compact operand tile (4 real rows + one zero row; a full 16-row
