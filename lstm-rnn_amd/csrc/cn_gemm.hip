@@ -200,11 +200,10 @@ void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
     if (g.M <= 0 || g.N <= 0) return;
     int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
     int nwg = tiles_m * tiles_n;
-    static bool attr_set = false;
-    if (!attr_set) {   // > 64 KiB of dynamic LDS needs the opt-in
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {   // > 64 KiB of dynamic LDS needs the opt-in
         (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        attr_set = true;
     }
     if (f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
     else     hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
@@ -400,10 +399,9 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
     if (blocks == 0) return;
     auto kern = gemm_tn_kernel<F32, BT>;
     constexpr int lds = TnGeom<F32, BT>::LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, grp);
 }

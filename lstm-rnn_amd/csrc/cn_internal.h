@@ -18,6 +18,20 @@ enum KClass { KC_REC_FWD = 0, KC_REC_BWD = 1, KC_GEMM_WIDE = 2, KC_GEMM_GRAD = 3
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// hipFuncSetAttribute (the > 64 KB dynamic LDS opt-in) is per device: a process may drive several GPUs
+struct DeviceOnce {
+    unsigned long long seen = 0;
+    bool first()
+    {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (seen & bit) return false;
+        seen |= bit;
+        return true;
+    }
+};
+
 // ---- GEMM ------------------------------------------------------------------------------------
 // All matrices are row-major; "op" element type is float (CN_PREC_F32) or bf16 (CN_PREC_BF16).
 struct GemmNT {            // C[m][n] = sum_k A[m][k] * B[n][k]   (+ bias[n]) -> act -> C / C2

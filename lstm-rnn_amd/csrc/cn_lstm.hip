@@ -596,10 +596,9 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
     const int pitch = lds_pitch((BWD ? 4 : 1) * p.Hp * ELT);
     const size_t lds = 2 * (size_t)(HP ? 16 : 4 * RPL + 1) * pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
     auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     // When the grid leaves CUs free (one workgroup per CU at most), each workgroup claims the CU's whole LDS so that
     // no workgroup of a concurrently running kernel (the gradient GEMMs of the side stream) can be placed beside

@@ -418,10 +418,9 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     const size_t xbytes = (size_t)nclusters * 2 * CS * RPL * (BWD ? 2 : 1) * NT * sizeof(u64);
     (void)hipMemsetAsync(p.xch, 0, xbytes, s);       // tags restart at 1 every launch
     auto kern = BWD ? lstm_bwd_cluster_kernel<HP, UPC, RPL> : lstm_fwd_cluster_kernel<HP, UPC, RPL>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
 }
