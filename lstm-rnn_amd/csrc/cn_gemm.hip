@@ -213,17 +213,20 @@ void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
 // gemm_tn
 // ---------------------------------------------------------------------------------------------
 // BT x BT output tile (BT = 64 or 128), 4 waves as 2 x 2, each wave (BT/2) x (BT/2) in 32x32 MFMA tiles.
-constexpr int TN_BK = 32;
+// rows of K per k-step: 64 for the 64 x 64 tiles (the small split-K products: 4-19 % faster than 32, fewer barriers per
+// byte), 32 for the 128 x 128 tiles (64 measured 3 % slower there)
+constexpr int tn_bk(int bt) { return bt == 64 ? 64 : 32; }
 // one LDS buffer per operand, next k-tile in registers (as gemm_nt): more workgroups per CU; the 8000 x 1024 x 25 600
 // product gains 32 % (342 -> 450 TFLOP/s), the small split-K products are unchanged
 constexpr int TN_NBUF = 1;
 template <bool F32, int BT> struct TnGeom {
     static constexpr int ELT = F32 ? 4 : 2;
+    static constexpr int BK = tn_bk(BT);
     static constexpr int PITCH = BT * ELT + 64;            // K-major rows; 4 consecutive k rows hit distinct bank quarters
-    static constexpr int TILE = TN_BK * PITCH;
+    static constexpr int TILE = BK * PITCH;
     static constexpr int LDS = 2 * TN_NBUF * TILE;         // (A,B) x TN_NBUF buffers
     static constexpr int CPR = BT * ELT / 16;              // 16-byte chunks per tile row
-    static constexpr int NLD = TN_BK * CPR / 256;          // chunks per thread per operand
+    static constexpr int NLD = BK * CPR / 256;          // chunks per thread per operand
     static constexpr int WT = BT / 64;                     // 32x32 MFMA tiles per wave and dimension
 };
 
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     if (kbeg >= kend) return;
-    const int nk = (kend - kbeg + TN_BK - 1) / TN_BK;
+    const int nk = (kend - kbeg + G::BK - 1) / G::BK;
 
     const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
     u32x4 ra[NLD], rb[NLD];
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
-            int k = kbeg + kt * TN_BK + kr;
+            int k = kbeg + kt * G::BK + kr;
             u32x4 z = {0u, 0u, 0u, 0u};
             ra[j] = z; rb[j] = z;
             if (k < kend) {
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
         if constexpr (F32) {
             // v_mfma_f32_32x32x2_f32: lane (r,h) holds A[m=r][k=2s+h] / B[k=2s+h][n=r]
 #pragma unroll 4
-            for (int s2 = 0; s2 < TN_BK / 2; ++s2) {
+            for (int s2 = 0; s2 < G::BK / 2; ++s2) {
                 float a[WT], b[WT];
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
             // address of row q, columns 4p..4p+3, lane i receives column i of the 4 rows.
             const int g16 = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
 #pragma unroll
-            for (int ks = 0; ks < TN_BK / 16; ++ks) {
+            for (int ks = 0; ks < G::BK / 16; ++ks) {
                 bf16x8 a[WT], b[WT];
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
@@ -370,6 +373,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
 template <bool F32, int BT>
 static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
+    using G = TnGeom<F32, BT>;
     GemmTNGroup grp{};
     int blocks = 0;
     long all_tiles = 0;
@@ -386,11 +390,11 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
         static const int target = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 1024;
         int splits = (int)((target + all_tiles - 1) / all_tiles);
-        int maxsplit = (g.K + 4 * TN_BK - 1) / (4 * TN_BK);
+        int maxsplit = (g.K + 4 * G::BK - 1) / (4 * G::BK);
         if (splits > maxsplit) splits = maxsplit;
         if (splits > cap_atomic) splits = (int)cap_atomic;
         if (splits < 1) splits = 1;
-        int kchunk = ((g.K + splits - 1) / splits + TN_BK - 1) / TN_BK * TN_BK;
+        int kchunk = ((g.K + splits - 1) / splits + G::BK - 1) / G::BK * G::BK;
         splits = (g.K + kchunk - 1) / kchunk;
         grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk;
         blocks += ntiles * splits;
