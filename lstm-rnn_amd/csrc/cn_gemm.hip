@@ -383,12 +383,12 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         if (i >= n) { grp.first_block[i] = 0x7fffffff; continue; }
         const GemmTN &g = gs[i];
         const int tiles_m = (g.M + BT - 1) / BT, tiles_n = (g.N + BT - 1) / BT, ntiles = tiles_m * tiles_n;
-        // K splits: enough workgroups (~4 per CU) to hide the latency of the short per-workgroup K loops, but every
+        // K splits: enough workgroups (2-3 per CU at 64 rows of K per k-step) to hide the latency of the short per-workgroup K loops, but every
         // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
         // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
-        // (a group shares the ~1024 workgroups: its products run side by side, and their atomics add up)
+        // (a group shares the ~576 workgroups: its products run side by side, and their atomics add up)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
-        static const int target = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 1024;
+        static const int target = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 576;   // swept 256..2048 on the headline step: 512-640 best
         int splits = (int)((target + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * G::BK - 1) / (4 * G::BK);
         if (splits > maxsplit) splits = maxsplit;
