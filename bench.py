@@ -130,6 +130,7 @@ def main():
     if args.tmin is None: args.tmin = wl0.get("tmin", 250)
     if args.tmax is None: args.tmax = max(wl0.get("tmax", 350), args.tmin)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL / cross-process device memory need dmabuf IPC on this host driver
     import torch
     import torch.distributed as dist
 
