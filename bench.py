@@ -82,11 +82,16 @@ def make_weights(layers, seed):
     return out
 
 
-def synth_fraction(pkg, rng, PS, P, C, tmin, tmax):
+def synth_sequences(rng, PS, P, C, tmin, tmax):
     """i.i.d. N(0,1) features, uniform targets, lengths U[tmin,tmax] sorted ascending (DataSet.cpp:603-605)."""
     lens = np.sort(rng.randint(tmin, tmax + 1, PS))
     xs = [rng.randn(n, P).astype(np.float32) for n in lens]
     ts = [rng.randint(0, C, n).astype(np.int32) for n in lens]
+    return xs, ts
+
+
+def synth_fraction(pkg, rng, PS, P, C, tmin, tmax):
+    xs, ts = synth_sequences(rng, PS, P, C, tmin, tmax)
     return pkg.make_fraction(xs, ts, PS)
 
 
@@ -139,12 +144,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # CN_BENCH_BACKEND=gloo: test mode for boxes with fewer GPUs than ranks (ranks share devices; the reductions go
+    # through the host).  It exercises the world > 1 control flow and stream ordering with real sums; never a measurement.
+    backend = os.environ.get("CN_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     pkg = ge.load_package()
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", device_index)
     prec = pkg.PREC_BF16 if args.precision == "bf16" else pkg.PREC_F32
 
     def barrier():
@@ -161,7 +173,7 @@ def main():
         nfrac = 4
         fracs = [synth_fraction(pkg, rng, PS, P, C, args.tmin, args.tmax) for _ in range(nfrac)]
         # (the library runs on a stream of its own; net.torch_stream() is that stream for torch / RCCL ordering)
-        net = pkg.NeuralNetwork(layers, weights, PS, args.tmax, precision=prec, device=local_rank)
+        net = pkg.NeuralNetwork(layers, weights, PS, args.tmax, precision=prec, device=device_index)
         # fractions resident in HBM (torch owns the device memory)
         dfr, keep = [], []
         for f in fracs:
@@ -175,6 +187,9 @@ def main():
         overlap_allreduce = (world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1") and \
             os.environ.get("CN_BENCH_FLAT_ALLREDUCE") != "1" and dist.is_initialized()
         wptr, gptr, dptr, count = net.param_arena()
+        wts = torch.as_tensor(pkg.parallel.DeviceArray(wptr, count), device=dev)
+        net.synchronize()
+        w0 = wts.clone()                                           # initial weights, for check.update_l2 / update_sum
         grads = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device=dev) if world > 1 else None
 
         def step(i, from_host=False):
@@ -208,6 +223,18 @@ def main():
         dt = time.perf_counter() - t0
         err_sum, correct = net.loss_read()
         res = {"frames": frames, "seconds": dt, "error_sum": err_sum, "weights": int(count)}
+        # what the warm-up + timed steps did to the weights (a data-parallel run must reproduce the single-process run
+        # on the union of the ranks' fractions: tests/test_gpu_parallel.py)
+        upd = (wts.double() - w0.double())
+        res["update_l2"], res["update_sum"] = float(upd.norm()), float(upd.sum())
+        if world > 1:
+            # data-parallel replicas must stay bit-identical: same reduced gradients, same update on every rank
+            with torch.cuda.stream(net.torch_stream(torch)):
+                sig = torch.stack([wts.double().sum(), wts.double().abs().sum()])
+                lo, hi = sig.clone(), sig.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize(dev)
+            res["replicas_identical"] = bool(torch.equal(lo, hi))
         if roofline_pass:
             # second pass of the same steps with hipEvents around every kernel class, on the ctx stream
             net.timing_enable(True); net.timing_reset()
@@ -263,7 +290,7 @@ def main():
                        "weights": res["weights"], "update": "stochastic momentum SGD every fraction",
                        "parallelism": "dp%d over sequences" % world},
         }
-        out["check"] = {"error_sum": res["error_sum"], "allreduce": "per-layer, overlapped" if (world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1") and os.environ.get("CN_BENCH_FLAT_ALLREDUCE") != "1" else ("flat" if world > 1 else "none")}
+        out["check"] = {"error_sum": res["error_sum"], "update_l2": res["update_l2"], "update_sum": res["update_sum"], **({"replicas_identical": res["replicas_identical"]} if "replicas_identical" in res else {}), "allreduce": "per-layer, overlapped" if (world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1") and os.environ.get("CN_BENCH_FLAT_ALLREDUCE") != "1" else ("flat" if world > 1 else "none")}
         if "host_frames_per_s" in res:
             out["pcie_inclusive"] = {"value": res["host_frames_per_s"], "unit": "frames/s",
                                      "note": "fractions handed over as pageable host buffers (cn_fraction_load); informational"}

@@ -69,6 +69,45 @@ def test_bench_per_layer_allreduce_path_matches_plain_path():
     assert abs(sums["overlap"]["error_sum"] - sums["plain"]["error_sum"]) <= 1e-3 * abs(sums["plain"]["error_sum"])
 
 
+@pytest.mark.parametrize("flat", [False, True])
+def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
+    """bench.py with WORLD_SIZE = 2 on a one-GPU box: CN_BENCH_BACKEND=gloo lets both ranks share the device and
+    reduces through the host, so the world > 1 control flow (per-layer exchange from the communication stream, or
+    the flat exchange; barrier; max-over-ranks timing) runs with real sums.  Replicas must end bit-identical."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 250 + int(flat)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND="gloo")
+    if flat:
+        env["CN_BENCH_FLAT_ALLREDUCE"] = "1"
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp2 over sequences"
+    assert d["check"]["replicas_identical"] is True and np.isfinite(d["check"]["error_sum"])
+    assert d["check"]["allreduce"] == ("flat" if flat else "per-layer, overlapped")
+    # the same five steps in ONE process on the union of the two ranks' fractions (16 sequences per fraction): gradients
+    # are sums over patterns, so the data-parallel run must move the weights the same way.  An exchange that read a
+    # layer's gradient before it was complete, or an update that did not wait for the exchange, shows up here.
+    sys.path.insert(0, ROOT)
+    import bench
+    wl = bench.WORKLOADS["timit_3x250_blstm_H125"]
+    layers = bench.net_desc(wl["P"], wl["hidden"], wl["C"])
+    rngs = [np.random.RandomState(1234 + r) for r in range(2)]
+    union = []
+    for _ in range(4):
+        seqs = [bench.synth_sequences(rng, 8, wl["P"], wl["C"], 20, 30) for rng in rngs]
+        union.append(pkg.make_fraction(seqs[0][0] + seqs[1][0], seqs[0][1] + seqs[1][1], 16))
+    with pkg.NeuralNetwork(layers, bench.make_weights(layers, 1234), 16, 30, precision=pkg.PREC_BF16) as net:
+        w0 = np.concatenate([l.weights() for l in net.trainable_layers()]).astype(np.float64)
+        for i in (0, 1, 2, 3, 0):
+            net.load_sequences(union[i]); net.compute_forward_pass(); net.compute_backward_pass()
+            net.update_weights_fused(1e-4, 0.9)
+        upd = np.concatenate([l.weights() for l in net.trainable_layers()]).astype(np.float64) - w0
+    assert abs(d["check"]["update_l2"] - np.linalg.norm(upd)) < 2e-3 * np.linalg.norm(upd), (d["check"], np.linalg.norm(upd))
+    assert abs(d["check"]["update_sum"] - upd.sum()) < 2e-3 * np.abs(upd).sum()
+
+
 def test_per_layer_exchange_is_ordered_between_gradient_and_update(pkg):
     """Stream ordering of compute_backward_pass_allreduce (cn_layer_join_stream + a communication stream), checked
     with a stand-in for the collective that DOUBLES each layer's weightUpdates on the communication stream (what a
