@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
 void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
 {
     if (g.M <= 0 || g.N <= 0) return;
+    if (gemm_nt_big_applies(f32, g)) { launch_gemm_nt_big(s, f32, g); return; }
     int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
     int nwg = tiles_m * tiles_n;
     static DeviceOnce attr_once;

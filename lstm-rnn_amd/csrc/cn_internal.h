@@ -50,6 +50,9 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
     int M, N, K;                  // M, N multiples of 32
 };
 void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g);
+// 256 x 256 LDS-DMA variant for the MFMA-bound shapes (cn_gemm_big.hip); launch_gemm_nt dispatches to it
+bool gemm_nt_big_applies(bool f32, const GemmNT &g);
+void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g);
 void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g);
 void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n);      // up to 3 small products in one launch
 

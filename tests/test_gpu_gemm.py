@@ -1,0 +1,66 @@
+"""-m gpu: the MFMA GEMM kernels on their own (cn_dbg_gemm_nt / cn_dbg_gemm_tn), against float64 numpy products.
+The small shapes run the 128 x 128 / 64 x 64 kernels of cn_gemm.hip, the large ones the 256 x 256 LDS-DMA kernel of
+cn_gemm_big.hip (>= 384 tiles, K in whole k-tiles) and the 128 x 128 gradient tiles; M and N are deliberately not
+multiples of the tile sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    """round-to-nearest-even to bf16, returned as float32 (what the operand conversion kernel does)."""
+    u = a.astype(np.float32).view(np.uint32)
+    r = ((u >> 16) & 1) + 0x7FFF
+    return ((u + r) & 0xFFFF0000).astype(np.uint32).view(np.float32)
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    from lstm_rnn_amd import binding as B
+    return pkg.load_library(), B
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shape", [(60, 128, 32), (1000, 1024, 256), (130, 192, 96),
+                                   (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024)])
+def test_gemm_nt(lib, prec, shape):
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32); bias = rng.randn(N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, prec, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    if prec == 1:
+        A, Bm = bf16_round(A), bf16_round(Bm)
+    # (float32 matmul of the reference on sub-blocks keeps the test fast; the error budget below covers it)
+    ref = A @ Bm.T + bias
+    tol = 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
+    bad = np.abs(out - ref)
+    assert bad.max() < tol, (bad.max(), tol, np.unravel_index(bad.argmax(), bad.shape))
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("shape", [(128, 32, 60), (1024, 256, 5000), (96, 160, 333), (4000, 2080, 700)])
+def test_gemm_tn(lib, prec, shape):
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(K, M).astype(np.float32); Bm = rng.randn(K, N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, prec, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_tn(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    if prec == 1:
+        A, Bm = bf16_round(A), bf16_round(Bm)
+    ref = A.T @ Bm
+    tol = 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
+    assert np.abs(out - ref).max() < tol
