@@ -156,7 +156,9 @@ int  cn_layer_weight_count(const cn_layer *layer);
 /* Layer::loadSequences(fraction) for every layer of the stack: uploads patTypes once (the
  * reference copies them per layer, Layer.cpp:140), inputs (InputLayer.cpp:49-60) and targets /
  * target classes (PostOutputLayer.cpp:67-79, MulticlassClassificationLayer.cu:186-192).
- * Error texts follow the reference ("Input layer size of X != data input pattern size of Y"). */
+ * Error texts follow the reference ("Input layer size of X != data input pattern size of Y").
+ * The host buffers of `fraction` may be reused as soon as the call returns (they are copied into pinned staging
+ * memory; the upload itself and the re-layout kernel are asynchronous).                                [async] */
 int  cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
 
 /* The same with every pointer of `fraction` addressing DEVICE memory of the context's GPU (inputs already

@@ -939,6 +939,7 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         launch_pad_convert(ctx->stream, ctx->f32, input->stage_in, (int)N, input->size, input->out_op, input->Lp);
         ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
         ctx->loaded = true;
+        if (!resident) HIP_CHECK(hipStreamSynchronize(ctx->stream));     // the caller may reuse its host buffers on return
     });
 }
 

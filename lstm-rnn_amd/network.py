@@ -203,8 +203,8 @@ class NeuralNetwork:
             keep.append(tg)
             f.targets = tg.ctypes.data_as(C.c_void_p)
             f.output_pattern_size = int(tg.shape[-1])
+        # (the library copies the host arrays into pinned staging memory before it returns: nothing to wait for)
         B.check(self.lib.cn_fraction_load(self.ctx, self.layers[0].handle, post.handle, C.byref(f)), self.ctx)
-        B.check(self.lib.cn_ctx_synchronize(self.ctx), self.ctx)     # host arrays may go away after return
         self.T, self.Tmin = f.max_seq_length, f.min_seq_length
         self.N = self.T * self.PS
 
