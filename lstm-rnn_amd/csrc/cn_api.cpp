@@ -62,8 +62,11 @@ struct cn_ctx {
     // per backward launch); on a subset of the CUs they run longer but draw less bandwidth
     hipStream_t side_slow = nullptr;
     hipEvent_t ev_sgd = nullptr, ev_ext = nullptr;
-    std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet
+    hipEvent_t ev_pack_last = nullptr;         // = ev_pack of the last layer whose operand copies cn_sgd_update_all rebuilt (not owned)
+    std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet ...
+    std::vector<hipStream_t> pending_join_streams;   // ... and the stream each event was recorded on (same index)
     bool overlap = true;
+    bool attach_forks = true;                  // CN_NO_ATTACHED_FORKS=1: fork / join / update events recorded with hipEventRecord
     bool f32 = true;
     std::string arch;
     std::vector<cn_layer *> layers;
@@ -213,22 +216,41 @@ struct Timed {
 // the main stream waits for everything the side stream still has in flight
 void join_side(cn_ctx *c)
 {
-    for (hipEvent_t e : c->pending_joins) HIP_CHECK(hipStreamWaitEvent(c->stream, e, 0));
-    c->pending_joins.clear();
+    // events of one stream complete in order: waiting for the newest of each stream covers the older ones (a wait on an
+    // event that has long completed still costs the stream ~3 us, and these sit in front of the weight update)
+    for (size_t i = 0; i < c->pending_joins.size(); ++i) {
+        bool newest = true;
+        for (size_t j = i + 1; j < c->pending_joins.size(); ++j) newest = newest && c->pending_join_streams[j] != c->pending_join_streams[i];
+        if (newest) HIP_CHECK(hipStreamWaitEvent(c->stream, c->pending_joins[i], 0));
+    }
+    c->pending_joins.clear(); c->pending_join_streams.clear();
 }
 // run `f(stream)` on the side stream after everything enqueued on the main stream so far
-template <typename F> void on_side(cn_layer *l, F &&f)
+// (fork_attached: ev_fork already completes with the last main-stream kernel, see fork_event)
+template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = false)
 {
     cn_ctx *c = l->ctx;
-    if (!c->overlap) { f(c->stream); return; }
+    if (!c->overlap) { f(c->stream, nullptr); return; }
     if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
-    HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
+    if (!fork_attached) HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
     // a recurrent kernel follows on the main stream when the preceding layer is an LSTM layer: slow lane
     hipStream_t st = (c->side_slow && l->prev && l->prev->lstm) ? c->side_slow : c->side;
     HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
-    f(st);
-    HIP_CHECK(hipEventRecord(l->ev_join, st));
-    c->pending_joins.push_back(l->ev_join);
+    // the join event rides on the last kernel of the side work too (f returns true when it attached it)
+    const bool join_attached = f(st, (c->attach_forks && !c->timing) ? l->ev_join : nullptr);
+    if (!join_attached) HIP_CHECK(hipEventRecord(l->ev_join, st));
+    c->pending_joins.push_back(l->ev_join); c->pending_join_streams.push_back(st);
+}
+// The event the side stream forks from, to be attached to the last main-stream kernel in front of the fork (a stop
+// event of that launch, hipExtLaunchKernelGGL): a separate hipEventRecord is a marker packet between two kernels of the
+// critical path and delays the second one by ~7 us (three to four forks per training step; 1.41 -> 1.39 ms per step with
+// the fork, join and update events all riding on kernels).  nullptr: record the event the ordinary way.
+hipEvent_t fork_event(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    if (!c->overlap || !c->attach_forks) return nullptr;
+    if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
+    return l->ev_fork;
 }
 void timing_collect(cn_ctx *c)
 {
@@ -308,8 +330,10 @@ void repack(cn_layer *l)
 {
     cn_ctx *c = l->ctx;
     if (l->pack_pending) {       // rebuilt on the side stream after the last update (cn_sgd_update_all)
-        HIP_CHECK(hipStreamWaitEvent(c->stream, l->ev_pack, 0));
-        l->pack_pending = false;
+        // ONE wait, for the last copy that was rebuilt (same stream, in order: it covers every layer's); they are all
+        // done long before the second trainable layer's forward pass asks, and each wait costs the stream ~3 us
+        HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_pack_last, 0));
+        for (cn_layer *o : c->layers) o->pack_pending = false;
     }
     if (!l->dirty) return;
     Timed tm(c, KC_OTHER);
@@ -386,11 +410,18 @@ void lstm_backward(cn_layer *l)
     const int R = l->dirs * 4 * l->Hp, Hp = l->Hp, PS = c->PSp, N = c->N;
     const size_t e = c->esz();
     repack(l);
+    bool fork_attached = false;
     // (the packed gradient accumulators are zero here: allocation clears them, the unpack kernel re-clears them)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) { check_rec_lds(l, true); launch_lstm_backward(c->stream, c->f32, r); }
+        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) {
+            check_rec_lds(l, true);
+            // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
+            hipEvent_t fork = (!l->prev->trainable && !c->timing) ? fork_event(l) : nullptr;
+            launch_lstm_backward(c->stream, c->f32, r, fork);
+            fork_attached = fork != nullptr;
+        }
         HIP_CHECK(hipGetLastError());
     }
     if (l->prev->trainable) {   // K8 (LstmLayer.cu:990-1009): one K = R product instead of 4*dirs
@@ -399,11 +430,13 @@ void lstm_backward(cn_layer *l)
         g.A = l->delta_op; g.lda = R; g.B = l->WinT; g.ldb = R;
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = R;
-        launch_gemm_nt(c->stream, c->f32, g);
+        hipEvent_t fork = c->timing ? nullptr : fork_event(l);     // (timing mode records its own events around the kernel)
+        launch_gemm_nt(c->stream, c->f32, g, fork);
+        fork_attached = fork != nullptr;
     }
     // K9 runs on the side stream: it only feeds weightUpdates, forked AFTER K8 so the critical-path GEMM has the chip to itself, and running beside the
     // preceding layer's recurrent kernel (which occupies ~10 % of the CUs)
-    on_side(l, [&](hipStream_t st) {
+    on_side(l, [&](hipStream_t st, hipEvent_t join) {
         {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
             Timed tm(c, KC_GEMM_GRAD, st);
             GemmTN gs[3]; int ng = 0;
@@ -428,9 +461,10 @@ void lstm_backward(cn_layer *l)
         }
         {
             Timed tm(c, KC_OTHER, st);
-            launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu);
+            launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu, join);
         }
-    });
+        return join != nullptr;
+    }, fork_attached);
 }
 
 void ff_forward(cn_layer *l)
@@ -474,15 +508,18 @@ void ff_backward(cn_layer *l)
         }
         l->mcc_pending = false;
     }
+    bool fork_attached = false;
     if (l->prev->trainable) {   // FeedForwardLayer.cu:188-198
         Timed tm(c, KC_GEMM_WIDE);
         GemmNT g{};
         g.A = l->delta_op; g.lda = l->Lp; g.B = l->WinT; g.ldb = l->Lp;
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = l->Lp;
-        launch_gemm_nt(c->stream, c->f32, g);
+        hipEvent_t fork = c->timing ? nullptr : fork_event(l);
+        launch_gemm_nt(c->stream, c->f32, g, fork);
+        fork_attached = fork != nullptr;
     }
-    on_side(l, [&](hipStream_t st) {
+    on_side(l, [&](hipStream_t st, hipEvent_t join) {
         {   // FeedForwardLayer.cu:200-207
             Timed tm(c, KC_GEMM_GRAD, st);
             GemmTN g{};
@@ -492,9 +529,10 @@ void ff_backward(cn_layer *l)
         }
         {
             Timed tm(c, KC_OTHER, st);
-            launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu);
+            launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu, join);
         }
-    });
+        return join != nullptr;
+    }, fork_attached);
 }
 
 }  // namespace
@@ -559,6 +597,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             c->side_slow = masked_stream(device_id, ncu, prop.multiProcessorCount);
         }
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
+        if (const char *e = getenv("CN_NO_ATTACHED_FORKS")) c->attach_forks = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
         HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
@@ -629,7 +668,7 @@ int cn_layer_join(cn_layer *layer)
         for (size_t i = 0; i < c->pending_joins.size(); ++i)
             if (c->pending_joins[i] == layer->ev_join) {
                 HIP_CHECK(hipStreamWaitEvent(c->stream, layer->ev_join, 0));
-                c->pending_joins.erase(c->pending_joins.begin() + i);
+                c->pending_joins.erase(c->pending_joins.begin() + i); c->pending_join_streams.erase(c->pending_join_streams.begin() + i);
                 break;
             }
     });
@@ -809,6 +848,9 @@ int cn_layer_destroy(cn_layer *layer)
         HIP_CHECK(hipSetDevice(c->device));
         join_side(c);                                   // side-stream work of this layer may still be in flight
         HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->side) HIP_CHECK(hipStreamSynchronize(c->side));      // (operand copies being rebuilt: ev_pack_last may be this layer's)
+        for (cn_layer *o : c->layers) o->pack_pending = false;
+        c->ev_pack_last = nullptr;
         for (void *p : layer->owned) hipFree(p);
         if (layer->ev_fork) { hipEventDestroy(layer->ev_fork); hipEventDestroy(layer->ev_join); }
         if (layer->ev_pack) hipEventDestroy(layer->ev_pack);
@@ -1250,14 +1292,16 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         finalize(ctx);
         join_side(ctx);
         Timed tm(ctx, KC_OTHER);
-        launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum);
+        const bool attach = ctx->overlap && ctx->attach_forks && !ctx->timing;
+        if (ctx->overlap && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
+        launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum,
+                   attach ? ctx->ev_sgd : nullptr);
         for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
         // The operand copies of the new weights are rebuilt right away: the first trainable layer's on this stream
         // (its forward pass is next), the others on the side stream, beside the next fraction's load and the first
         // layer's forward pass; each layer's forward pass waits for its own copy (repack()).
         if (ctx->overlap) {
-            if (!ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
-            HIP_CHECK(hipEventRecord(ctx->ev_sgd, ctx->stream));
+            if (!attach) HIP_CHECK(hipEventRecord(ctx->ev_sgd, ctx->stream));
             HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_sgd, 0));
             bool first = true;
             for (cn_layer *l : ctx->layers) {
@@ -1270,6 +1314,7 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
                     else         launch_ff_pack(ctx->side, ctx->f32, ff_geom(l), l->bias, l->w, l->Win, l->WinT, l->bias_p);
                 }
                 HIP_CHECK(hipEventRecord(l->ev_pack, ctx->side));
+                ctx->ev_pack_last = l->ev_pack;
                 l->dirty = false; l->pack_pending = true;
             }
         }

@@ -125,11 +125,11 @@ __global__ void lstm_unpack_kernel(LstmGeom g, float *dWin, float *dWrec, float 
     }
 }
 
-void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu)
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu, hipEvent_t done)
 {
     long total = (long)g.L * (4 * (g.P + 1) + 4 * g.H + 3);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, s, g, dWin, dWrec, dbias, dpeep, wu);
+    hipExtLaunchKernelGGL(lstm_unpack_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g, dWin, dWrec, dbias, dpeep, wu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -175,11 +175,11 @@ __global__ void ff_unpack_kernel(FfGeom g, float bias, float *dW, float *colsum,
         }
     }
 }
-void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu)
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu, hipEvent_t done)
 {
     long total = (long)g.L * (g.P + 1);
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(ff_unpack_kernel, dim3(blocks), dim3(256), 0, s, g, bias, dW, colsum, wu);
+    hipExtLaunchKernelGGL(ff_unpack_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, g, bias, dW, colsum, wu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -834,11 +834,11 @@ __global__ void sgd_kernel(float *w, const float *wu, float *wd, size_t n, float
         w[i] = __fadd_rn(w[i], dl);                               // :55
     }
 }
-void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom)
+void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done)
 {
     if (n == 0) return;
     int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, s, w, wu, wd, n, lr, mom);
+    hipExtLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, w, wu, wd, n, lr, mom);
 }
 
 }  // namespace cn

@@ -195,10 +195,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     }
 }
 
-void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
+void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done)
 {
     if (g.M <= 0 || g.N <= 0) return;
-    if (gemm_nt_big_applies(f32, g)) { launch_gemm_nt_big(s, f32, g); return; }
+    if (gemm_nt_big_applies(f32, g)) { launch_gemm_nt_big(s, f32, g, done); return; }
     int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
     int nwg = tiles_m * tiles_n;
     static DeviceOnce attr_once;
@@ -206,8 +206,8 @@ void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g)
         (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     }
-    if (f32) hipLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
-    else     hipLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, g, tiles_n, nwg);
+    if (f32) hipExtLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    else     hipExtLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -189,7 +189,7 @@ bool gemm_nt_big_applies(bool f32, const GemmNT &g)
     return tiles >= 384;
 }
 
-void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g)
+void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done)
 {
     const int tiles_m = (g.M + BG_BM - 1) / BG_BM, tiles_n = (g.N + BG_BN - 1) / BG_BN, nwg = tiles_m * tiles_n;
     static DeviceOnce attr_once;
@@ -197,8 +197,8 @@ void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g)
         (void)hipFuncSetAttribute((const void *)gemm_nt_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
         (void)hipFuncSetAttribute((const void *)gemm_nt_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_LDS);
     }
-    if (f32) hipLaunchKernelGGL(gemm_nt_big_kernel<true>, dim3(nwg), dim3(512), BG_LDS, s, g, tiles_n, nwg);
-    else     hipLaunchKernelGGL(gemm_nt_big_kernel<false>, dim3(nwg), dim3(512), BG_LDS, s, g, tiles_n, nwg);
+    if (f32) hipExtLaunchKernelGGL(gemm_nt_big_kernel<true>, dim3(nwg), dim3(512), BG_LDS, s, nullptr, done, 0, g, tiles_n, nwg);
+    else     hipExtLaunchKernelGGL(gemm_nt_big_kernel<false>, dim3(nwg), dim3(512), BG_LDS, s, nullptr, done, 0, g, tiles_n, nwg);
 }
 
 }  // namespace cn

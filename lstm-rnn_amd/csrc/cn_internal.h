@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -49,10 +50,12 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
     float *C; long ldc;           // [M][N] fp32, pre-zeroed
     int M, N, K;                  // M, N multiples of 32
 };
-void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g);
+// `done`: optional event that completes with the kernel itself (hipExtLaunchKernelGGL stop event): a fork point for
+// another stream without a marker packet on this stream (an hipEventRecord between two kernels costs the second one ~7 us)
+void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done = nullptr);
 // 256 x 256 LDS-DMA variant for the MFMA-bound shapes (cn_gemm_big.hip); launch_gemm_nt dispatches to it
 bool gemm_nt_big_applies(bool f32, const GemmNT &g);
-void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g);
+void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done = nullptr);
 void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g);
 void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n);      // up to 3 small products in one launch
 
@@ -80,7 +83,7 @@ struct LstmRec {
 };
 size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T);       // dynamic LDS per workgroup of the single-CU kernels
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
-void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p);
+void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
 size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl);
 bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p);
@@ -93,11 +96,11 @@ void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, co
                       void *Win, void *WinT, void *Wrec, void *WrecT, float *bias_p, float *peep_p);
 // packed fp32 gradients -> flat reference layout
 // (the packed accumulators are cleared as they are read)
-void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu);
+void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu, hipEvent_t done = nullptr);
 struct FfGeom { int P, Pp, L, Lp; int prevH, prevHp, prevDirs; };
 void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w,
                     void *W, void *WT, float *bias_p);
-void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu);
+void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu, hipEvent_t done = nullptr);
 
 // inputs [N][P] fp32 (reference layout) -> [N][Pp] op, zero padded
 void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
@@ -127,7 +130,7 @@ void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int 
 void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
 // sse
 // UpdateWeightFn over a flat range
-void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom);
+void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
 // (host row n = t*PS + s maps to device row t*PSp + s)
 void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp);

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
 // launchers
 // ---------------------------------------------------------------------------------------------
 template <bool F32, bool BWD, int HP, int UG, int RPL>
-static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
+static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t done)
 {
     const int ELT = F32 ? 4 : 2;
     const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
@@ -606,45 +606,45 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves)
     // 229 us per backward launch in the step timeline); the GEMMs lose 26 of 256 CUs instead.
     size_t lds_claim = lds;
     if (p.dirs * nsg <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
-    hipLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, p);
+    hipExtLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
 }
 
 template <bool F32, bool BWD, int HP, int UG>
-static void launch_rpl(hipStream_t s, const LstmRec &p, int nwaves)
+static void launch_rpl(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t done)
 {
-    if (p.rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves);
-    else if (p.rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves);
-    else               launch_one<F32, BWD, HP, UG, 4>(s, p, nwaves);
+    if (p.rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves, done);
+    else if (p.rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves, done);
+    else               launch_one<F32, BWD, HP, UG, 4>(s, p, nwaves, done);
 }
 
 template <bool F32, bool BWD>
-static void launch_rec(hipStream_t s, const LstmRec &p)
+static void launch_rec(hipStream_t s, const LstmRec &p, hipEvent_t done = nullptr)
 {
     const int groups = p.Hp / 16;
     switch (p.Hp) {
-    case 32:  launch_rpl<F32, BWD, 32, 1>(s, p, 2); return;
-    case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4); return;
-    case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6); return;
+    case 32:  launch_rpl<F32, BWD, 32, 1>(s, p, 2, done); return;
+    case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4, done); return;
+    case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6, done); return;
     case 128:
         // 8 waves x 1 unit group (two waves per SIMD overlap each other's MFMA, VALU and scalar issue).  For the
         // backward kernel 4 waves x 2 unit groups (half the LDS operand reads: every wave reads the whole
         // 16 x 4Hp delta tile) used to win by 4 %; since the stage copies removed the latch stall it loses:
         // 0.64 vs 0.56 us per step (CN_BWD_UG2 keeps it selectable)
-        if (BWD && !F32 && getenv("CN_BWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);
-        else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4);   // measured slower: 0.63 vs 0.47 us per step
-        else launch_rpl<F32, BWD, 128, 1>(s, p, 8);
+        if (BWD && !F32 && getenv("CN_BWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4, done);
+        else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4, done);   // measured slower: 0.63 vs 0.47 us per step
+        else launch_rpl<F32, BWD, 128, 1>(s, p, 8, done);
         return;
     case 160:     // bf16 only: 200 / 288 KB of W_rec still fit one CU's registers (10 / 12 waves, three on some SIMDs)
-        if constexpr (!F32) { launch_rpl<F32, BWD, 160, 1>(s, p, 10); return; }
+        if constexpr (!F32) { launch_rpl<F32, BWD, 160, 1>(s, p, 10, done); return; }
         break;
     case 192:
-        if constexpr (!F32) { launch_rpl<F32, BWD, 192, 1>(s, p, 12); return; }
+        if constexpr (!F32) { launch_rpl<F32, BWD, 192, 1>(s, p, 12, done); return; }
         break;
     default: break;
     }
-    if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups);
-    else if (groups <= 32) launch_rpl<F32, BWD, 0, 2>(s, p, groups / 2);
-    else                   launch_rpl<F32, BWD, 0, 4>(s, p, groups / 4);
+    if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups, done);
+    else if (groups <= 32) launch_rpl<F32, BWD, 0, 2>(s, p, groups / 2, done);
+    else                   launch_rpl<F32, BWD, 0, 4>(s, p, groups / 4, done);
 }
 
 #ifdef CN_STAMP
@@ -668,9 +668,9 @@ void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
 {
     if (f32) launch_rec<true, false>(s, p); else launch_rec<false, false>(s, p);
 }
-void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p)
+void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p, hipEvent_t done)
 {
-    if (f32) launch_rec<true, true>(s, p); else launch_rec<false, true>(s, p);
+    if (f32) launch_rec<true, true>(s, p, done); else launch_rec<false, true>(s, p, done);
 }
 
 }  // namespace cn
