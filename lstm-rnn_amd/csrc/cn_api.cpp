@@ -231,6 +231,10 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
 {
     cn_ctx *c = l->ctx;
     if (!c->overlap) { f(c->stream, nullptr); return; }
+    // The first trainable layer's gradient work has nothing to run beside: only the weight update follows.  On the main
+    // stream it saves the two cross-stream hand-offs (fork, join) in front of the update.
+    static const bool tail_on_main = getenv("CN_TAIL_ON_SIDE") == nullptr;
+    if (tail_on_main && l->prev && !l->prev->trainable && !fork_attached) { f(c->stream, nullptr); return; }
     if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
     if (!fork_attached) HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
     // a recurrent kernel follows on the main stream when the preceding layer is an LSTM layer: slow lane
@@ -418,7 +422,8 @@ void lstm_backward(cn_layer *l)
         if (!launch_lstm_cluster(c->stream, c->f32, true, r)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
-            hipEvent_t fork = (!l->prev->trainable && !c->timing) ? fork_event(l) : nullptr;
+            static const bool tail_on_side = getenv("CN_TAIL_ON_SIDE") != nullptr;
+            hipEvent_t fork = (tail_on_side && !l->prev->trainable && !c->timing) ? fork_event(l) : nullptr;
             launch_lstm_backward(c->stream, c->f32, r, fork);
             fork_attached = fork != nullptr;
         }
