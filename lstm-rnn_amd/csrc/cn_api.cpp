@@ -82,6 +82,7 @@ struct cn_ctx {
     float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
     float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
     unsigned long long *d_xch = nullptr; size_t xch_bytes = 0;   // cluster kernels' exchange granules
+    unsigned xch_epoch = 0;       // granule tags handed out so far (LstmRec::xch_epoch)
     int *d_fault = nullptr;       // device fault word (bounded spins)
     float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
     cn_layer *rowstat_of = nullptr;
@@ -373,6 +374,9 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.bias = l->bias;
     r.rpl = c->rpl;
     r.xch = c->d_xch; r.fault = c->d_fault;
+    // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
+    if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }
+    r.xch_epoch = c->xch_epoch;
 }
 
 // the single-CU recurrent kernels keep two operand tiles (and, backward, one byte per time step and sequence) in LDS
@@ -403,7 +407,8 @@ void lstm_forward(cn_layer *l)
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, false, r)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
+        if (launch_lstm_cluster(c->stream, c->f32, false, r)) c->xch_epoch += (unsigned)c->T + 1;
+        else { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -419,7 +424,8 @@ void lstm_backward(cn_layer *l)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, true, r)) {
+        if (launch_lstm_cluster(c->stream, c->f32, true, r)) c->xch_epoch += (unsigned)c->T + 1;
+        else {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
             static const bool tail_on_side = getenv("CN_TAIL_ON_SIDE") != nullptr;
@@ -787,7 +793,8 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
                 if (xb > ctx->xch_bytes) {
                     if (ctx->d_xch) HIP_CHECK(hipFree(ctx->d_xch));
                     HIP_CHECK(hipMalloc((void **)&ctx->d_xch, xb));
-                    ctx->xch_bytes = xb;
+                    HIP_CHECK(hipMemsetAsync(ctx->d_xch, 0, xb, ctx->stream));
+                    ctx->xch_bytes = xb; ctx->xch_epoch = 0;
                 }
             }
             break; }

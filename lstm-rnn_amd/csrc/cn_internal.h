@@ -78,7 +78,8 @@ struct LstmRec {
     float bias;                   // JSON bias value (scales the bias gradient)
     int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
     // multi-CU cluster kernels (cn_lstm_cluster.hip)
-    unsigned long long *xch;      // exchange granules, zeroed per launch (nullable: cluster path off)
+    unsigned long long *xch;      // exchange granules (nullable: cluster path off), zeroed at allocation
+    unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T; the caller advances it by T + 1 per launch
     int *fault;                   // set to 1 by a bounded spin that gave up
 };
 size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T);       // dynamic LDS per workgroup of the single-CU kernels

@@ -11,7 +11,7 @@
 // value as ONE naturally aligned 8-byte granule {tag = step + 1, value} with a relaxed agent-scope atomic store
 // (sc1, write-through); the consumer re-reads the granule with relaxed agent-scope atomic loads (sc1, bypasses
 // the per-CU L1) until the tag matches -- no fences, placement independent.  Granule slots alternate with the
-// step parity: a producer can only overwrite slot p at step t+2 after it has consumed its partners' step t+1,
+// step parity (tags count on across launches, LstmRec::xch_epoch): a producer can only overwrite slot p at step t+2 after it has consumed its partners' step t+1,
 // which they published after consuming its step t from that very slot.  The exchange buffer is zeroed before
 // every launch (tags restart at 1); every spin is bounded and reports through a fault word instead of hanging.
 // Cluster members sit 8 block ids apart (same XCD under round-robin placement: speed only, never correctness);
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) slots[j * RPL + r] = xprev + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
-            consume_all<(CS - 1) * RPL>(slots, it, p.fault, vals, gaveup);
+            consume_all<(CS - 1) * RPL>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const __bf16 yb = (__bf16)(dummy ? 0.f : y);
             cst[r] = co;
             // hand y[t] of this unit to the partners first (it is on their critical path), then keep it here
-            publish(xslot + (long)member * (RPL * NT) + r * NT + tid, it + 1, __builtin_bit_cast(unsigned short, yb));
+            publish(xslot + (long)member * (RPL * NT) + r * NT + tid, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned short, yb));
             *(__bf16 *)(ynxt + (4 * q + r) * pitch + lunit * 2) = yb;       // the tile is member-relative: own units first
             const f32x4 av = {ni, ig, fg, og};
             *(f32x4 *)(actsT + oA[r]) = av;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                     const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * 2 * NT) + (r * 2) * NT + tid;
                     slots[(j * RPL + r) * 2] = theirs; slots[(j * RPL + r) * 2 + 1] = theirs + NT;
                 }
-            consume_all<(CS - 1) * RPL * 2>(slots, it, p.fault, vals, gaveup);
+            consume_all<(CS - 1) * RPL * 2>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -375,8 +375,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             const u64 bits = __builtin_bit_cast(u64, dv);
             {
                 u64 *mine = xslot + (long)member * (RPL * 2 * NT) + (r * 2) * NT + tid;
-                publish(mine, it + 1, (unsigned)bits);
-                publish(mine + NT, it + 1, (unsigned)(bits >> 32));
+                publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
+                publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
             }
             *(bf16x4 *)(dnxt + (4 * q + r) * pitch + lunit * 8) = dv;        // member-relative tile: own units first
             *(bf16x4 *)(deltaT + oA[r]) = dv;
@@ -416,7 +416,10 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     const int grid = (nclusters + 7) / 8 * 8 * CS;
     const size_t lds = 2 * 16 * (size_t)lds_pitch((BWD ? 4 : 1) * HP * 2);
     const size_t xbytes = (size_t)nclusters * 2 * CS * RPL * (BWD ? 2 : 1) * NT * sizeof(u64);
-    (void)hipMemsetAsync(p.xch, 0, xbytes, s);       // tags restart at 1 every launch
+    // (no clearing per launch: tags continue from LstmRec::xch_epoch, which the caller advances by T + 1 per launch, so
+    // the granules a previous launch left behind never match; the memset kernel and its stream bubble cost ~7 us per
+    // layer pass)
+    (void)xbytes;
     auto kern = BWD ? lstm_bwd_cluster_kernel<HP, UPC, RPL> : lstm_fwd_cluster_kernel<HP, UPC, RPL>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
