@@ -616,15 +616,19 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
 }
 // The same fusion for wide rows (256 < Lp <= 8192): one workgroup walks rows blockIdx.x, blockIdx.x + grid, ...; a thread
-// owns columns tid + 256 k and keeps their sums in registers; one atomic per column and workgroup at the end.
+// owns the four columns 4 (tid + 256 k) .. + 3 of every k (16-byte loads and stores, 8-byte bf16 stores) and keeps their
+// sums in registers; one atomic per column and workgroup at the end.
 template <bool F32>
 __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                                                                    float *err, void *delta_op, float *colsum)
 {
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    constexpr int NV = SMW_VPT / 4;                       // 4-column groups per thread
     const int tid = threadIdx.x;
-    float cs[SMW_VPT];
+    f32x4 cs[NV];
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) cs[k] = 0.f;
+    for (int k = 0; k < NV; ++k) cs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long row = blockIdx.x; row < N; row += gridDim.x) {
         const int tc = tcls[row];
         const bool real = pat[row] != 0;
@@ -632,18 +636,28 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
         float et = 0.f, off = 0.f;
         if (real && tc >= 0) { const float pt_ = yr[tc]; et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
 #pragma unroll
-        for (int k = 0; k < SMW_VPT; ++k) {
-            const int j = tid + 256 * k;
+        for (int k = 0; k < NV; ++k) {
+            const int j = 4 * (tid + 256 * k);
             if (j >= Lp) break;
-            float dl = 0.f;
-            if (real && j < L) dl = yr[j] * ((j == tc ? et : 0.f) - off);
-            err[row * Lp + j] = dl;
-            if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
+            f32x4 dl = {0.f, 0.f, 0.f, 0.f};
+            if (real) {
+                const f32x4 yv = *(const f32x4 *)(yr + j);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (j + e < L) dl[e] = yv[e] * ((j + e == tc ? et : 0.f) - off);
+            }
+            *(f32x4 *)(err + row * Lp + j) = dl;
+            if constexpr (!F32) *(bf16x4 *)((__bf16 *)delta_op + row * Lp + j) = bf16x4{(__bf16)dl[0], (__bf16)dl[1], (__bf16)dl[2], (__bf16)dl[3]};
             cs[k] += dl;
         }
     }
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) { const int j = tid + 256 * k; if (j < Lp) atomicAdd(&colsum[j], cs[k]); }
+    for (int k = 0; k < NV; ++k) {
+        const int j = 4 * (tid + 256 * k);
+        if (j < Lp) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&colsum[j + e], cs[k][e]);
+        }
+    }
 }
 
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
