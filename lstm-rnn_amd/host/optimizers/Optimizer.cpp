@@ -46,15 +46,17 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     const bool classification = dynamic_cast<layers::MulticlassClassificationLayer *>(&m_neuralNetwork.postOutputLayer()) != 0 ||
                                 dynamic_cast<layers::BinaryClassificationLayer *>(&m_neuralNetwork.postOutputLayer()) != 0;   // Optimizer.cu:52-55
 
+    // The reference reads the error of every fraction back (calculateError + countCorrectClassifications,
+    // Optimizer.cu:46-55), which synchronises host and device once per fraction.  Here the per-fraction terms are
+    // added up on the device, in the same order and in float like the reference's `error += ...`, and read back once
+    // per pass over the data set: the host keeps enqueueing fractions while the device works.
+    hipCheck(cn_loss_read(m_neuralNetwork.context(), nullptr, nullptr, 1), m_neuralNetwork.context());     // clear the sums
     data_sets::DataSetFraction frac;
     bool firstFraction = true;
     while (ds.getNextFraction(&frac)) {
         m_neuralNetwork.loadSequences(frac);
         m_neuralNetwork.computeForwardPass();
-        float e = 0; int correct = 0;
-        hipCheck(cn_loss_eval(m_neuralNetwork.postOutputLayer().handle(), &e, &correct), m_neuralNetwork.context());   // Optimizer.cu:46-55
-        error += e;
-        if (classification) *classError -= (real_t)correct;
+        hipCheck(cn_loss_accumulate(m_neuralNetwork.postOutputLayer().handle()), m_neuralNetwork.context());
 
         if (calcWeightUpdates) {
             // weight noise: the forward pass above used the clean weights, the backward pass runs on noisy ones
@@ -96,6 +98,12 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
         firstFraction = false;
     }
     if (calcWeightUpdates && !m_hybridOnlineBatch) _updateWeights();
+    {
+        float e = 0; long correct = 0;
+        hipCheck(cn_loss_read(m_neuralNetwork.context(), &e, &correct, 1), m_neuralNetwork.context());
+        error = e;
+        if (classification) *classError -= (real_t)correct;
+    }
     error /= ds.totalSequences();                                           // :99-101
     *classError /= (real_t)ds.totalTimesteps();
     return error;
