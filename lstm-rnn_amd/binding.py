@@ -1,6 +1,8 @@
 """ctypes binding of include/currennt_hip.h (one declaration per exported symbol)."""
 import ctypes as C
+import importlib.util
 import os
+import sys
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -73,6 +75,11 @@ def load_library():
     if not os.path.exists(path):
         raise CurrenntHipError(-5, "libcurrennt_hip.so is not built (run __graft_entry__.build()); "
                                    "there is no CPU fallback for the HIP path")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, the library is linked against the system's.
+    # Whichever is loaded first serves both (same SONAME); when the system's comes first, torch later reports
+    # "No HIP GPUs are available".  So a process that can import torch loads torch's runtime before the library.
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None and not os.environ.get("CURRENNT_HIP_NO_TORCH_PRELOAD"):
+        import torch  # noqa: F401
     L = C.CDLL(path)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.cn_ctx_create.argtypes = [ci, ci, vp, C.POINTER(vp)]
