@@ -1304,15 +1304,33 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         finalize(ctx);
         join_side(ctx);
         Timed tm(ctx, KC_OTHER);
-        const bool attach = ctx->overlap && ctx->attach_forks && !ctx->timing;
-        if (ctx->overlap && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
+        int ntrain = 0;
+        for (cn_layer *l : ctx->layers) if (l->trainable) ++ntrain;
+        // The operand copies of the new weights are rebuilt right away, all layers in ONE launch on this stream
+        // (pack_group_kernel): it costs about as much as the first layer's copy alone did, which was on the critical
+        // path anyway, and the other layers' copies no longer need a fork event, the side stream and a wait.
+        static const bool group_off = getenv("CN_NO_PACK_GROUP") != nullptr;
+        const bool grouped = ctx->overlap && !group_off && ntrain <= PACK_GROUP_MAX;
+        const bool attach = ctx->overlap && !grouped && ctx->attach_forks && !ctx->timing;
+        if (ctx->overlap && !grouped && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
         launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum,
                    attach ? ctx->ev_sgd : nullptr);
         for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
-        // The operand copies of the new weights are rebuilt right away: the first trainable layer's on this stream
-        // (its forward pass is next), the others on the side stream, beside the next fraction's load and the first
-        // layer's forward pass; each layer's forward pass waits for its own copy (repack()).
-        if (ctx->overlap) {
+        if (grouped) {
+            PackGroup grp{};
+            for (cn_layer *l : ctx->layers) {
+                if (!l->trainable) continue;
+                PackItem &it = grp.item[grp.n++];
+                it.lstm = l->lstm ? 1 : 0;
+                if (l->lstm) it.lg = lstm_geom(l); else it.fg = ff_geom(l);
+                it.bias = l->bias; it.w = l->w; it.Win = l->Win; it.WinT = l->WinT; it.Wrec = l->Wrec; it.WrecT = l->WrecT;
+                it.bias_p = l->bias_p; it.peep_p = l->peep_p;
+                l->dirty = false; l->pack_pending = false;
+            }
+            launch_pack_group(ctx->stream, ctx->f32, grp);
+        } else if (ctx->overlap) {
+            // (more layers than one group launch takes: the first trainable layer's copy on this stream, its forward pass
+            // is next; the others on the side stream, each layer's forward pass waits for them in repack())
             if (!attach) HIP_CHECK(hipEventRecord(ctx->ev_sgd, ctx->stream));
             HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev_sgd, 0));
             bool first = true;

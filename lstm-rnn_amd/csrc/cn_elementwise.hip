@@ -42,15 +42,16 @@ __device__ __forceinline__ int pad_col(int i, int prevH, int prevHp)
 // ---------------------------------------------------------------------------------------------
 // LSTM weight packing (flat layout: LstmLayer.hpp:36-55, LstmLayer.cu:535-541,583-596)
 // ---------------------------------------------------------------------------------------------
+// (first / count: the workgroups [first, first + count) of the launch work on this layer: pack_group_kernel)
 template <bool F32>
-__global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *Win, void *WinT,
-                                 void *Wrec, void *WrecT, float *bias_p, float *peep_p)
+__device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, const float *w, void *Win, void *WinT,
+                                               void *Wrec, void *WrecT, float *bias_p, float *peep_p, int first, int count)
 {
     const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp, dirs = g.dirs;
     const long R = (long)dirs * 4 * Hp;                 // packed gate rows
     const long nIn = R * Pp, nRec = (long)dirs * 4 * Hp * Hp, nB = (long)dirs * 4 * Hp, nPe = (long)dirs * 3 * Hp;
     const long total = nIn + nRec + nB + nPe;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (blockIdx.x - first) * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)count * blockDim.x) {
         if (idx < nIn) {
             // packed gate row r = (d*Hp + j)*4 + gate: a lane of the recurrent kernels moves n/i/f/o of
             // one unit with a single 16-byte access
@@ -80,6 +81,12 @@ __global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *W
             peep_p[k] = (j < H) ? w[4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j] : 0.f;
         }
     }
+}
+template <bool F32>
+__global__ void lstm_pack_kernel(LstmGeom g, float bias, const float *w, void *Win, void *WinT,
+                                 void *Wrec, void *WrecT, float *bias_p, float *peep_p)
+{
+    lstm_pack_body<F32>(g, bias, w, Win, WinT, Wrec, WrecT, bias_p, peep_p, 0, gridDim.x);
 }
 
 void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, const float *w,
@@ -137,10 +144,10 @@ void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, flo
 // FeedForwardLayer.cu:148,160)
 // ---------------------------------------------------------------------------------------------
 template <bool F32>
-__global__ void ff_pack_kernel(FfGeom g, float bias, const float *w, void *W, void *WT, float *bias_p)
+__device__ __forceinline__ void ff_pack_body(const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p, int first, int count)
 {
     const long nW = (long)g.Lp * g.Pp, total = nW + g.Lp;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = (blockIdx.x - first) * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)count * blockDim.x) {
         if (idx < nW) {
             const int j = idx / g.Pp, pc = idx % g.Pp;
             const int i = unpad_col(pc, g.P, g.prevH, g.prevHp, g.prevDirs);
@@ -152,6 +159,39 @@ __global__ void ff_pack_kernel(FfGeom g, float bias, const float *w, void *W, vo
             bias_p[j] = (j < g.L) ? bias * w[(long)g.L * g.P + j] : 0.f;            // FeedForwardLayer.cu:59
         }
     }
+}
+template <bool F32>
+__global__ void ff_pack_kernel(FfGeom g, float bias, const float *w, void *W, void *WT, float *bias_p)
+{
+    ff_pack_body<F32>(g, bias, w, W, WT, bias_p, 0, gridDim.x);
+}
+
+// Every trainable layer's operand copies in ONE launch (after cn_sgd_update_all): four launches of 4-9 us each were
+// either on the critical path (the first layer's) or cost a fork event, a side stream and a wait (the others').
+template <bool F32>
+__global__ void pack_group_kernel(PackGroup grp)
+{
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < PACK_GROUP_MAX; ++k) if (k < grp.n && (int)blockIdx.x >= grp.first[k]) i = k;
+    const PackItem &it = grp.item[i];
+    const int count = (i + 1 < grp.n ? grp.first[i + 1] : (int)gridDim.x) - grp.first[i];
+    if (it.lstm) lstm_pack_body<F32>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count);
+    else         ff_pack_body<F32>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count);
+}
+void launch_pack_group(hipStream_t s, bool f32, PackGroup &grp, hipEvent_t done)
+{
+    int blocks = 0;
+    for (int i = 0; i < grp.n; ++i) {
+        const PackItem &it = grp.item[i];
+        const long total = it.lstm ? (long)it.lg.dirs * 4 * it.lg.Hp * (it.lg.Pp + it.lg.Hp + 1) + (long)it.lg.dirs * 3 * it.lg.Hp
+                                   : (long)it.fg.Lp * it.fg.Pp + it.fg.Lp;
+        int b = (int)((total + 255) / 256); if (b > 1024) b = 1024;
+        grp.first[i] = blocks; blocks += b;
+    }
+    if (blocks == 0) return;
+    if (f32) hipExtLaunchKernelGGL(pack_group_kernel<true>, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, grp);
+    else     hipExtLaunchKernelGGL(pack_group_kernel<false>, dim3(blocks), dim3(256), 0, s, nullptr, done, 0, grp);
 }
 void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p)
 {

@@ -99,6 +99,14 @@ void launch_lstm_pack(hipStream_t s, bool f32, const LstmGeom &g, float bias, co
 // (the packed accumulators are cleared as they are read)
 void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, float *dWrec, float *dbias, float *dpeep, float *wu, hipEvent_t done = nullptr);
 struct FfGeom { int P, Pp, L, Lp; int prevH, prevHp, prevDirs; };
+// all trainable layers' operand copies in one launch
+constexpr int PACK_GROUP_MAX = 8;
+struct PackItem {
+    int lstm; LstmGeom lg; FfGeom fg; float bias; const float *w;
+    void *Win, *WinT, *Wrec, *WrecT; float *bias_p, *peep_p;
+};
+struct PackGroup { PackItem item[PACK_GROUP_MAX]; int first[PACK_GROUP_MAX]; int n; };
+void launch_pack_group(hipStream_t s, bool f32, PackGroup &grp, hipEvent_t done = nullptr);
 void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const float *w,
                     void *W, void *WT, float *bias_p);
 void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu, hipEvent_t done = nullptr);
