@@ -33,6 +33,24 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads (tests only; bench.py's cpu_baseline stays at 1 = the reference's single-threaded Thrust-host build,
+ * CMakeLists.txt:11-13).  Work is split over OUTPUT elements only: every sum still runs serially over k on one
+ * thread in the reference's order, so results are bit-identical for any thread count. */
+static int g_threads = 1;
+void orc_set_threads(int n)
+{
+    g_threads = n > 0 ? n : 1;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#endif
+}
+int orc_get_threads(void) { return g_threads; }
+#define ORC_PAR(work) const long orc_work_ = (long)(work); (void)orc_work_; \
+    _Pragma("omp parallel for schedule(static) if (g_threads > 1 && orc_work_ > 20000)")
 
 typedef float real_t;
 
@@ -117,6 +135,7 @@ static void mm_nn(real_t *c, const real_t *a, int rowsA, int colsA,
                   const real_t *b, int rowsB, int colsB, int add)
 {
     int total = rowsA * colsB;
+    ORC_PAR((long)total * colsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offRowA = a + (idx % rowsA);
         const real_t *offColB = b + (idx / rowsA) * rowsB;
@@ -133,6 +152,7 @@ static void mm_tn(real_t *c, const real_t *a, int rowsA, int colsA,
                   const real_t *b, int rowsB, int colsB, int add)
 {
     int total = colsA * colsB;
+    ORC_PAR((long)total * rowsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offColA = a + (idx % colsA) * rowsA;
         const real_t *offColB = b + (idx / colsA) * rowsB;
@@ -150,6 +170,7 @@ static void mm_nt(real_t *c, const real_t *a, int rowsA, int colsA,
 {
     (void)colsB;
     int total = rowsA * rowsB;
+    ORC_PAR((long)total * colsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offRowA = a + (idx % rowsA);
         const real_t *offRowB = b + (idx / rowsA);
@@ -567,6 +588,7 @@ void orc_lstm_backward(int P, int L, int bidir, real_t bias, int PS, int maxT, i
 
     /* :1012-1044 weight updates */
     int nw = orc_lstm_weight_count(P, L, bidir);
+    ORC_PAR((long)nw * N)
     for (int i = 0; i < nw; ++i)
         wu[i] = weight_update(&l, x, i);
 }

@@ -68,8 +68,22 @@ def lib():
     L.orc_binary_correct.argtypes = [ci, i8p, f32p, f32p]
     L.orc_binary_correct.restype = ci
     L.orc_post_backward.argtypes = [ci, ci, ci, i8p, f32p, f32p, f32p]
+    L.orc_set_threads.argtypes = [ci]
+    L.orc_get_threads.restype = ci
+    L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", "1")))
     _lib = L
     return L
+
+
+def set_threads(n):
+    """Worker threads of the oracle (default 1 = the reference's single-threaded Thrust-host build).  Outputs are
+    split over threads, every sum stays serial in the reference's order: results are bit-identical for any n.
+    The test suite raises it so that config-size cases finish in seconds; bench.py's cpu_baseline keeps 1."""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().orc_get_threads())
 
 
 def _ptr(a):

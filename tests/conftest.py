@@ -23,6 +23,8 @@ def pkg():
 def orc():
     mod = ge.load_oracle()
     mod.lib()
+    # (bit-identical for any thread count: oracle.set_threads; bench.py's cpu_baseline leg keeps 1 thread)
+    mod.set_threads(min(32, len(os.sched_getaffinity(0))))
     return mod
 
 

@@ -1,0 +1,209 @@
+"""-m gpu parity tests at the sizes BASELINE.json's `configs` name ("configs not exercised"):
+
+  configs[0]  39 -> lstm128 -> softmax183                       (examples/phoneme_recognition_timit topology)
+  configs[2]  39 -> blstm156 -> blstm300 -> blstm102 -> softmax51   (examples/speech_recognition_chime/
+              no_subsampling/network.jsn, on KAT-0's real CHiME frames)
+  configs[3]  40 -> 4 x blstm512 -> softmax8000                  (synthetic LVCSR; first test of the C = 8000 kernels)
+  configs[4]  39 -> blstm1024 -> softmax183 at T = 2000, and 5 x blstm1024 at T = 2000 (cluster kernels,
+              LDS dummy table T*4*RPL, 32-bit xch_epoch accumulation)
+
+All through the C ABI against the CPU oracle on the same seeded inputs.  fp32 parity mode uses the standard
+tolerances (posterior max-abs < 1e-4 = BASELINE.json north star, gradients < 2e-4 of the layer's max); bf16
+throughput mode uses the bf16 tolerances of test_bf16_mode_close.  Reference call sequences being matched:
+LstmLayer.cu:763-1051, SoftmaxLayer.cu:250-353, MulticlassClassificationLayer.cu:159-240."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_kat0, net_desc, random_sequences, random_weights, real_mask
+from test_gpu_parity import POSTERIOR_TOL, check_network, rel_err, run_both
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config0_literal_lstm128_softmax183(pkg, orc):
+    """BASELINE configs[0]: 39 -> lstm 128 -> softmax 183, ragged lengths, a partial fraction (one unused slot)."""
+    rng = np.random.RandomState(50)
+    P, C, PS = 39, 183, 8
+    layers = net_desc(P, [("lstm", 128)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, [60, 57, 57, 49, 41, 33, 20], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    with net:
+        # three momentum steps on the same fraction: weights track the oracle (Q10)
+        for step in range(3):
+            for n in (ref, net):
+                if step:
+                    n.load_sequences(frac); n.compute_forward_pass(); n.compute_backward_pass()
+            ref.update_weights(1e-3, 0.9); net.update_weights(1e-3, 0.9)
+            for lay in net.trainable_layers():
+                assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
+
+
+CHIME_LAYERS = [("blstm", 156), ("blstm", 300), ("blstm", 102)]
+
+
+def chime_fraction(pkg):
+    _, _, xs, ts = load_kat0()              # first 10 sequences of val_1_speaker.nc, 39-d, 51 classes
+    return xs, ts, pkg.make_fraction(xs, ts, 10)
+
+
+def test_config2_literal_chime_network_fp32(pkg, orc):
+    """BASELINE configs[2]: the literal CHiME example topology (no_subsampling/network.jsn) in fp32 parity mode on
+    KAT-0's real CHiME frames (T = 152, 1 345 real frames, 175 dummy slots)."""
+    rng = np.random.RandomState(51)
+    layers = net_desc(39, CHIME_LAYERS, 51)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts, frac = chime_fraction(pkg)
+    ref, net = check_network(pkg, orc, layers, weights, frac, 10)
+    net.close()
+
+
+def test_config2_literal_chime_network_bf16(pkg, orc):
+    """The same net in the bf16 throughput mode (H = 78 / 150 / 51 -> the 6-, 10- and 4-wave register-resident kernels)."""
+    rng = np.random.RandomState(51)
+    layers = net_desc(39, CHIME_LAYERS, 51)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts, frac = chime_fraction(pkg)
+    ref, net, (e_ref, _), (e, _) = run_both(pkg, orc, layers, weights, frac, 10, precision=1)
+    with net:
+        real = real_mask(frac)
+        assert np.abs(net.outputs().reshape(-1, 51)[real] - ref.outputs().reshape(-1, 51)[real]).max() < 3e-2
+        assert abs(e - e_ref) < 1e-2 * e_ref
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 5e-2, lay.name
+
+
+def lvcsr_case(pkg, depth):
+    rng = np.random.RandomState(52)
+    P, C, PS = 40, 8000, 4
+    layers = net_desc(P, [("blstm", 512)] * depth, C)
+    weights = random_weights(layers, rng, 0.05)
+    xs, ts = random_sequences(rng, [22, 20, 17, 9], P, C=C)
+    return layers, weights, pkg.make_fraction(xs, ts, PS), PS, C
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_config3_lvcsr_softmax8000_fp32(pkg, orc, depth):
+    """BASELINE configs[3]: 40 -> {2,4} x blstm512 -> softmax 8000 in fp32 parity mode: the block-per-pattern
+    C = 8000 softmax / multiclass kernels (SMW_VPT = 32 values per thread) and the 256-unit-per-direction layers."""
+    layers, weights, frac, PS, C = lvcsr_case(pkg, depth)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS)
+    with net:
+        # every posterior row of a real frame sums to 1, dummy rows are untouched by the softmax
+        real = real_mask(frac)
+        y = net.outputs().reshape(-1, C)
+        assert np.abs(y[real].sum(1) - 1.0).max() < 1e-5
+
+
+def test_config3_lvcsr_softmax8000_bf16(pkg, orc):
+    """The same 4-layer stack in bf16 mode (2-CU cluster kernels for Hp = 256, 256x256 LDS-DMA GEMM when it applies)."""
+    layers, weights, frac, PS, C = lvcsr_case(pkg, 4)
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=1)
+    with net:
+        real = real_mask(frac)
+        y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+        assert np.abs(y - yr).max() < 3e-2 and np.abs(y.sum(1) - 1.0).max() < 1e-4
+        assert abs(e - e_ref) < 1e-2 * e_ref
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 6e-2, lay.name
+
+
+def test_config4_long_utterance_T2000_cluster_vs_oracle(pkg, orc):
+    """BASELINE configs[4] layer shape: 39 -> blstm1024 -> softmax183, T = 2000, bf16 8-CU cluster kernels against the
+    fp32 oracle (about 70 GFLOP of oracle work).  Ragged: one sequence ends at 1 501, the fraction has an unused slot.
+    Weights are small (|w| <= 0.02) so that 2000 recurrent bf16 steps stay comparable to fp32."""
+    rng = np.random.RandomState(53)
+    P, C, PS = 39, 183, 3
+    layers = net_desc(P, [("blstm", 1024)], C)
+    weights = random_weights(layers, rng, 0.02)
+    xs, ts = random_sequences(rng, [2000, 1999, 1501], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=1)
+    with net:
+        real = real_mask(frac)
+        y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+        assert np.all(np.isfinite(y)) and np.abs(y - yr).max() < 3e-2
+        assert abs(e - e_ref) < 1e-2 * e_ref
+        # the last and the first frames of the longest sequence (both directions have run the full 2000 steps there)
+        h, hr = net.layers[1].outputs()[:, 0, :], ref.layers[1].outputs[:net.N * 1024].reshape(2000, PS, 1024)[:, 0, :]
+        assert np.abs(h[[0, 1999]] - hr[[0, 1999]]).max() < 2e-2
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 6e-2, lay.name
+
+
+def _run_longutt(pkg, layers, weights, frac, PS, T, steps, no_cluster):
+    if no_cluster:
+        os.environ["CN_NO_CLUSTER"] = "1"
+    try:
+        with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_BF16) as net:
+            errs = []
+            for _ in range(steps):
+                net.load_sequences(frac); net.compute_forward_pass()
+                errs.append(net.error_and_correct()[0])
+                net.compute_backward_pass(); net.update_weights_fused(1e-6, 0.9)
+            net.synchronize()
+            return errs, net.outputs(), [l.weights() for l in net.trainable_layers()]
+    finally:
+        os.environ.pop("CN_NO_CLUSTER", None)
+
+
+def test_config4_long_utterance_5x1024_T2000_property(pkg):
+    """BASELINE configs[4] as written: 39 -> 5 x blstm1024 -> softmax183, PS = 16, T = 2000, bf16.  No oracle at this size
+    (2.3 TFLOP per pass); size-independent properties instead: everything finite, posterior rows sum to 1, two passes
+    over the same fraction through the cluster kernels (granule tags count on across the 20 cluster launches: 40 020
+    tags) give the same error as the single-CU streaming kernels (CN_NO_CLUSTER=1) on the same weights, and training
+    two steps moves both paths to the same weights."""
+    rng = np.random.RandomState(54)
+    P, C, PS, T = 39, 183, 16, 2000
+    layers = net_desc(P, [("blstm", 1024)] * 5, C)
+    weights = random_weights(layers, rng, 0.02)
+    xs, ts = random_sequences(rng, [T] * 14 + [T - 7, T - 450], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    e1, y1, w1 = _run_longutt(pkg, layers, weights, frac, PS, T, 2, no_cluster=False)
+    e2, y2, w2 = _run_longutt(pkg, layers, weights, frac, PS, T, 2, no_cluster=True)
+    real = real_mask(frac)
+    y1r = y1.reshape(-1, C)[real]
+    assert np.all(np.isfinite(e1)) and np.all(np.isfinite(y1r))
+    assert np.abs(y1r.sum(1) - 1.0).max() < 1e-4
+    assert abs(e1[0] - e2[0]) < 2e-3 * abs(e2[0]) and abs(e1[1] - e2[1]) < 2e-3 * abs(e2[1]), (e1, e2)
+    assert np.abs(y1 - y2).max() < 2e-2
+    for a, b, w0 in zip(w1, w2, [np.concatenate([weights[l["name"]][k] for k in ("input", "bias", "internal")])
+                                  for l in layers if l["name"] in weights]):
+        moved = np.abs(a - w0).max()
+        assert moved > 0 and np.abs(a - b).max() < 0.1 * moved + 1e-7, (moved, np.abs(a - b).max())
+
+
+def test_cluster_launches_back_to_back_with_different_T(pkg):
+    """The cluster kernels' granule tags continue across launches (LstmRec::xch_epoch is advanced by the launcher): forward /
+    backward launches back to back over fractions of different T must not match a previous launch's granules.  The same
+    three fractions through the streaming kernels are the reference."""
+    rng = np.random.RandomState(55)
+    P, C, PS = 12, 6, 8
+    layers = net_desc(P, [("blstm", 512), ("blstm", 1024)], C)
+    weights = random_weights(layers, rng, 0.04)
+    fracs = []
+    for T in (9, 31, 4, 17):
+        xs, ts = random_sequences(rng, [T - (i % 3 if T > 3 else 0) for i in range(PS)], P, C=C)
+        fracs.append(pkg.make_fraction(xs, ts, PS))
+    res = {}
+    for mode in ("cluster", "stream"):
+        if mode == "stream":
+            os.environ["CN_NO_CLUSTER"] = "1"
+        try:
+            with pkg.NeuralNetwork(layers, weights, PS, 31, precision=pkg.PREC_BF16) as net:
+                out = []
+                for f in fracs:
+                    net.load_sequences(f); net.compute_forward_pass()
+                    e = net.error_and_correct()[0]
+                    net.compute_backward_pass()
+                    out.append((e, [l.weight_updates() for l in net.trainable_layers()]))
+                res[mode] = out
+        finally:
+            os.environ.pop("CN_NO_CLUSTER", None)
+    for (e1, g1), (e2, g2) in zip(res["cluster"], res["stream"]):
+        assert abs(e1 - e2) < 1e-3 * abs(e2)
+        for a, b in zip(g1, g2):
+            assert rel_err(a, b) < 1e-2
