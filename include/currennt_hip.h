@@ -40,7 +40,8 @@ typedef enum cn_status {
     CN_ERR_SHAPE     = -2,   /* size mismatch (reference: "Invalid matrix dimensions", ...)  */
     CN_ERR_HIP       = -3,   /* a HIP runtime call failed                                    */
     CN_ERR_STATE     = -4,   /* call order violated (e.g. forward before a fraction is loaded)*/
-    CN_ERR_NO_DEVICE = -5    /* no gfx950 device / code object cannot run here               */
+    CN_ERR_NO_DEVICE = -5,   /* no gfx950 device / code object cannot run here               */
+    CN_ERR_COMM      = -6    /* RCCL could not be loaded / a collective call failed            */
 } cn_status;
 
 /* arithmetic mode of the GEMM operands (accumulation and all state are always fp32) */
@@ -211,9 +212,39 @@ int  cn_ctx_weights_touched(cn_ctx *ctx);
 /* UpdateWeightFn (SteepestDescentOptimizer.cu:39-59): delta = momentum*delta - lr*update;
  * w += delta; then refresh the packed device copies the kernels read. */
 int  cn_sgd_update(cn_layer *layer, float learning_rate, float momentum);
-/* the same for every trainable layer of the context in one launch (per-layer learning rates are
- * not applied here; use cn_sgd_update per layer for those, TrainableLayer.cu:58) */
+/* per-layer learning rate (the JSON "learningRate" of TrainableLayer.cu:58; negative = none) that cn_sgd_update_all
+ * uses for this layer instead of its argument, as SteepestDescentOptimizer.cu:78-80 does */
+int  cn_layer_set_learning_rate(cn_layer *layer, float learning_rate);
+/* the same update for every trainable layer of the context in one launch; layers with a learning rate of their own
+ * (cn_layer_set_learning_rate) are updated with it */
 int  cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum);
+
+/* ---- data-parallel training over the GPUs of one node (no counterpart in the reference, which
+ *      drives a single device: main.cpp:526-541) ------------------------------------------------------------
+ * One process (or thread) per GPU, one cn_ctx each.  The parallel sequences of a fraction are independent, so
+ * ranks take disjoint sequences and meet only in the SUM over patterns of the weight gradients
+ * (LstmLayer.cu:502-510, FeedForwardLayer.cu:94-100,206) and in the scalar error / #correct: one all-reduce(SUM)
+ * of weightUpdates per layer on RCCL over xGMI, then the identical UpdateWeightFn on every rank keeps the replicas
+ * bit-identical without a broadcast.  librccl is opened at run time (dlopen "librccl.so.1"; a process that already
+ * holds one, e.g. through PyTorch, shares it); the library has no link-time dependency on it. */
+#define CN_COMM_ID_BYTES 128
+/* rank 0: a fresh rendezvous id (ncclGetUniqueId); hand its 128 bytes to every rank out of band (pipe, file, MPI, ...) */
+int  cn_comm_unique_id(char *id /* [CN_COMM_ID_BYTES] */);
+/* collective over all `world` ranks: binds a communicator for ctx's device to the context (ncclCommInitRank) */
+int  cn_comm_init(cn_ctx *ctx, const char *id /* [CN_COMM_ID_BYTES] */, int rank, int world);
+int  cn_comm_destroy(cn_ctx *ctx);
+/* rank / world size of the bound communicator; world = 0 when there is none.  Either pointer may be NULL. */
+int  cn_comm_info(const cn_ctx *ctx, int *rank, int *world);
+/* all-reduce(SUM, fp32, in place) of the weightUpdates of `n` layers, in the order given, on the context's
+ * communication stream: that stream waits for each layer's gradient work only (not for what the context's stream has
+ * enqueued since: the backward pass of the layers below keeps running beside the exchange), and the context's stream
+ * waits for the reductions in front of the next cn_sgd_update* / cn_layer_read.  Call it right after
+ * cn_layer_backward(layer) for "bucket = layer" overlap.  n == 0 (layers may be NULL): the whole weightUpdates arena
+ * of the context in ONE all-reduce, after all gradient work.  Collective: every rank makes the same calls in the same
+ * order.                                                                                              [async] */
+int  cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n);
+/* cn_loss_read over all ranks: all-reduce(SUM) of the device-side error / #correct sums, then read.   [sync] */
+int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
@@ -223,6 +254,9 @@ int  cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum);
 int  cn_ctx_timing_enable(cn_ctx *ctx, int enable);
 int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, long *launches); /* [sync] */
 int  cn_ctx_timing_reset(cn_ctx *ctx);
+/* name of the recurrent kernel a layer's forward (backward != 0: backward) pass launches for the loaded fraction
+ * shape, e.g. "lstm_bwd_kernel<bf16,Hp=128,rpl=1>" or "lstm_bwd_cluster_kernel<Hp=256,2 CUs>"; "" for other layers */
+const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward);
 
 #ifdef __cplusplus
 }

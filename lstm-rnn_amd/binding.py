@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 PREC_F32, PREC_BF16 = 0, 1
+COMM_ID_BYTES = 128
 
 # cn_layer_kind, keyed by the type strings of LayerFactory.cu:52-87
 LAYER_KINDS = {
@@ -32,7 +33,9 @@ EXPORTS = [
     "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_layer_forward",
     "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
-    "cn_sgd_update_all", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
+    "cn_sgd_update_all", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
+    "cn_layer_recurrent_kernel",
+    "cn_comm_unique_id", "cn_comm_init", "cn_comm_destroy", "cn_comm_info", "cn_allreduce_grads", "cn_loss_read_global",
     # include/currennt_hip_debug.h
     "cn_dbg_gemm_nt", "cn_dbg_gemm_tn",
 ]
@@ -122,6 +125,15 @@ def load_library():
     L.cn_ctx_timing_enable.argtypes = [vp, ci]
     L.cn_ctx_timing_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.cn_ctx_timing_reset.argtypes = [vp]
+    L.cn_layer_set_learning_rate.argtypes = [vp, cf]
+    L.cn_layer_recurrent_kernel.argtypes = [vp, ci]
+    L.cn_layer_recurrent_kernel.restype = C.c_char_p
+    L.cn_comm_unique_id.argtypes = [C.c_char_p]
+    L.cn_comm_init.argtypes = [vp, C.c_char_p, ci, ci]
+    L.cn_comm_destroy.argtypes = [vp]
+    L.cn_comm_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.cn_allreduce_grads.argtypes = [vp, C.POINTER(vp), ci]
+    L.cn_loss_read_global.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_long), ci]
     L.cn_dbg_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci]
     L.cn_dbg_gemm_tn.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     _LIB = L

@@ -9,6 +9,9 @@
 #include "cn_internal.h"
 #include "../../include/currennt_hip_debug.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>       // types and prototypes only: librccl is opened with dlopen (struct Rccl below), never linked
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,6 +71,7 @@ struct cn_ctx {
     bool overlap = true;
     bool attach_forks = true;                  // CN_NO_ATTACHED_FORKS=1: fork / join / update events recorded with hipEventRecord
     bool f32 = true;
+    int num_cus = 256;                         // hipDeviceProp_t::multiProcessorCount of the bound device
     std::string arch;
     std::vector<cn_layer *> layers;
 
@@ -95,6 +99,13 @@ struct cn_ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     bool stage_used[2] = {false, false};
     unsigned upload_idx = 0;
+
+    // data-parallel training: RCCL communicator of this rank, its stream and the newest reduction's event
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_comm = nullptr, ev_comm_fork = nullptr;
+    bool comm_pending = false;
 
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
@@ -142,6 +153,7 @@ struct cn_layer {
     size_t woff = 0;
     int nw = 0;
     float *w = nullptr, *wu = nullptr, *wd = nullptr;
+    float own_lr = -1.f;                  // JSON "learningRate" (TrainableLayer.cu:58); negative: the optimizer's
     std::vector<float> pending_w;         // set_weights before the arena exists
     bool dirty = true;                    // packed copies out of date
 
@@ -225,6 +237,75 @@ void join_side(cn_ctx *c)
         if (newest) HIP_CHECK(hipStreamWaitEvent(c->stream, c->pending_joins[i], 0));
     }
     c->pending_joins.clear(); c->pending_join_streams.clear();
+    // ... and for the gradient all-reduces of the communication stream (in order on that stream: the newest covers all)
+    if (c->comm_pending) { HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_comm, 0)); c->comm_pending = false; }
+}
+// `st` waits for the gradient work of `layer` and for nothing else the context has enqueued since
+void stream_wait_layer(cn_layer *layer, hipStream_t st)
+{
+    cn_ctx *c = layer->ctx;
+    bool pending = false;
+    for (hipEvent_t e : c->pending_joins) pending = pending || e == layer->ev_join;
+    if (pending) { HIP_CHECK(hipStreamWaitEvent(st, layer->ev_join, 0)); return; }
+    // nothing of this layer is on the side stream (CN_NO_OVERLAP, the first trainable layer, or already joined): its
+    // gradient is ordered on the context's stream
+    if (!c->ev_ext) HIP_CHECK(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(c->ev_ext, c->stream));
+    HIP_CHECK(hipStreamWaitEvent(st, c->ev_ext, 0));
+}
+
+// ---- RCCL, opened at run time ----------------------------------------------------------------
+// No link-time dependency: a host that never trains data-parallel needs no librccl, and a process that already holds
+// one (PyTorch ships a librccl.so with the SONAME librccl.so.1) shares it instead of loading a second copy.
+struct Rccl {
+    void *handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+};
+Rccl &rccl()
+{
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (r.handle) return r;
+    const char *names[] = {getenv("CN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    std::string tried;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+        tried += std::string(tried.empty() ? "" : "; ") + dlerror();
+    }
+    if (!h) throw cn_error(CN_ERR_COMM, "cannot open librccl (data-parallel training needs RCCL): " + tried);
+    auto sym = [&](const char *name) {
+        void *f = dlsym(h, name);
+        if (!f) throw cn_error(CN_ERR_COMM, std::string("librccl lacks ") + name);
+        return f;
+    };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.handle = h;
+    return r;
+}
+void rccl_check(ncclResult_t e, const char *what)
+{
+    if (e != ncclSuccess) throw cn_error(CN_ERR_COMM, std::string(what) + ": " + rccl().GetErrorString(e));
+}
+#define RCCL_CHECK(x) rccl_check((x), #x)
+void require_comm(cn_ctx *c, const char *who)
+{
+    if (!c->comm) throw cn_error(CN_ERR_STATE, std::string(who) + ": no communicator bound to this context (call cn_comm_init first)");
 }
 // run `f(stream)` on the side stream after everything enqueued on the main stream so far
 // (fork_attached: ev_fork already completes with the last main-stream kernel, see fork_event)
@@ -373,7 +454,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
     r.rpl = c->rpl;
-    r.xch = c->d_xch; r.fault = c->d_fault;
+    r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = c->num_cus;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
     if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }
     r.xch_epoch = c->xch_epoch;
@@ -407,8 +488,7 @@ void lstm_forward(cn_layer *l)
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (launch_lstm_cluster(c->stream, c->f32, false, r)) c->xch_epoch += (unsigned)c->T + 1;
-        else { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
+        if (!launch_lstm_cluster(c->stream, c->f32, false, r, &c->xch_epoch)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -424,8 +504,7 @@ void lstm_backward(cn_layer *l)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (launch_lstm_cluster(c->stream, c->f32, true, r)) c->xch_epoch += (unsigned)c->T + 1;
-        else {
+        if (!launch_lstm_cluster(c->stream, c->f32, true, r, &c->xch_epoch)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
             static const bool tail_on_side = getenv("CN_TAIL_ON_SIDE") != nullptr;
@@ -597,6 +676,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             throw cn_error(CN_ERR_NO_DEVICE, "cn_ctx_create: device is " + arch + ", this library is built for gfx950 only");
         c = new cn_ctx;
         c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
+        c->num_cus = prop.multiProcessorCount;
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         HIP_CHECK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -610,8 +690,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_NO_ATTACHED_FORKS")) c->attach_forks = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
-        HIP_CHECK(hipMalloc((void **)&c->d_loss, 4 * sizeof(float)));
-        HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 4 * sizeof(float), c->stream));
+        HIP_CHECK(hipMalloc((void **)&c->d_loss, 6 * sizeof(float)));          // per call | running sums | sums over all ranks
+        HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 6 * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
         HIP_CHECK(hipMalloc((void **)&c->d_fault, sizeof(int)));
         HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));
@@ -632,6 +712,9 @@ int cn_ctx_destroy(cn_ctx *ctx)
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);
         if (ctx->ev_ext) hipEventDestroy(ctx->ev_ext);
         if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }
+        if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
+        if (ctx->comm) { (void)rccl().CommDestroy(ctx->comm); ctx->comm = nullptr; }
+        if (ctx->comm_stream) { hipStreamDestroy(ctx->comm_stream); hipEventDestroy(ctx->ev_comm); hipEventDestroy(ctx->ev_comm_fork); }
         for (int i = 0; i < 2; ++i) {
             if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
             if (ctx->d_stage[i]) hipFree(ctx->d_stage[i]);
@@ -691,17 +774,89 @@ int cn_layer_join_stream(cn_layer *layer, void *stream)
 {
     if (!layer || !stream) { g_last_error = "cn_layer_join_stream: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
-        hipStream_t st = (hipStream_t)stream;
-        bool pending = false;
-        for (hipEvent_t e : c->pending_joins) pending = pending || e == layer->ev_join;
-        if (pending) { HIP_CHECK(hipStreamWaitEvent(st, layer->ev_join, 0)); return; }
-        // nothing of this layer is on the side stream (CN_NO_OVERLAP, or already joined): its gradient is ordered
-        // on the context's stream
-        if (!c->ev_ext) HIP_CHECK(hipEventCreateWithFlags(&c->ev_ext, hipEventDisableTiming));
-        HIP_CHECK(hipEventRecord(c->ev_ext, c->stream));
-        HIP_CHECK(hipStreamWaitEvent(st, c->ev_ext, 0));
+        HIP_CHECK(hipSetDevice(layer->ctx->device));
+        stream_wait_layer(layer, (hipStream_t)stream);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel training (RCCL)
+// ---------------------------------------------------------------------------------------------
+int cn_comm_unique_id(char *id)
+{
+    if (!id) { g_last_error = "cn_comm_unique_id: id is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        static_assert(sizeof(ncclUniqueId) == CN_COMM_ID_BYTES, "CN_COMM_ID_BYTES must match ncclUniqueId");
+        ncclUniqueId u;
+        RCCL_CHECK(rccl().GetUniqueId(&u));
+        memcpy(id, &u, sizeof(u));
+    });
+}
+
+int cn_comm_init(cn_ctx *ctx, const char *id, int rank, int world)
+{
+    if (!ctx || !id) { g_last_error = "cn_comm_init: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        if (world < 1 || rank < 0 || rank >= world) throw cn_error(CN_ERR_BAD_ARG, "cn_comm_init: rank " + std::to_string(rank) + " outside world of " + std::to_string(world));
+        if (ctx->comm) throw cn_error(CN_ERR_STATE, "cn_comm_init: this context already has a communicator");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof(u));
+        RCCL_CHECK(rccl().CommInitRank(&ctx->comm, world, u, rank));
+        ctx->comm_rank = rank; ctx->comm_world = world;
+        if (!ctx->comm_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm_fork, hipEventDisableTiming));
+        }
+    });
+}
+
+int cn_comm_destroy(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_comm_destroy: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        if (!ctx->comm) return;
+        HIP_CHECK(hipSetDevice(ctx->device));
+        HIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        RCCL_CHECK(rccl().CommDestroy(ctx->comm));
+        ctx->comm = nullptr; ctx->comm_world = 0; ctx->comm_rank = 0; ctx->comm_pending = false;
+    });
+}
+
+int cn_comm_info(const cn_ctx *ctx, int *rank, int *world)
+{
+    if (!ctx) { g_last_error = "cn_comm_info: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    if (rank) *rank = ctx->comm_rank;
+    if (world) *world = ctx->comm_world;
+    return CN_OK;
+}
+
+int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !layers)) { g_last_error = "cn_allreduce_grads: bad argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        require_comm(ctx, "cn_allreduce_grads");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        finalize(ctx);
+        if (n == 0) {
+            // the whole arena in one exchange: every gradient GEMM first, then fork the communication stream
+            join_side(ctx);
+            HIP_CHECK(hipEventRecord(ctx->ev_comm_fork, ctx->stream));
+            HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_fork, 0));
+            float *g = ctx->arena + ctx->total;
+            if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
+        } else {
+            for (int i = 0; i < n; ++i) {
+                cn_layer *l = layers[i];
+                if (!l || l->ctx != ctx || !l->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_allreduce_grads: not a trainable layer of this context");
+                stream_wait_layer(l, ctx->comm_stream);
+                RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
+            }
+        }
+        HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
+        ctx->comm_pending = true;
     });
 }
 
@@ -734,7 +889,8 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
         if (!preceding) {
             // sequences per workgroup of the recurrent kernels: the fewest (4, 8, 16) that still give at most
             // one workgroup per CU for a bidirectional layer; PS is padded to a whole number of groups
-            int rpl = ctx->rpl_override ? ctx->rpl_override : (2 * ((l->PS + 3) / 4) <= 256 ? 1 : (2 * ((l->PS + 7) / 8) <= 256 ? 2 : 4));
+            const int cus = ctx->num_cus;
+            int rpl = ctx->rpl_override ? ctx->rpl_override : (2 * ((l->PS + 3) / 4) <= cus ? 1 : (2 * ((l->PS + 7) / 8) <= cus ? 2 : 4));
             if (rpl != 1 && rpl != 2 && rpl != 4) throw cn_error(CN_ERR_BAD_ARG, "CN_RPL must be 1, 2 or 4");
             ctx->rpl = rpl;
             ctx->PSp = round_up(l->PS, 4 * rpl);
@@ -767,7 +923,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             // W_rec from L2 every time step costs an order of magnitude more
             if (!ctx->f32 && l->Hp > 192 && l->Hp < 512 && l->Hp != 256) {
                 const int hc = l->Hp < 256 ? 256 : 512;
-                if (lstm_cluster_xch_bytes(false, hc, l->dirs, ctx->PSp, ctx->rpl) > 0) l->Hp = hc;
+                if (lstm_cluster_xch_bytes(false, hc, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus) > 0) l->Hp = hc;
             }
             l->Lp = l->dirs * l->Hp;
             const size_t R = (size_t)l->dirs * 4 * l->Hp;
@@ -789,7 +945,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
             l->dWin = l->grad_block; l->dWrec = l->dWin + R * l->Pp; l->dbias = l->dWrec + R * l->Hp; l->dpeep = l->dbias + R;
             {   // exchange buffer of the multi-CU cluster kernels (layers whose W_rec exceeds one CU)
-                const size_t xb = lstm_cluster_xch_bytes(ctx->f32, l->Hp, l->dirs, ctx->PSp, ctx->rpl);
+                const size_t xb = lstm_cluster_xch_bytes(ctx->f32, l->Hp, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus);
                 if (xb > ctx->xch_bytes) {
                     if (ctx->d_xch) HIP_CHECK(hipFree(ctx->d_xch));
                     HIP_CHECK(hipMalloc((void **)&ctx->d_xch, xb));
@@ -1124,6 +1280,26 @@ int cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
     });
 }
 
+int cn_loss_read_global(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
+{
+    if (!ctx) { g_last_error = "cn_loss_read_global: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        require_comm(ctx, "cn_loss_read_global");
+        HIP_CHECK(hipSetDevice(ctx->device));
+        float *g = ctx->d_loss + 4, h[2];
+        RCCL_CHECK(rccl().GroupStart());
+        RCCL_CHECK(rccl().AllReduce(ctx->d_loss_acc, g, 1, ncclFloat32, ncclSum, ctx->comm, ctx->stream));
+        RCCL_CHECK(rccl().AllReduce(ctx->d_loss_acc + 1, g + 1, 1, ncclInt32, ncclSum, ctx->comm, ctx->stream));
+        RCCL_CHECK(rccl().GroupEnd());
+        HIP_CHECK(hipMemcpyAsync(h, g, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+        if (reset) HIP_CHECK(hipMemsetAsync(ctx->d_loss_acc, 0, sizeof(h), ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        check_fault(ctx);
+        if (error_sum) *error_sum = h[0];
+        if (correct_sum) { int cc; memcpy(&cc, &h[1], sizeof(int)); *correct_sum = cc; }
+    });
+}
+
 // ---------------------------------------------------------------------------------------------
 // weights and buffers
 // ---------------------------------------------------------------------------------------------
@@ -1296,6 +1472,14 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
     });
 }
 
+int cn_layer_set_learning_rate(cn_layer *layer, float learning_rate)
+{
+    if (!layer) { g_last_error = "cn_layer_set_learning_rate: layer is NULL"; return CN_ERR_BAD_ARG; }
+    if (!layer->trainable) { g_last_error = "cn_layer_set_learning_rate: layer has no weights"; return CN_ERR_BAD_ARG; }
+    layer->own_lr = learning_rate;
+    return CN_OK;
+}
+
 int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
 {
     if (!ctx) { g_last_error = "cn_sgd_update_all: ctx is NULL"; return CN_ERR_BAD_ARG; }
@@ -1313,8 +1497,20 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         const bool grouped = ctx->overlap && !group_off && ntrain <= PACK_GROUP_MAX;
         const bool attach = ctx->overlap && !grouped && ctx->attach_forks && !ctx->timing;
         if (ctx->overlap && !grouped && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
-        launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum,
-                   attach ? ctx->ev_sgd : nullptr);
+        bool own_rates = false;
+        for (cn_layer *l : ctx->layers) own_rates = own_rates || (l->trainable && l->own_lr >= 0.f);
+        if (!own_rates) {
+            launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum,
+                       attach ? ctx->ev_sgd : nullptr);
+        } else {
+            // a layer with a "learningRate" of its own (SteepestDescentOptimizer.cu:78-80): one launch per layer
+            cn_layer *last = nullptr;
+            for (cn_layer *l : ctx->layers) if (l->trainable) last = l;
+            for (cn_layer *l : ctx->layers)
+                if (l->trainable)
+                    launch_sgd(ctx->stream, l->w, l->wu, l->wd, (size_t)l->nw, l->own_lr >= 0.f ? l->own_lr : learning_rate, momentum,
+                               (attach && l == last) ? ctx->ev_sgd : nullptr);
+        }
         for (cn_layer *l : ctx->layers) if (l->trainable) l->dirty = true;
         if (grouped) {
             PackGroup grp{};
@@ -1377,6 +1573,25 @@ int cn_ctx_timing_reset(cn_ctx *ctx)
         timing_collect(ctx);
         for (int k = 0; k < KC_COUNT; ++k) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }
     });
+}
+
+const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward)
+{
+    static thread_local std::string name;
+    name.clear();
+    if (!layer || !layer->lstm) return name.c_str();
+    cn_ctx *c = layer->ctx;
+    const char *dirn = backward ? "bwd" : "fwd";
+    const int cs = lstm_cluster_size(c->f32, layer->Hp, layer->dirs, c->PSp, c->rpl, c->num_cus);
+    char buf[160];
+    if (c->d_xch && cs > 0)
+        snprintf(buf, sizeof(buf), "lstm_%s_cluster_kernel<%d,%d,%d>", dirn, layer->Hp, layer->Hp / cs, c->rpl);
+    else {
+        const bool resident = lstm_rec_resident(c->f32, layer->Hp);
+        snprintf(buf, sizeof(buf), "lstm_%s_kernel<%s,%d,1,%d>", dirn, c->f32 ? "true" : "false", resident ? layer->Hp : 0, c->rpl);
+    }
+    name = buf;
+    return name.c_str();
 }
 
 // ---------------------------------------------------------------------------------------------

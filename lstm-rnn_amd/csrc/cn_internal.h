@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -21,15 +22,13 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // hipFuncSetAttribute (the > 64 KB dynamic LDS opt-in) is per device: a process may drive several GPUs
 struct DeviceOnce {
-    unsigned long long seen = 0;
+    std::atomic<unsigned long long> seen{0};
     bool first()
     {
         int d = 0;
         (void)hipGetDevice(&d);
         const unsigned long long bit = 1ull << (d & 63);
-        if (seen & bit) return false;
-        seen |= bit;
-        return true;
+        return (seen.fetch_or(bit) & bit) == 0;        // (contexts of several host threads may launch concurrently)
     }
 };
 
@@ -79,15 +78,22 @@ struct LstmRec {
     int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
     // multi-CU cluster kernels (cn_lstm_cluster.hip)
     unsigned long long *xch;      // exchange granules (nullable: cluster path off), zeroed at allocation
-    unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T; the caller advances it by T + 1 per launch
+    unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T (launch_lstm_cluster sets it and advances the counter)
     int *fault;                   // set to 1 by a bounded spin that gave up
+    int num_cus;                  // CUs of the device: a cluster grid must be resident as a whole
 };
 size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T);       // dynamic LDS per workgroup of the single-CU kernels
+bool lstm_rec_resident(bool f32, int Hp);                                     // W_rec fragments register resident (single-CU kernels)
 void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
 void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
-size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl);
-bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p);
+// `num_cus`: the CU count of the device; the spin-wait hand-off needs every member workgroup resident, so a grid larger
+// than the device (a partitioned or CU-masked part) does not take the cluster path
+size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus);
+int lstm_cluster_size(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus);     // CUs per cluster, 0 = path does not apply
+// `epoch`: the context's granule-tag counter; the launcher hands tags epoch + 1 ... epoch + T to this launch and advances
+// the counter by T + 1, so no caller can forget to (stale granules of an earlier launch never match)
+bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch);
 
 // ---- element-wise / packing kernels -----------------------------------------------------------
 struct LstmGeom { int P, Pp, L, H, Hp, dirs; int prevH, prevHp, prevDirs; /* prevH=0: identity column map */ };

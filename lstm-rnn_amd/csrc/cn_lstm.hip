@@ -656,10 +656,14 @@ extern "C" int cn_dbg_read_stamps(unsigned long long *host)      // [2][16][8]
 
 // dynamic LDS of one workgroup of the single-CU kernels (launch_one): two operand tiles (+ the backward kernel's
 // dummy-slot table); resident shapes are those launch_rec dispatches on
+bool lstm_rec_resident(bool f32, int Hp)
+{
+    return Hp == 32 || Hp == 64 || Hp == 96 || Hp == 128 || (!f32 && (Hp == 160 || Hp == 192));
+}
 size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T)
 {
     const int ELT = f32 ? 4 : 2;
-    const bool resident = Hp == 32 || Hp == 64 || Hp == 96 || Hp == 128 || (!f32 && (Hp == 160 || Hp == 192));
+    const bool resident = lstm_rec_resident(f32, Hp);
     const size_t pitch = (size_t)lds_pitch((bwd ? 4 : 1) * Hp * ELT);
     return 2 * (size_t)(resident ? 16 : 4 * rpl + 1) * pitch + (bwd ? (((size_t)T * 4 * rpl + 15) & ~(size_t)15) : 0);
 }

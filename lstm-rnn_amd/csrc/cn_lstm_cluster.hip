@@ -15,13 +15,17 @@
 // which they published after consuming its step t from that very slot.  The exchange buffer is zeroed before
 // every launch (tags restart at 1); every spin is bounded and reports through a fault word instead of hanging.
 // Cluster members sit 8 block ids apart (same XCD under round-robin placement: speed only, never correctness);
-// the launcher only uses this path when the whole grid is resident (<= one workgroup per CU).
+// the launcher only uses this path when the whole grid is resident (<= one workgroup per CU of the device, whose CU count
+// it is given), and launches of different contexts on one device are serialised (cluster_gate) so that two half-resident
+// grids cannot wait for each other.
 //
 // Arithmetic is identical to cn_lstm.hip (same MFMA tiles, same cell update); bf16 operand mode only.
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace cn {
 
@@ -433,19 +437,65 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
 static int cluster_size(int Hp) { return Hp == 256 ? 2 : (Hp == 512 ? 8 : 0); }
 
 // bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
-size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl)
+int lstm_cluster_size(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus)
 {
     const int CS = cluster_size(Hp);
     if (f32 || CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
-    if ((nclusters + 7) / 8 * 8 * CS > 256) return 0;          // every member must be resident (one workgroup per CU)
+    if ((nclusters + 7) / 8 * 8 * CS > num_cus) return 0;      // every member must be resident (one workgroup per CU)
+    return CS;
+}
+size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus)
+{
+    const int CS = lstm_cluster_size(f32, Hp, dirs, PS, rpl, num_cus);
+    if (CS == 0) return 0;
+    const int nclusters = dirs * (PS / (4 * rpl));
     const int NT = (Hp / CS) * 4;
     return (size_t)nclusters * 2 * CS * rpl * 2 * NT * sizeof(u64);
 }
 
-bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p)
+// Cluster launches of one device go through one gate: a cluster kernel needs ALL its workgroups resident, and two such
+// grids of different contexts (streams) started together can each hold part of the CUs and spin for partners that never
+// get one.  While a single stream launches cluster kernels the gate costs nothing; from the moment a second stream shows up
+// every cluster launch waits (device side) for the completion event of the one before it.
+struct ClusterGate { std::mutex mu; hipEvent_t last = nullptr; hipStream_t last_stream = nullptr; bool multi = false; };
+static ClusterGate &cluster_gate()
 {
-    if (!p.xch || lstm_cluster_xch_bytes(f32, p.Hp, p.dirs, p.PS, p.rpl) == 0) return false;
+    static std::mutex mu;
+    static std::map<int, ClusterGate *> gates;
+    int d = 0;
+    (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> lock(mu);
+    ClusterGate *&g = gates[d];
+    if (!g) g = new ClusterGate;
+    return *g;
+}
+
+static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p);
+
+bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch)
+{
+    if (!p.xch || lstm_cluster_size(f32, p.Hp, p.dirs, p.PS, p.rpl, p.num_cus) == 0) return false;
+    p.xch_epoch = *epoch;
+    *epoch += (unsigned)p.T + 1;
+    ClusterGate &gate = cluster_gate();
+    std::lock_guard<std::mutex> lock(gate.mu);
+    if (gate.last_stream && gate.last_stream != s && !gate.multi) {
+        // first launch from a second stream: the earlier launches carry no event yet, wait for them on the host once
+        (void)hipStreamSynchronize(gate.last_stream);
+        (void)hipEventCreateWithFlags(&gate.last, hipEventDisableTiming);
+        gate.multi = true;
+    } else if (gate.multi && gate.last_stream != s) {
+        (void)hipStreamWaitEvent(s, gate.last, 0);
+    }
+    launch_cluster_shape(s, bwd, p);
+    if (gate.multi) (void)hipEventRecord(gate.last, s);
+    gate.last_stream = s;
+    return true;
+}
+
+static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p)
+{
     if (p.Hp == 256) {
         if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
         else                 { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
@@ -453,7 +503,6 @@ bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, const LstmRec &p)
         if (p.rpl == 1)      { if (bwd) launch_cluster<512, 64, 1, true>(s, p); else launch_cluster<512, 64, 1, false>(s, p); }
         else                 { if (bwd) launch_cluster<512, 64, 2, true>(s, p); else launch_cluster<512, 64, 2, false>(s, p); }
     }
-    return true;
 }
 
 }  // namespace cn

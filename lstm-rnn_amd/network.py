@@ -43,6 +43,8 @@ class Layer:
                                   net.max_seq_length if prev is None else 0, C.byref(h)), net.ctx)
         self.handle = h
         self.weight_count = L.cn_layer_weight_count(h) if self.trainable else 0
+        if self.trainable and self.learning_rate >= 0.0:       # cn_sgd_update_all honours it too (SteepestDescentOptimizer.cu:78-80)
+            B.check(L.cn_layer_set_learning_rate(h, self.learning_rate), net.ctx)
         if self.type in ("lstm", "blstm"):
             self.dirs = 2 if self.type == "blstm" else 1
             self.H = self.size // self.dirs
@@ -261,6 +263,54 @@ class NeuralNetwork:
             for w in works:
                 w.wait()            # orders the context's stream behind the reduction
 
+    # -- data-parallel training through the library's own RCCL communicator -----------------------
+    def comm_unique_id(self):
+        """Rank 0: 128 rendezvous bytes (ncclGetUniqueId) to hand to every rank out of band."""
+        buf = C.create_string_buffer(B.COMM_ID_BYTES)
+        B.check(self.lib.cn_comm_unique_id(buf), self.ctx)
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        """Collective: bind an RCCL communicator for this context's GPU (cn_comm_init)."""
+        if len(unique_id) != B.COMM_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % B.COMM_ID_BYTES)
+        B.check(self.lib.cn_comm_init(self.ctx, unique_id, int(rank), int(world)), self.ctx)
+
+    def comm_info(self):
+        r, w = C.c_int(), C.c_int()
+        B.check(self.lib.cn_comm_info(self.ctx, C.byref(r), C.byref(w)), self.ctx)
+        return r.value, w.value
+
+    def allreduce_grads(self, layers=None):
+        """SUM all-reduce of the weightUpdates of `layers` (None: the whole arena in one exchange) on the library's
+        communication stream; the next update waits for it on the device."""
+        if not layers:
+            B.check(self.lib.cn_allreduce_grads(self.ctx, None, 0), self.ctx)
+            return
+        arr = (C.c_void_p * len(layers))(*[l.handle for l in layers])
+        B.check(self.lib.cn_allreduce_grads(self.ctx, arr, len(layers)), self.ctx)
+
+    def compute_backward_pass_dp(self):
+        """Backward pass with the gradient exchange folded in, bucket = layer (SURVEY.md 8e "Overlap"): the reduction of
+        layer k is enqueued as soon as its backward pass is, and runs beside the recurrent kernels of the layers below.
+        All RCCL calls are made by the library (cn_allreduce_grads); follow with update_weights_fused()."""
+        for lay in reversed(self.layers):
+            B.check(self.lib.cn_layer_backward(lay.handle), self.ctx)
+            if lay.trainable:
+                self.allreduce_grads([lay])
+
+    def loss_read_global(self, reset=True):
+        err, cor = C.c_float(), C.c_long()
+        B.check(self.lib.cn_loss_read_global(self.ctx, C.byref(err), C.byref(cor), 1 if reset else 0), self.ctx)
+        return float(err.value), int(cor.value)
+
+    def recurrent_kernel(self, backward):
+        """Name of the recurrent kernel the first LSTM layer launches (for bench.py's roofline record)."""
+        for lay in self.layers:
+            if lay.type in ("lstm", "blstm"):
+                return self.lib.cn_layer_recurrent_kernel(lay.handle, 1 if backward else 0).decode()
+        return ""
+
     def _loss(self):
         err, cor = C.c_float(), C.c_int()
         B.check(self.lib.cn_loss_eval(self.layers[-1].handle, C.byref(err), C.byref(cor)), self.ctx)
@@ -281,6 +331,7 @@ class NeuralNetwork:
             B.check(self.lib.cn_sgd_update(lay.handle, lr, momentum), self.ctx)
 
     def update_weights_fused(self, learning_rate, momentum):
+        """One launch for all layers; layers with a JSON learningRate of their own keep it (cn_layer_set_learning_rate)."""
         B.check(self.lib.cn_sgd_update_all(self.ctx, learning_rate, momentum), self.ctx)
 
     def outputs(self):

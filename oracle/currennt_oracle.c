@@ -50,7 +50,7 @@ void orc_set_threads(int n)
 }
 int orc_get_threads(void) { return g_threads; }
 #define ORC_PAR(work) const long orc_work_ = (long)(work); (void)orc_work_; \
-    _Pragma("omp parallel for schedule(static) if (g_threads > 1 && orc_work_ > 20000)")
+    _Pragma("omp parallel for schedule(static) if (g_threads > 1 && orc_work_ > 400000)")
 
 typedef float real_t;
 

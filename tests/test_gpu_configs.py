@@ -113,12 +113,12 @@ def test_config3_lvcsr_softmax8000_bf16(pkg, orc):
 
 def test_config4_long_utterance_T2000_cluster_vs_oracle(pkg, orc):
     """BASELINE configs[4] layer shape: 39 -> blstm1024 -> softmax183, T = 2000, bf16 8-CU cluster kernels against the
-    fp32 oracle (about 70 GFLOP of oracle work).  Ragged: one sequence ends at 1 501, the fraction has an unused slot.
-    Weights are small (|w| <= 0.02) so that 2000 recurrent bf16 steps stay comparable to fp32."""
+    fp32 oracle (about 90 GFLOP of oracle work).  Ragged: one sequence ends at 1 501, the fraction has an unused slot.
+    The oracle runs multi-threaded here (bit-identical to its single-threaded order, oracle.set_threads)."""
     rng = np.random.RandomState(53)
     P, C, PS = 39, 183, 3
     layers = net_desc(P, [("blstm", 1024)], C)
-    weights = random_weights(layers, rng, 0.02)
+    weights = random_weights(layers, rng, 0.05)
     xs, ts = random_sequences(rng, [2000, 1999, 1501], P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)
     ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=1)

@@ -50,14 +50,15 @@ def test_bench_under_torchrun_one_rank():
 
 
 def test_bench_per_layer_allreduce_path_matches_plain_path():
-    """The overlapped per-layer all-reduce path of bench.py (cn_layer_join + async RCCL all-reduce per layer),
-    forced on with one rank where the reduction is the identity: same accumulated error as the plain path."""
+    """The overlapped per-layer all-reduce path of bench.py -- the LIBRARY's RCCL communicator (cn_comm_init, one
+    cn_allreduce_grads per layer right behind its backward pass) -- forced on with one rank where the reduction is the
+    identity: same accumulated error and the same weight movement as the plain path."""
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--parallel-sequences", "8",
             "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
     sums = {}
     for mode in ("plain", "overlap"):
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_MIN_SECONDS="0")
         if mode == "overlap":
             env["CN_BENCH_FORCE_ALLREDUCE"] = "1"
         out = subprocess.run(base + ["--master-port", str(29650 + os.getpid() % 200 + (mode == "overlap"))] + args,
@@ -65,8 +66,94 @@ def test_bench_per_layer_allreduce_path_matches_plain_path():
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         sums[mode] = d["check"]
-    assert sums["overlap"]["allreduce"].startswith("per-layer") and sums["plain"]["allreduce"] == "none"
+    assert sums["overlap"]["allreduce"].startswith("per-layer") and "library RCCL" in sums["overlap"]["allreduce"]
+    assert sums["plain"]["allreduce"] == "none"
     assert abs(sums["overlap"]["error_sum"] - sums["plain"]["error_sum"]) <= 1e-3 * abs(sums["plain"]["error_sum"])
+    assert abs(sums["overlap"]["update_l2"] - sums["plain"]["update_l2"]) <= 1e-3 * sums["plain"]["update_l2"]
+
+
+def test_bench_gpus_flag_without_launcher():
+    """`python bench.py --gpus N` with no launcher starts N ranks itself (before any GPU call); on a box with fewer GPUs
+    than ranks it must FAIL loudly instead of reporting a one-GPU number as n_gpus = N (missing #1)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-roofline-pass"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
+    assert "needs %d GPUs" % n in out.stderr + out.stdout
+    # and with N = 1 the flag path is the plain single-process run
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--parallel-sequences", "8",
+                          "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-also"],
+                         capture_output=True, text=True, timeout=900, env=dict(env, CN_BENCH_MIN_SECONDS="0"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_library_communicator_one_rank(pkg):
+    """cn_comm_unique_id / cn_comm_init / cn_allreduce_grads / cn_loss_read_global through the C ABI with a one-rank RCCL
+    communicator (the only world size a one-GPU box can run on RCCL): the per-layer exchange, the flat exchange and the
+    plain path train to the same weights, and the global loss equals the local one.  Without a communicator the calls
+    fail with CN_ERR_STATE."""
+    rng = np.random.RandomState(61)
+    P, C, PS, T = 20, 11, 12, 40
+    layers = net_desc(P, [("blstm", 64), ("blstm", 64)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, [T - (i % 5) for i in range(PS)], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    out = {}
+    for mode in ("plain", "layer", "flat"):
+        with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_F32) as net:
+            if mode == "plain":
+                with pytest.raises(pkg.CurrenntHipError, match="no communicator"):
+                    net.allreduce_grads(None)
+                assert net.comm_info() == (0, 0)
+            else:
+                net.comm_init(net.comm_unique_id(), 0, 1)
+                assert net.comm_info() == (0, 1)
+            for _ in range(3):
+                net.load_sequences(frac); net.compute_forward_pass(); net.loss_accumulate()
+                if mode == "layer":
+                    net.compute_backward_pass_dp()
+                else:
+                    net.compute_backward_pass()
+                    if mode == "flat":
+                        net.allreduce_grads(None)
+                net.update_weights_fused(1e-3, 0.9)
+            loss = net.loss_read_global(reset=False) if mode != "plain" else None
+            local = net.loss_read()
+            if loss is not None:
+                assert loss == local
+            out[mode] = (np.concatenate([l.weights() for l in net.trainable_layers()]), local)
+    for mode in ("layer", "flat"):
+        assert np.array_equal(out[mode][0], out["plain"][0]) or np.abs(out[mode][0] - out["plain"][0]).max() < 1e-6
+        assert out[mode][1] == out["plain"][1]
+
+
+def test_per_layer_learning_rate_in_fused_update(pkg, orc):
+    """A layer with a JSON "learningRate" of its own (TrainableLayer.cu:58, SteepestDescentOptimizer.cu:78-80): the fused
+    update (cn_sgd_update_all) and the per-layer update train to the same weights as the oracle."""
+    rng = np.random.RandomState(62)
+    P, C, PS = 6, 4, 3
+    layers = net_desc(P, [("blstm", 12), ("lstm", 8)], C)
+    layers[2]["learningRate"] = 5e-2
+    weights = random_weights(layers, rng, 0.3)
+    xs, ts = random_sequences(rng, [9, 8, 5], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref = orc.OracleNetwork(layers, weights, PS, 9)
+    for _ in range(3):
+        ref.load_sequences(frac); ref.compute_forward_pass(); ref.compute_backward_pass(); ref.update_weights(1e-2, 0.9)
+    for fused in (False, True):
+        with pkg.NeuralNetwork(layers, weights, PS, 9) as net:
+            for _ in range(3):
+                net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass()
+                if fused:
+                    net.update_weights_fused(1e-2, 0.9)
+                else:
+                    net.update_weights(1e-2, 0.9)
+            for lay in net.trainable_layers():
+                assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (fused, lay.name)
 
 
 @pytest.mark.parametrize("flat", [False, True])
@@ -77,7 +164,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29300 + os.getpid() % 250 + int(flat)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND="gloo")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND="gloo", CN_BENCH_MIN_SECONDS="0")   # one repetition
     if flat:
         env["CN_BENCH_FLAT_ALLREDUCE"] = "1"
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -85,7 +172,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp2 over sequences"
     assert d["check"]["replicas_identical"] is True and np.isfinite(d["check"]["error_sum"])
-    assert d["check"]["allreduce"] == ("flat" if flat else "per-layer, overlapped")
+    assert d["check"]["allreduce"].startswith("flat" if flat else "per-layer, overlapped") and "test double" in d["check"]["allreduce"]
     # the same five steps in ONE process on the union of the two ranks' fractions (16 sequences per fraction): gradients
     # are sums over patterns, so the data-parallel run must move the weights the same way.  An exchange that read a
     # layer's gradient before it was complete, or an update that did not wait for the exchange, shows up here.
