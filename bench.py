@@ -455,8 +455,9 @@ def cpu_baseline(pkg, wl, args, precisions):
     rng = np.random.RandomState(77)
     P, C = wl["P"], wl["C"]
     fpf = flops_per_frame(P, wl["hidden"], C)
-    nseq = 4
-    tlen = int(max(6, min(40, 4e9 / 21 / fpf / nseq)))                         # ~4 GFLOP of oracle work for the 21 passes
+    nseq = 6
+    tlen = int(max(6, min(60, 45e9 / 21 / fpf / nseq)))                        # <= ~45 GFLOP of oracle work for the 21 passes
+    orc.set_threads(min(8, len(os.sched_getaffinity(0))))                      # checker, not the timed baseline: bit-identical for any thread count
     proj = rng.randn(2 * P, C).astype(np.float32)
     fracs = []
     for _ in range(2):
@@ -493,6 +494,7 @@ def cpu_baseline(pkg, wl, args, precisions):
             parity[name] = {"posterior_max_abs": post, "weights_rel_l2": wrel, "weights_max_abs": wmax,
                             "error_first": float(e[0]), "error_last": float(e[-1]), "error_last_oracle": float(eref[-1])}
     out["parity_vs_cpu"] = parity
+    orc.set_threads(1)
     return out
 
 

@@ -707,6 +707,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
     return guarded([&] {
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->stream);
+        lstm_cluster_stream_gone(ctx->stream);
         if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
         if (ctx->side_slow) hipStreamSynchronize(ctx->side_slow);     // shared per device, never destroyed: masked_stream()
         if (ctx->ev_sgd) hipEventDestroy(ctx->ev_sgd);

@@ -94,6 +94,7 @@ int lstm_cluster_size(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus);
 // `epoch`: the context's granule-tag counter; the launcher hands tags epoch + 1 ... epoch + T to this launch and advances
 // the counter by T + 1, so no caller can forget to (stale granules of an earlier launch never match)
 bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch);
+void lstm_cluster_stream_gone(hipStream_t s);         // cn_ctx_destroy: the per-device launch gate forgets the stream
 
 // ---- element-wise / packing kernels -----------------------------------------------------------
 struct LstmGeom { int P, Pp, L, H, Hp, dirs; int prevH, prevHp, prevDirs; /* prevH=0: identity column map */ };

@@ -473,6 +473,14 @@ static ClusterGate &cluster_gate()
 
 static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p);
 
+// a context is going away (its stream has been synchronised): the gate must not name the stream any more
+void lstm_cluster_stream_gone(hipStream_t s)
+{
+    ClusterGate &gate = cluster_gate();
+    std::lock_guard<std::mutex> lock(gate.mu);
+    if (gate.last_stream == s) gate.last_stream = nullptr;
+}
+
 bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch)
 {
     if (!p.xch || lstm_cluster_size(f32, p.Hp, p.dirs, p.PS, p.rpl, p.num_cus) == 0) return false;

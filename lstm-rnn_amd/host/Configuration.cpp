@@ -38,6 +38,8 @@ const char *Configuration::usage()
     return "Usage: currennt_hip [options] [options-file]\n"
            "  common:   --network F --parallel_sequences N --random_seed N --cuda B(ignored) --list_devices B\n"
            "            --precision f32|bf16 --device N\n"
+           "            --gpus N (training only: data-parallel over N GPUs of this node, devices --device .. --device+N-1;\n"
+           "                      parallel_sequences is per GPU; gradients are summed with RCCL)\n"
            "  training: --train B --stochastic B (= --hybrid_online_batch) --shuffle_fractions B --shuffle_sequences B\n"
            "            --max_epochs N --max_epochs_no_best N --validate_every N --test_every N --learning_rate X\n"
            "            --momentum X --save_network F --train_file F[,F] --val_file F --test_file F --truncate_seq N\n"
@@ -99,6 +101,9 @@ void Configuration::apply(const std::string &key, const std::string &v)
         else throw std::runtime_error("Error while parsing the command line and/or options file: unknown precision '" + v + "'");
     }
     else if (key == "device") m_device = atoi(v.c_str());
+    else if (key == "gpus") { m_gpus = atoi(v.c_str()); if (m_gpus < 1) throw std::runtime_error("Error while parsing the command line and/or options file: --gpus must be >= 1"); }
+    else if (key == "dp_rank") m_dpRank = atoi(v.c_str());
+    else if (key == "dp_world") m_dpWorld = atoi(v.c_str());
     else if (key == "dump_fractions") m_dumpFractions = toBool(key, v);
     else if (key == "input_noise_sigma") m_inputNoiseSigma = (real_t)atof(v.c_str());
     else if (key == "weight_noise_sigma") m_weightNoiseSigma = (real_t)atof(v.c_str());

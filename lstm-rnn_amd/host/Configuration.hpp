@@ -53,6 +53,11 @@ public:
     const std::vector<std::string> &feedForwardInputFiles() const { return m_feedForwardInputFiles; }
     cn_precision precision() const { return m_precision; }
     int device() const { return m_device; }
+    // data-parallel training over `gpus` devices of this node, one process per GPU (no counterpart in the reference,
+    // which drives one device: main.cpp:526-541); dpRank/dpWorld: shard of a host-only --dump_fractions run
+    int gpus() const { return m_gpus; }
+    int dpRank() const { return m_dpRank; }
+    int dpWorld() const { return m_dpWorld; }
     bool help() const { return m_help; }
     bool dumpFractions() const { return m_dumpFractions; }
     // data/noise options of Configuration.cpp:139-146,171-176
@@ -78,7 +83,7 @@ private:
     bool m_help = false, m_trainingMode = false, m_hybridOnlineBatch = false, m_shuffleFractions = false,
          m_shuffleSequences = false, m_listDevices = false, m_revertStd = true, m_weightsNormal = false;
     int m_parallelSequences = 1, m_maxEpochs = -1, m_maxEpochsNoBest = 20, m_validateEvery = 1, m_testEvery = 1,
-        m_truncSeqLength = 0, m_outputFeatureKind = 9, m_device = 0;
+        m_truncSeqLength = 0, m_outputFeatureKind = 9, m_device = 0, m_gpus = 1, m_dpRank = 0, m_dpWorld = 1;
     unsigned m_randomSeed = 0;
     real_t m_learningRate = 1e-5f, m_momentum = 0.9f, m_featurePeriod = 10, m_trainingFraction = 1, m_validationFraction = 1,
            m_testFraction = 1, m_weightsUniformMin = -0.1f, m_weightsUniformMax = 0.1f, m_weightsNormalSigma = 0.1f, m_weightsNormalMean = 0;

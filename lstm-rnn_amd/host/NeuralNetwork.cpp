@@ -95,8 +95,15 @@ void NeuralNetwork::loadSequences(const data_sets::DataSetFraction &fraction)
     f.pat_types = fraction.patTypes().data(); f.inputs = fraction.inputs().data();
     f.target_classes = fraction.targetClasses().empty() ? 0 : fraction.targetClasses().data();
     f.targets = fraction.outputs().empty() ? 0 : fraction.outputs().data();
+    // (no synchronisation: cn_fraction_load has copied the host vectors into pinned staging memory when it returns, so
+    // the caller may release them, and the upload runs under the previous fraction's compute)
     hipCheck(cn_fraction_load(m_ctx, m_layers.front()->handle(), m_layers.back()->handle(), &f), m_ctx);
-    hipCheck(cn_ctx_synchronize(m_ctx), m_ctx);      // the fraction's host vectors may be released after this call
+}
+
+void NeuralNetwork::initDataParallel(const char *id, int rank, int world)
+{
+    hipCheck(cn_comm_init(m_ctx, id, rank, world), m_ctx);
+    m_rank = rank; m_world = world; m_dp = true;
 }
 
 void NeuralNetwork::computeForwardPass()
@@ -105,7 +112,13 @@ void NeuralNetwork::computeForwardPass()
 }
 void NeuralNetwork::computeBackwardPass()
 {
-    for (size_t i = m_layers.size(); i-- > 0;) m_layers[i]->computeBackwardPass();
+    for (size_t i = m_layers.size(); i-- > 0;) {
+        m_layers[i]->computeBackwardPass();
+        if (m_dp && m_exchangePerFraction && dynamic_cast<layers::TrainableLayer *>(m_layers[i].get())) {
+            cn_layer *h = m_layers[i]->handle();
+            hipCheck(cn_allreduce_grads(m_ctx, &h, 1), m_ctx);
+        }
+    }
 }
 real_t NeuralNetwork::calculateError() const
 {

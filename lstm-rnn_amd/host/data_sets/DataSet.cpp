@@ -97,6 +97,13 @@ DataSet::DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fra
         std::sort(m_sequences.begin(), m_sequences.end(), [](const sequence_t &a, const sequence_t &b) { return a.length < b.length; });
 }
 
+void DataSet::setShard(int rank, int world)
+{
+    if (world < 1 || rank < 0 || rank >= world) throw std::runtime_error("Invalid data-parallel shard");
+    if (m_prefetch.valid()) m_prefetch.wait();
+    m_rank = rank; m_world = world;
+}
+
 unsigned DataSet::nextRandom(unsigned n)
 {
     // The reference draws from boost::mt19937 (DataSet.cpp:169-181), which is not available here; a
@@ -114,7 +121,7 @@ void DataSet::shuffleFractions()
 {
     std::vector<std::vector<sequence_t> > fractions;
     for (size_t i = 0; i < m_sequences.size(); ++i) {
-        if (i % m_parallelSequences == 0) fractions.resize(fractions.size() + 1);
+        if (i % ((size_t)m_parallelSequences * m_world) == 0) fractions.resize(fractions.size() + 1);      // whole global fractions move
         fractions.back().push_back(m_sequences[i]);
     }
     for (size_t i = fractions.size(); i > 1; --i) std::swap(fractions[i - 1], fractions[nextRandom((unsigned)i)]);
@@ -132,13 +139,17 @@ void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac)
     frac->m_outputPatternSize = m_outputPatternSize;
     frac->m_maxSeqLength = std::numeric_limits<int>::min();
     frac->m_minSeqLength = std::numeric_limits<int>::max();
-    for (int seqIdx = firstSeqIdx; seqIdx < firstSeqIdx + PS; ++seqIdx) {                      // :316-328
+    // this rank's sequences of the global fraction: firstSeqIdx + rank, + world, ... (world = 1: the reference's loop)
+    auto globalIdx = [&](int i) { return firstSeqIdx + m_rank + i * m_world; };
+    for (int i = 0; i < PS; ++i) {                                                             // :316-328
+        const int seqIdx = globalIdx(i);
         if (seqIdx >= (int)m_sequences.size()) continue;
         frac->m_maxSeqLength = std::max(frac->m_maxSeqLength, m_sequences[seqIdx].length);
         frac->m_minSeqLength = std::min(frac->m_minSeqLength, m_sequences[seqIdx].length);
         DataSetFraction::seq_info_t si = { m_sequences[seqIdx].originalSeqIdx, m_sequences[seqIdx].length, m_sequences[seqIdx].seqTag };
         frac->m_seqInfo.push_back(si);
     }
+    if (frac->m_seqInfo.empty()) { frac->m_maxSeqLength = 1; frac->m_minSeqLength = 0; }        // all-dummy fraction (setShard)
     const size_t slots = (size_t)frac->m_maxSeqLength * PS;
     frac->m_inputs.assign(slots * Pf, 0.0f);                                                   // :330-336
     frac->m_patTypes.assign(slots, (char)PATTYPE_NONE);
@@ -146,8 +157,8 @@ void DataSet::makeFraction(int firstSeqIdx, DataSetFraction *frac)
     else frac->m_outputs.assign(slots * m_outputPatternSize, 0.0f);
     std::vector<float> noisy;
     for (int i = 0; i < PS; ++i) {
-        if (firstSeqIdx + i >= (int)m_sequences.size()) continue;
-        const sequence_t &seq = m_sequences[firstSeqIdx + i];
+        if (globalIdx(i) >= (int)m_sequences.size()) continue;
+        const sequence_t &seq = m_sequences[globalIdx(i)];
         const float *src = m_inputData.data() + seq.inputsBegin;
         if (m_augment.noiseDeviation) {                                                        // _addNoise, :250-265
             // the reference draws from boost::mt19937 + boost::normal_distribution (absent here);
@@ -184,7 +195,7 @@ bool DataSet::produceNext(DataSetFraction *frac)
     }
     if (m_curFirstSeqIdx < (int)m_sequences.size()) {
         makeFraction(m_curFirstSeqIdx, frac);
-        m_curFirstSeqIdx += m_parallelSequences;
+        m_curFirstSeqIdx += m_parallelSequences * m_world;
         return true;
     }
     m_curFirstSeqIdx = 0;                                        // :660-662

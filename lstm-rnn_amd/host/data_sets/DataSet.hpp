@@ -55,6 +55,13 @@ public:
     DataSet(const DataSet &) = delete;
     DataSet &operator=(const DataSet &) = delete;
 
+    // Data-parallel training: a GLOBAL fraction is world * parallelSequences consecutive sequences of the
+    // (sorted / shuffled) list and rank r packs sequences r, r + world, r + 2 world, ... of it -- round-robin over the
+    // length-sorted list keeps the ranks' T nearly equal.  Every rank sees the same number of fractions per epoch; a rank
+    // whose share of the last global fraction is empty gets an all-dummy fraction (one time step of PATTYPE_NONE), which
+    // contributes zero error and zero gradients but keeps the collectives matched.  Shuffles use the same seed on every
+    // rank, so all ranks permute alike.
+    void setShard(int rank, int world);
     bool isClassificationData() const { return m_isClassificationData; }
     bool empty() const { return m_totalTimesteps == 0; }
     // next fraction, or false once per epoch after the last one (DataSet.cpp:632-668)
@@ -72,7 +79,7 @@ public:
 private:
     bool m_fractionShuffling = false, m_sequenceShuffling = false, m_isClassificationData = false;
     int m_parallelSequences = 0, m_totalSequences = 0, m_totalTimesteps = 0, m_minSeqLength = 0, m_maxSeqLength = 0,
-        m_inputPatternSize = 0, m_outputPatternSize = 0, m_curFirstSeqIdx = -1;
+        m_inputPatternSize = 0, m_outputPatternSize = 0, m_curFirstSeqIdx = -1, m_rank = 0, m_world = 1;
     unsigned m_rngState = 0;
     Hip::real_vector m_outputMeans, m_outputStdevs, m_inputData, m_targetData;
     Hip::int_vector m_classData;

@@ -1,7 +1,10 @@
 // currennt_hip: a `currennt`-compatible driver over the MI355X library (subset of currennt/src/main.cpp:
 // training loop with the progress table, trained_network.jsn export, forward pass writers
 // single_csv / csv / htk).  Exit code 2 and "FAILED: msg" on any error like main.cpp:492-495.
+#include <signal.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -22,7 +25,15 @@ namespace {
 
 enum data_set_type { DATA_SET_TRAINING, DATA_SET_VALIDATION, DATA_SET_TEST, DATA_SET_FEEDFORWARD };
 
-std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, data_set_type dsType)   // main.cpp:574-640
+// This process' place in a data-parallel run (--gpus N: one process per GPU, forked by main() before any GPU call).
+// idPipe: rank 0 writes the RCCL rendezvous id to every other rank's pipe, rank r > 0 reads its own.
+struct DataParallel {
+    int rank = 0, world = 1;
+    bool active = false;                       // go through the communicator even with world == 1 (CN_DP_FORCE=1: test hook)
+    std::vector<int> idWriteFds; int idReadFd = -1;
+};
+
+std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, data_set_type dsType, const DataParallel &dp = DataParallel())   // main.cpp:574-640
 {
     std::string type; std::vector<std::string> filenames; real_t fraction = 1; bool fracShuf = false, seqShuf = false; int truncSeqLength = 0;
     data_sets::DataSet::Augment augment;            // context and lag apply to every set (DataSet.cpp:302-305), noise to two (main.cpp:593,613)
@@ -42,6 +53,8 @@ std::shared_ptr<data_sets::DataSet> loadDataSet(const Configuration &config, dat
     if (filenames.empty()) throw std::runtime_error("No " + type + " file given");
     std::shared_ptr<data_sets::DataSet> ds = std::make_shared<data_sets::DataSet>(
         filenames, config.parallelSequences(), fraction, truncSeqLength, fracShuf, seqShuf, config.trainingMode(), config.randomSeed(), augment);
+    if (dp.world > 1) ds->setShard(dp.rank, dp.world);
+    else if (config.dpWorld() > 1) ds->setShard(config.dpRank(), config.dpWorld());            // host-only --dump_fractions of one shard
     printf("done.\n");
     printf("Loaded fraction:  %d%%\n", (int)(fraction * 100));
     printf("Sequences:        %d\n", ds->totalSequences());
@@ -168,8 +181,9 @@ void feedForward(const Configuration &config, NeuralNetwork &nn, data_sets::Data
     }
 }
 
-int trainerMain(const Configuration &config)                                                    // main.cpp:97-498
+int trainerMain(const Configuration &config, const DataParallel &dp = DataParallel())           // main.cpp:97-498
 {
+    const bool root = dp.rank == 0;            // only rank 0 writes files (all ranks hold identical weights)
     try {
         const std::string networkFile = config.continueFile().empty() ? config.networkFile() : config.continueFile();   // main.cpp:102
         printf("Reading network from '%s'... ", networkFile.c_str());
@@ -182,9 +196,9 @@ int trainerMain(const Configuration &config)                                    
         validationSet = std::make_shared<data_sets::DataSet>(); testSet = std::make_shared<data_sets::DataSet>();
         feedForwardSet = std::make_shared<data_sets::DataSet>();
         if (config.trainingMode()) {
-            trainingSet = loadDataSet(config, DATA_SET_TRAINING);
-            if (!config.validationFiles().empty()) validationSet = loadDataSet(config, DATA_SET_VALIDATION);
-            if (!config.testFiles().empty()) testSet = loadDataSet(config, DATA_SET_TEST);
+            trainingSet = loadDataSet(config, DATA_SET_TRAINING, dp);
+            if (!config.validationFiles().empty()) validationSet = loadDataSet(config, DATA_SET_VALIDATION, dp);
+            if (!config.testFiles().empty()) testSet = loadDataSet(config, DATA_SET_TEST, dp);
         } else feedForwardSet = loadDataSet(config, DATA_SET_FEEDFORWARD);
 
         int maxSeqLength = config.trainingMode()
@@ -202,7 +216,7 @@ int trainerMain(const Configuration &config)                                    
                 for (size_t i = 0; i < frac.outputs().size(); ++i) sx += 1000.0 * frac.outputs()[i];
                 for (size_t i = 0; i < frac.patTypes().size(); ++i) none += frac.patTypes()[i] == PATTYPE_NONE;
                 printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s\n", idx++, frac.maxSeqLength(),
-                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.seqInfo(0).seqTag.c_str());
+                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.numSequences() ? frac.seqInfo(0).seqTag.c_str() : "-");
             }
             return 0;
         }
@@ -216,7 +230,24 @@ int trainerMain(const Configuration &config)                                    
         NeuralNetwork::WeightsInit wi = { config.weightsDistributionIsNormal(), config.weightsDistributionUniformMin(),
                                           config.weightsDistributionUniformMax(), config.weightsDistributionNormalSigma(),
                                           config.weightsDistributionNormalMean(), config.randomSeed() };
-        NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device(), &wi);
+        NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device() + dp.rank, &wi);
+        if (dp.active) {
+            // rendezvous: rank 0 draws the id and hands it to the other ranks through their pipes, then every rank joins
+            char id[CN_COMM_ID_BYTES];
+            if (dp.rank == 0) {
+                hipCheck(cn_comm_unique_id(id), neuralNetwork.context());
+                for (int fd : dp.idWriteFds)
+                    if (write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) throw std::runtime_error("Could not hand the communicator id to a rank");
+            } else {
+                size_t got = 0;
+                while (got < sizeof(id)) {
+                    ssize_t n = read(dp.idReadFd, id + got, sizeof(id) - got);
+                    if (n <= 0) throw std::runtime_error("Could not read the communicator id from rank 0");
+                    got += (size_t)n;
+                }
+            }
+            neuralNetwork.initDataParallel(id, dp.rank, dp.world);
+        }
         if (!trainingSet->empty() && trainingSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
             throw std::runtime_error("Post output layer size != target pattern size of the training set");
         if (!validationSet->empty() && validationSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
@@ -287,10 +318,10 @@ int trainerMain(const Configuration &config)                                    
                             size_t pos = config.networkFile().find_last_of('.');
                             base = (pos != std::string::npos && pos > 0) ? config.networkFile().substr(0, pos) : config.networkFile();
                         }
-                        saveNetwork(neuralNetwork, base + ".best.jsn");
+                        if (root) saveNetwork(neuralNetwork, base + ".best.jsn");
                     }
                 } else infoRows += printfRow("        \n");
-                if (config.autosave()) saveState(config, neuralNetwork, optimizer, infoRows);  // main.cpp:275-277
+                if (config.autosave() && root) saveState(config, neuralNetwork, optimizer, infoRows);  // main.cpp:275-277
             }
             printf("\n");
             if (optimizer.epochsSinceLowestValidationError() == config.maxEpochsNoBest())
@@ -300,7 +331,7 @@ int trainerMain(const Configuration &config)                                    
             else printf("Final training set error: %lf\n", optimizer.curTrainingError());
             printf("\n");
             printf("Storing the trained network in '%s'... ", config.trainedNetworkFile().c_str());
-            saveNetwork(neuralNetwork, config.trainedNetworkFile());
+            if (root) saveNetwork(neuralNetwork, config.trainedNetworkFile());
             printf("done.\n");
         } else {
             feedForward(config, neuralNetwork, *feedForwardSet);
@@ -310,6 +341,56 @@ int trainerMain(const Configuration &config)                                    
         return 2;
     }
     return 0;
+}
+
+// --gpus N: one process per GPU.  The ranks are forked HERE, before this process has made any GPU call (a process that
+// has initialised the GPU must neither fork workers nor exec); each child runs trainerMain on device --device + rank with
+// its shard of every fraction.  Rank 0 keeps the console; the other ranks' output is dropped.  The parent only waits:
+// exit code = the first failing rank's (the others are terminated, they would wait in a collective for ever).
+int runDataParallel(const Configuration &config, int world)
+{
+    printf("Data-parallel training on %d GPU%s (devices %d..%d), %d parallel sequences per GPU.\n", world, world == 1 ? "" : "s",
+           config.device(), config.device() + world - 1, config.parallelSequences());
+    fflush(stdout);
+    std::vector<int> readFd(world, -1), writeFd(world, -1);
+    for (int r = 1; r < world; ++r) {
+        int p[2];
+        if (pipe(p) != 0) throw std::runtime_error("pipe() failed");
+        readFd[r] = p[0]; writeFd[r] = p[1];
+    }
+    std::vector<pid_t> pids(world, -1);
+    for (int r = 0; r < world; ++r) {
+        pid_t pid = fork();
+        if (pid < 0) throw std::runtime_error("fork() failed");
+        if (pid == 0) {
+            DataParallel dp;
+            dp.rank = r; dp.world = world; dp.active = true;
+            if (r == 0) { for (int k = 1; k < world; ++k) { dp.idWriteFds.push_back(writeFd[k]); close(readFd[k]); } }
+            else {
+                dp.idReadFd = readFd[r];
+                for (int k = 1; k < world; ++k) { close(writeFd[k]); if (k != r) close(readFd[k]); }
+                if (!freopen("/dev/null", "w", stdout)) _exit(2);
+            }
+            int rc = trainerMain(config, dp);
+            fflush(stdout);
+            _exit(rc);
+        }
+        pids[r] = pid;
+    }
+    for (int r = 1; r < world; ++r) { close(readFd[r]); close(writeFd[r]); }
+    int rc = 0, left = world;
+    while (left > 0) {
+        int status = 0;
+        pid_t done = wait(&status);
+        if (done < 0) break;
+        --left;
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
+        if (code != 0 && rc == 0) {
+            rc = code;
+            for (int r = 0; r < world; ++r) if (pids[r] != done) kill(pids[r], SIGTERM);
+        }
+    }
+    return rc;
 }
 
 }  // namespace
@@ -332,7 +413,10 @@ int main(int argc, const char *argv[])
         printf("Started in %s training mode.\n", config.hybridOnlineBatch() ? "hybrid online/batch" : "batch");   // Configuration.cpp:316
         printf("Computations run on the MI355X (libcurrennt_hip: %s, %s operands).\n", cn_version(),
                config.precision() == CN_PREC_BF16 ? "bf16" : "fp32");
-        return trainerMain(config);
+        const bool forceDp = getenv("CN_DP_FORCE") != 0;       // test hook: --gpus 1 through the whole data-parallel path
+        if (config.gpus() == 1 && !forceDp) return trainerMain(config);
+        if (!config.trainingMode()) throw std::runtime_error("--gpus > 1 is a training option");
+        return runDataParallel(config, config.gpus());
     } catch (const std::exception &e) {
         printf("FAILED: %s\n", e.what());
         return 2;

@@ -16,6 +16,7 @@ Optimizer::Optimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingS
     , m_curValidationError(std::numeric_limits<real_t>::max()), m_curTestError(std::numeric_limits<real_t>::max())
     , m_curValidationClassError(0), m_curTrainingClassError(0), m_curTestClassError(0)
 {
+    m_neuralNetwork.setExchangePerFraction(hybridOnlineBatch);
     m_bestWeights.resize(m_neuralNetwork.layers().size());
     m_curWeightUpdates.resize(m_neuralNetwork.layers().size());
     _storeWeights();
@@ -100,7 +101,12 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     if (calcWeightUpdates && !m_hybridOnlineBatch) _updateWeights();
     {
         float e = 0; long correct = 0;
-        hipCheck(cn_loss_read(m_neuralNetwork.context(), &e, &correct, 1), m_neuralNetwork.context());
+        // data-parallel: the sums of all ranks (every rank then computes the same epoch errors and takes the same
+        // early-stopping decisions)
+        if (m_neuralNetwork.dataParallel())
+            hipCheck(cn_loss_read_global(m_neuralNetwork.context(), &e, &correct, 1), m_neuralNetwork.context());
+        else
+            hipCheck(cn_loss_read(m_neuralNetwork.context(), &e, &correct, 1), m_neuralNetwork.context());
         error = e;
         if (classification) *classError -= (real_t)correct;
     }
@@ -229,20 +235,24 @@ SteepestDescentOptimizer::SteepestDescentOptimizer(NeuralNetwork &neuralNetwork,
 
 void SteepestDescentOptimizer::_updateWeights()
 {
-    const std::vector<std::shared_ptr<layers::Layer> > &ls = _neuralNetwork().layers();
+    NeuralNetwork &nn = _neuralNetwork();
+    const std::vector<std::shared_ptr<layers::Layer> > &ls = nn.layers();
+    if (!hybridOnlineBatch()) {
+        // batch mode: the epoch sum replaces the device weightUpdates before the update; data-parallel ranks then add
+        // their epoch sums up in one exchange over the whole arena
+        for (size_t i = 1; i + 1 < ls.size(); ++i) {
+            layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
+            if (!layer) continue;
+            hipCheck(cn_layer_upload(layer->handle(), CN_BUF_WEIGHT_UPDATES, _curWeightUpdates()[i].data(), _curWeightUpdates()[i].size()), nn.context());
+        }
+        if (nn.dataParallel()) hipCheck(cn_allreduce_grads(nn.context(), 0, 0), nn.context());
+    }
     for (size_t i = 1; i + 1 < ls.size(); ++i) {
         layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
         if (!layer) continue;
         real_t lr = m_learningRate;
         if (layer->learningRate() >= 0.0) lr = layer->learningRate();        // SteepestDescentOptimizer.cu:78-80
-        if (!hybridOnlineBatch()) {
-            // batch mode: the epoch sum replaces the device weightUpdates before the update
-            void *wu = cn_layer_device_ptr(layer->handle(), CN_BUF_WEIGHT_UPDATES);
-            if (!wu) throw std::runtime_error("cannot address the weight updates of layer '" + layer->name() + "'");
-            hipCheck(cn_layer_upload(layer->handle(), CN_BUF_WEIGHT_UPDATES, _curWeightUpdates()[i].data(), _curWeightUpdates()[i].size()),
-                     _neuralNetwork().context());
-        }
-        hipCheck(cn_sgd_update(layer->handle(), lr, m_momentum), _neuralNetwork().context());
+        hipCheck(cn_sgd_update(layer->handle(), lr, m_momentum), nn.context());
     }
 }
 

@@ -207,3 +207,26 @@ def test_cluster_launches_back_to_back_with_different_T(pkg):
         assert abs(e1 - e2) < 1e-3 * abs(e2)
         for a, b in zip(g1, g2):
             assert rel_err(a, b) < 1e-2
+
+
+def test_all_dummy_fraction_contributes_nothing(pkg):
+    """A data-parallel rank whose share of the last global fraction is empty loads an all-dummy fraction (T = 1, Tmin = 0,
+    every slot PATTYPE_NONE; DataSet::setShard): zero error, zero #correct, exactly zero gradients, and the following
+    update leaves the weights where momentum alone puts them -- so the rank can take part in the all-reduce."""
+    rng = np.random.RandomState(56)
+    P, C, PS = 9, 5, 6
+    layers = net_desc(P, [("blstm", 40), ("lstm", 24)], C)
+    weights = random_weights(layers, rng, 0.2)
+    xs, ts = random_sequences(rng, [12, 11, 11, 8, 5, 3], P, C=C)
+    real_frac = pkg.make_fraction(xs, ts, PS)
+    dummy = {"T": 1, "Tmin": 0, "PS": PS, "numSeqs": 0, "inputs": np.zeros((PS, P), np.float32),
+             "patTypes": np.zeros(PS, np.int8), "targetClasses": np.full(PS, -1, np.int32)}
+    for prec in (pkg.PREC_F32, pkg.PREC_BF16):
+        with pkg.NeuralNetwork(layers, weights, PS, 12, precision=prec) as net:
+            net.load_sequences(real_frac); net.compute_forward_pass(); net.compute_backward_pass()     # leave non-zero state behind
+            net.load_sequences(dummy); net.compute_forward_pass()
+            e, c = net.error_and_correct()
+            net.compute_backward_pass()
+            assert e == 0.0 and c == 0
+            for lay in net.trainable_layers():
+                assert np.all(lay.weight_updates() == 0.0), lay.name

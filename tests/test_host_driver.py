@@ -68,6 +68,40 @@ def test_reader_and_packer_cpu(pkg, tmp_path):
         assert int(kv["sum_targets"]) == int(f["targetClasses"][f["targetClasses"] >= 0].sum())
 
 
+def test_data_parallel_shards_cpu(pkg, tmp_path):
+    """--gpus N sharding of the C++ DataSet (DataSet::setShard; SURVEY 8e "Partitioning"): a global fraction is
+    world * parallel_sequences consecutive sequences of the length-sorted list, rank r packs r, r + world, ...  Checked
+    against the Python mirror (parallel.shard_indices + make_fraction), incl. a rank whose share of the last global
+    fraction is EMPTY (it gets an all-dummy fraction so that every rank makes the same number of collective calls)."""
+    if not os.path.exists(BIN):
+        import __graft_entry__ as ge
+        ge.build()
+    lens = (11, 5, 9, 3, 14, 7, 8, 12, 6)                 # 9 sequences, world 2 x PS 2 -> global fractions of 4, 4, 1
+    layers, weights, xs, ts, nc, net = problem(tmp_path, lens)
+    order = sorted(range(len(lens)), key=lambda i: lens[i])
+    world, PS = 2, 2
+    rows = {}
+    for r in range(world):
+        out = subprocess.run([BIN, "--train", "true", "--train_file", nc, "--network", net, "--parallel_sequences", str(PS),
+                              "--dump_fractions", "true", "--dp_rank", str(r), "--dp_world", str(world)], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stdout + out.stderr
+        rows[r] = [dict(p.split("=") for p in l.split()[2:]) for l in out.stdout.splitlines() if l.startswith("FRACTION")]
+    assert len(rows[0]) == len(rows[1]) == 3
+    for k in range(3):
+        glob = order[k * world * PS:(k + 1) * world * PS]
+        for r in range(world):
+            mine = [glob[i] for i in pkg.parallel.shard_indices(len(glob), world, r)]
+            kv = rows[r][k]
+            assert int(kv["seqs"]) == len(mine)
+            if not mine:
+                assert int(kv["T"]) == 1 and int(kv["Tmin"]) == 0 and int(kv["none"]) == PS and float(kv["sum_inputs"]) == 0.0
+                continue
+            f = pkg.make_fraction([xs[i] for i in mine], [ts[i] for i in mine], PS)
+            assert int(kv["T"]) == f["T"] and int(kv["Tmin"]) == f["Tmin"] and int(kv["none"]) == int((f["patTypes"] == 0).sum())
+            assert abs(float(kv["sum_inputs"]) - float(f["inputs"].astype(np.float64).sum())) < 1e-3
+            assert int(kv["sum_targets"]) == int(f["targetClasses"][f["targetClasses"] >= 0].sum())
+
+
 def test_context_splicing_output_lag_and_input_noise_cpu(pkg, tmp_path):
     """--input_left_context / --input_right_context / --output_time_lag (DataSet.cpp:302-305,346-397) against the
     Python packer, and --input_noise_sigma (DataSet.cpp:250-265): reproducible per seed, changes the inputs."""
@@ -200,3 +234,86 @@ def test_driver_autosave_continue_and_weight_noise(pkg, tmp_path):
     c = json.load(open(noisy))
     diff = max(np.abs(np.asarray(a["weights"][n]["input"]) - np.asarray(c["weights"][n]["input"])).max() for n in a["weights"])
     assert 0 < diff < 0.05
+
+
+def _weights_of(path):
+    doc = json.load(open(path))
+    return {n: np.concatenate([np.asarray(w[k], np.float64).reshape(-1) for k in ("input", "bias", "internal")]) for n, w in doc["weights"].items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stochastic", ["true", "false"])
+def test_driver_data_parallel_path_one_rank(pkg, tmp_path, stochastic):
+    """`--gpus 1` through the whole data-parallel path of the C++ driver (CN_DP_FORCE=1: forked rank, RCCL rendezvous over the
+    pipe, cn_comm_init, one cn_allreduce_grads per layer behind its backward pass -- or one flat exchange of the epoch
+    sum in batch mode --, cn_loss_read_global): with one rank every reduction is the identity, so the run must end in the
+    same network and print the same error columns as the plain single-process run.  (World sizes > 1 need as many GPUs:
+    RCCL refuses two ranks on one device.)"""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    common = [BIN, "--train", "true", "--stochastic", stochastic, "--train_file", nc, "--val_file", nc, "--network", net, "--parallel_sequences", "3",
+              "--max_epochs", "3", "--learning_rate", "1e-2", "--momentum", "0.9"]
+    plain, dp = str(tmp_path / "plain.jsn"), str(tmp_path / "dp.jsn")
+    a = subprocess.run(common + ["--save_network", plain], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run(common + ["--gpus", "1", "--save_network", dp], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, CN_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert "Data-parallel training on 1 GPU" in b.stdout
+    rows = lambda out: [l.split("|")[2:5] for l in out.splitlines() if l.strip()[:1].isdigit() and "|" in l]
+    assert rows(a.stdout) == rows(b.stdout) and len(rows(a.stdout)) == 3
+    wa, wb = _weights_of(plain), _weights_of(dp)
+    for n in wa:
+        assert np.abs(wa[n] - wb[n]).max() < 1e-6, n
+
+
+@pytest.mark.gpu
+def test_driver_batch_mode_matches_oracle(pkg, orc, tmp_path):
+    """Batch (non `--stochastic`) training: the fractions' weightUpdates are summed over the epoch and ONE update follows
+    (Optimizer.cu:72-85,95-97; SteepestDescentOptimizer.cu:67-94).  Against the oracle driven the same way."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    trained = str(tmp_path / "batch.jsn")
+    out = subprocess.run([BIN, "--train", "true", "--stochastic", "false", "--train_file", nc, "--network", net, "--parallel_sequences", "3",
+                          "--max_epochs", "3", "--learning_rate", "1e-2", "--momentum", "0.9", "--save_network", trained],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Started in batch training mode." in out.stdout
+    fracs = pkg.make_fractions(xs, ts, 3, sort_by_length=True)
+    ref = orc.OracleNetwork(layers, weights, 3, max(len(x) for x in xs))
+    for epoch in range(3):
+        acc = None
+        for f in fracs:
+            ref.load_sequences(f); ref.compute_forward_pass(); ref.compute_backward_pass()
+            g = [l.weightUpdates.copy() for l in ref.trainable_layers()]
+            acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+        for l, a in zip(ref.trainable_layers(), acc):
+            l.weightUpdates[:] = a
+        ref.update_weights(1e-2, 0.9)
+    got = _weights_of(trained)
+    for lay in ref.trainable_layers():
+        assert np.abs(got[lay.name] - lay.weights).max() < 2e-5, lay.name
+
+
+@pytest.mark.gpu
+def test_driver_csv_writer(pkg, orc, tmp_path):
+    """--ff_output_format csv: one <tag without extension>.csv per sequence below --ff_output_file, one row per frame,
+    ';' separated (main.cpp:392-430)."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    cdir = str(tmp_path / "csvout")
+    out = subprocess.run([BIN, "--train", "false", "--ff_input_file", nc, "--network", net, "--parallel_sequences", "4",
+                          "--ff_output_file", cdir, "--ff_output_format", "csv", "--revert_std", "false"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    fracs = pkg.make_fractions(xs, ts, 4)
+    ref = orc.OracleNetwork(layers, weights, 4, max(len(x) for x in xs))
+    k = 0
+    for f in fracs:
+        ref.load_sequences(f); ref.compute_forward_pass()
+        y = ref.outputs()
+        for i, n in enumerate(f["seqLengths"]):
+            path = os.path.join(cdir, "dir", "seq%03d.csv" % k)
+            assert os.path.exists(path), path
+            rows = [r for r in open(path).read().strip().split("\n")]
+            assert len(rows) == n
+            vals = np.array([r.split(";") for r in rows], np.float64)
+            assert vals.shape == (n, 4) and np.abs(vals - y[:n, i, :]).max() < 1e-4
+            k += 1
+    assert k == len(xs)
