@@ -10,16 +10,19 @@
  * Every function cites the reference file:line (relative to
  * currennt_lib/src/) whose arithmetic and summation order it restates.
  *
- * PINNING: the reference's own test (tests/test1) pins no results in this fork
- * (expected_network.jsn == network.jsn).  The oracle is
- * pinned against KAT-0: error, #correct and per-layer
- * sums recorded from the reference's own Cpu build on tests/test1/network.jsn +
- * the first 10 sequences of examples/speech_recognition_chime/val_1_speaker.nc
- * (tests/test_oracle_kat0.py), and cross-checked against an independent fp64
- * autograd model of the same equations (tests/test_oracle_autograd.py).
- * `oracle/_ref` (the reference compiled from its own sources) is NOT built:
- * the layer sources need Boost (absent in this image) and stand-ins for
- * missing libraries are not permitted.
+ * PINNING: (1) oracle/_ref -- the reference's own object code for the arithmetic of this path: helpers/Matrix.cu
+ * compiled as it lies under /root/reference, and the functors of layers/LstmLayer.cu, FeedForwardLayer.cu,
+ * SoftmaxLayer.cu and MulticlassClassificationLayer.cu driven by a harness (oracle/ref/*.cpp) in the reference's call
+ * order.  tests/test_oracle_ref.py holds this file BIT-EQUAL to it (all LSTM internals, outputs, propagated errors,
+ * every gradient, five training steps of the KAT-0 network); tests/golden/ref_golden.npz carries vectors generated from
+ * it for machines without /root/reference (tests/test_oracle_golden.py).  The layer CLASSES of the reference
+ * (TrainableLayer.cu and up) need Boost, absent in this image, and are not built: the time-loop call sequences
+ * (LstmLayer.cu:763-1051) are restated in the harness, and (2) KAT-0 pins those end to end (error,
+ * #correct and per-layer sums of tests/test1/network.jsn on the first 10 sequences of
+ * examples/speech_recognition_chime/val_1_speaker.nc, recorded by the survey session from a shim-assisted build of the
+ * full layer classes; tests/test_oracle_kat0.py).  (3) An independent fp64 autograd model of the same equations
+ * (tests/test_oracle_autograd.py).  The reference's own test (tests/test1) pins nothing in this fork
+ * (expected_network.jsn == network.jsn).
  *
  * Conventions (SURVEY.md section 7 "Memory layouts"):
  *   layer activations  a[(t*PS + ps)*L + unit]      (column-major L x N, N = T*PS)

@@ -86,6 +86,46 @@ def get_threads():
     return int(lib().orc_get_threads())
 
 
+_REF_PATH = os.path.join(_HERE, "_ref", "libcurrennt_ref.so")
+_ref = None
+# the functions oracle/_ref implements with the reference's own functors (oracle/ref/*.cpp): same signatures as orc_*
+_REF_FUNCS = ["matmul", "lstm_forward", "lstm_backward", "ff_forward", "ff_backward", "softmax_forward", "softmax_backward",
+              "mcc_error", "mcc_correct", "mcc_backward"]
+
+
+class _RefLib:
+    """oracle/_ref/libcurrennt_ref.so behind the oracle's function names: orc_X -> ref_X for the functions the reference's
+    own object code covers, the oracle's C restatement for the rest (weight counts, SGD update, other post output layers)."""
+
+    def __init__(self, ref, orc):
+        self._ref, self._orc = ref, orc
+
+    def __getattr__(self, name):
+        if name.startswith("orc_") and name[4:] in _REF_FUNCS:
+            return getattr(self._ref, "ref_" + name[4:])
+        return getattr(self._orc, name)
+
+
+def ref_available():
+    """True when oracle/_ref/libcurrennt_ref.so exists (built here from /root/reference by `make -C oracle _ref`, or
+    shipped prebuilt to the GPU box)."""
+    return os.path.exists(_REF_PATH)
+
+
+def ref_lib():
+    global _ref
+    if _ref is not None:
+        return _ref
+    if not ref_available():
+        raise RuntimeError("oracle/_ref is not built (needs /root/reference: make -C oracle _ref)")
+    R, L = C.CDLL(_REF_PATH), lib()
+    for f in _REF_FUNCS:
+        o, r = getattr(L, "orc_" + f), getattr(R, "ref_" + f)
+        r.argtypes, r.restype = o.argtypes, o.restype
+    _ref = _RefLib(R, L)
+    return _ref
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -145,7 +185,10 @@ class _Layer:
 class OracleNetwork:
     """Layer stack driven like NeuralNetwork.cpp:37-130,161-190."""
 
-    def __init__(self, layers, weights, parallel_sequences, max_seq_length):
+    def __init__(self, layers, weights, parallel_sequences, max_seq_length, backend="oracle"):
+        """backend "oracle": the C restatement; "ref": the same call sequence through oracle/_ref, i.e. the reference's own
+        compiled functors and Cpu GEMM (tests/test_oracle_ref.py holds the two bit-equal)."""
+        self._L = lib() if backend == "oracle" else ref_lib()
         self.PS, self.maxT = parallel_sequences, max_seq_length
         self.layers = []
         prev = None
@@ -178,7 +221,7 @@ class OracleNetwork:
 
     # -- NeuralNetwork::computeForwardPass (NeuralNetwork.cpp:168-173)
     def compute_forward_pass(self):
-        L = lib()
+        L = self._L
         for lay in self.layers[1:-1]:
             P, x = lay.prev.size, lay.prev.outputs
             if lay.type in ("lstm", "blstm"):
@@ -194,7 +237,7 @@ class OracleNetwork:
 
     # -- PostOutputLayer::calculateError
     def calculate_error(self):
-        L = lib()
+        L = self._L
         post, out = self.layers[-1], self.layers[-2]
         if post.type == "multiclass_classification":
             return float(L.orc_mcc_error(post.size, self.N, self.targetClasses, out.outputs))
@@ -203,12 +246,12 @@ class OracleNetwork:
     def count_correct_classifications(self):
         post, out = self.layers[-1], self.layers[-2]
         if post.type == "binary_classification":
-            return int(lib().orc_binary_correct(self.N, self.patTypes, self.targets, out.outputs))
-        return int(lib().orc_mcc_correct(post.size, self.N, self.targetClasses, out.outputs))
+            return int(self._L.orc_binary_correct(self.N, self.patTypes, self.targets, out.outputs))
+        return int(self._L.orc_mcc_correct(post.size, self.N, self.targetClasses, out.outputs))
 
     # -- NeuralNetwork::computeBackwardPass (NeuralNetwork.cpp:175-184), reverse order
     def compute_backward_pass(self):
-        L = lib()
+        L = self._L
         post, out = self.layers[-1], self.layers[-2]
         if post.type == "multiclass_classification":
             L.orc_mcc_backward(post.size, self.N, self.targetClasses, out.outputs, out.outputErrors)

@@ -70,3 +70,25 @@ def random_sequences(rng, lengths, P, C=None, L=None):
 
 def real_mask(frac):
     return np.asarray(frac["patTypes"]).reshape(-1) != 0
+
+
+def load_ref_golden(name):
+    """One case of tests/golden/ref_golden.npz (outputs of the reference's own compiled functors, made by
+    tests/golden/make_ref_golden.py): (layers, weights, xs, ts, PS, expected dict)."""
+    z = np.load(os.path.join(GOLDEN, "ref_golden.npz"))
+    pre = name + "/"
+    layers = json.loads(str(z[pre + "layers_json"]))
+    weights, exp = {}, {}
+    for k in z.files:
+        if not k.startswith(pre):
+            continue
+        parts = k[len(pre):].split("/")
+        if parts[0] == "w":
+            weights.setdefault(parts[1], {})[parts[2]] = z[k]
+        elif parts[0] not in ("layers_json", "PS", "seqLengths", "inputs", "targetClasses"):
+            exp["/".join(parts)] = z[k]
+    lens = z[pre + "seqLengths"]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    xs = [z[pre + "inputs"][off[i]:off[i + 1]] for i in range(len(lens))]
+    ts = [z[pre + "targetClasses"][off[i]:off[i + 1]] for i in range(len(lens))]
+    return layers, weights, xs, ts, int(z[pre + "PS"]), exp
