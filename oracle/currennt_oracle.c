@@ -12,7 +12,7 @@
  *
  * PINNING: (1) oracle/_ref -- the reference's own object code for the arithmetic of this path: helpers/Matrix.cu
  * compiled as it lies under /root/reference, and the functors of layers/LstmLayer.cu, FeedForwardLayer.cu,
- * SoftmaxLayer.cu and MulticlassClassificationLayer.cu driven by a harness (oracle/ref/*.cpp) in the reference's call
+ * SoftmaxLayer.cu and MulticlassClassificationLayer.cu driven by a harness (the oracle/ref sources) in the reference's call
  * order.  tests/test_oracle_ref.py holds this file BIT-EQUAL to it (all LSTM internals, outputs, propagated errors,
  * every gradient, five training steps of the KAT-0 network); tests/golden/ref_golden.npz carries vectors generated from
  * it for machines without /root/reference (tests/test_oracle_golden.py).  The layer CLASSES of the reference
