@@ -36,7 +36,7 @@ def test_kat0_oracle(pkg, orc):
     err = net.calculate_error()
     cor = net.count_correct_classifications()
     net.compute_backward_pass()
-    assert abs(err - KAT0_ERROR) < 2e-3, err          # fp32 sum of 1345 logs, printed with 6 decimals
+    assert abs(err - KAT0_ERROR) < 6e-4, err          # one fp32 ulp at 5293 (4.9e-4): the recorded value is matched to the last bit
     assert cor == KAT0_CORRECT
     N = frac["T"] * 10
     for name, (nw, s_out, s_dw, n_dw) in KAT0_LAYERS.items():
@@ -44,8 +44,9 @@ def test_kat0_oracle(pkg, orc):
         assert lay.weights.size == nw
         out = lay.outputs[:N * lay.size].astype(np.float64)
         dw = lay.weightUpdates.astype(np.float64)
-        # the survey printed 7 significant digits of fp32-accumulated sums; allow 2e-5 relative
-        # (plus a small absolute term for the sums that cancel to ~1e-3)
-        assert abs(out.sum() - s_out) <= 2e-5 * abs(s_out) + 2e-4, (name, out.sum(), s_out)
-        assert abs(dw.sum() - s_dw) <= 2e-5 * abs(s_dw) + 2e-5 * np.abs(dw).sum(), (name, dw.sum(), s_dw)
-        assert abs(np.sqrt((dw * dw).sum()) - n_dw) <= 2e-5 * n_dw, (name, np.sqrt((dw * dw).sum()), n_dw)
+        # the survey printed 7 significant digits: 1e-6 relative is what that printing allows (measured: <= 1.4e-7 on every
+        # ||dW||); sums that cancel (subsample_level_1's outputs add up to 7e-3 from terms of order 1) get an absolute term
+        # scaled by the sum of magnitudes
+        assert abs(out.sum() - s_out) <= 1e-6 * abs(s_out) + 1e-7 * np.abs(out).sum(), (name, out.sum(), s_out)
+        assert abs(dw.sum() - s_dw) <= 1e-6 * abs(s_dw) + 1e-6 * np.abs(dw).sum(), (name, dw.sum(), s_dw)
+        assert abs(np.sqrt((dw * dw).sum()) - n_dw) <= 1e-6 * n_dw, (name, np.sqrt((dw * dw).sum()), n_dw)
