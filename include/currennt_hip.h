@@ -46,8 +46,13 @@ typedef enum cn_status {
 
 /* arithmetic mode of the GEMM operands (accumulation and all state are always fp32) */
 typedef enum cn_precision {
-    CN_PREC_F32  = 0,   /* fp32 operands on v_mfma_f32_*_f32: parity mode (real_t = float, Types.hpp:39) */
-    CN_PREC_BF16 = 1    /* bf16 operands on v_mfma_f32_*_bf16: throughput mode                           */
+    CN_PREC_F32    = 0, /* fp32 operands on v_mfma_f32_*_f32: exact-fp32 parity mode (real_t = float, Types.hpp:39); the fp32
+                           MFMAs run at 1/16 of the bf16 rate                                                              */
+    CN_PREC_BF16   = 1, /* bf16 operands on v_mfma_f32_*_bf16: throughput mode                                            */
+    CN_PREC_BF16X3 = 2  /* fp32 operands in memory, every operand split into bf16 hi + bf16 lo inside the kernels and a product
+                           computed as three bf16 MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulation): ~2^-16 relative per term,
+                           i.e. the fp32 tolerance of BASELINE.json (posterior max-abs < 1e-4) at a third of the bf16 MFMA rate --
+                           the parity mode that is fast; state, activations and gradients sums are fp32 as in the other modes      */
 } cn_precision;
 
 /* layer kinds = the type strings of LayerFactory.cu:52-87 that are on the hot path */

@@ -7,7 +7,7 @@ layers/Layer.hpp) used by the tests and bench.py.  The directory name contains a
 loaded through `__graft_entry__.load_package()` under the module name `lstm_rnn_amd`.
 """
 from .binding import (CurrenntHipError, lib_path, load_library, build_library,  # noqa: F401
-                      PREC_F32, PREC_BF16, LAYER_KINDS, BUF)
+                      PREC_F32, PREC_BF16, PREC_BF16X3, LAYER_KINDS, BUF)
 from .fraction import make_fraction, make_fractions, PATTYPE_NONE  # noqa: F401
 from .network import NeuralNetwork  # noqa: F401
 from . import parallel  # noqa: F401

@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 COMM_ID_BYTES = 128
 
 # cn_layer_kind, keyed by the type strings of LayerFactory.cu:52-87

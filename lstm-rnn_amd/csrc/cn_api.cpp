@@ -70,7 +70,8 @@ struct cn_ctx {
     std::vector<hipStream_t> pending_join_streams;   // ... and the stream each event was recorded on (same index)
     bool overlap = true;
     bool attach_forks = true;                  // CN_NO_ATTACHED_FORKS=1: fork / join / update events recorded with hipEventRecord
-    bool f32 = true;
+    bool f32 = true;                           // operands are fp32 in memory (CN_PREC_F32 and CN_PREC_BF16X3)
+    int prec = P_F32;                          // arithmetic of the MFMA products: P_F32 / P_BF16 / P_X3 (cn_internal.h)
     int num_cus = 256;                         // hipDeviceProp_t::multiProcessorCount of the bound device
     std::string arch;
     std::vector<cn_layer *> layers;
@@ -464,11 +465,11 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
 void check_rec_lds(const cn_layer *l, bool bwd)
 {
     const cn_ctx *c = l->ctx;
-    const size_t need = lstm_rec_lds_bytes(c->f32, bwd, l->Hp, c->rpl, c->T);
+    const size_t need = lstm_rec_lds_bytes(c->prec, bwd, l->Hp, c->rpl, c->T);
     if (need > 160 * 1024)
         throw cn_error(CN_ERR_SHAPE, "LSTM layer with " + std::to_string(l->H) + " units per direction, " + std::to_string(c->T) +
                        " time steps: the recurrent " + (bwd ? "backward" : "forward") + " kernel needs " + std::to_string(need / 1024) +
-                       " KB of LDS per workgroup (160 KB available)" + (c->f32 ? "; use CN_PREC_BF16 for layers this wide" : "") +
+                       " KB of LDS per workgroup (160 KB available)" + (c->prec == P_F32 ? "; use CN_PREC_BF16 or CN_PREC_BF16X3 for layers this wide" : "") +
                        " or shorter fractions (truncate_seq)");
 }
 
@@ -483,12 +484,12 @@ void lstm_forward(cn_layer *l)
         g.A = l->prev->out_op; g.lda = l->Pp; g.B = l->Win; g.ldb = l->Pp;
         g.C = l->acts; g.ldc = R; g.C2 = nullptr; g.ldc2 = 0; g.bias = l->bias_p; g.act = ACT_IDENTITY;
         g.M = c->N; g.N = R; g.K = l->Pp;
-        launch_gemm_nt(c->stream, c->f32, g);
+        launch_gemm_nt(c->stream, c->prec, g);
     }
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, false, r, &c->xch_epoch)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->f32, r); }
+        if (!launch_lstm_cluster(c->stream, c->prec, false, r, &c->xch_epoch)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->prec, r); }
         HIP_CHECK(hipGetLastError());
     }
 }
@@ -504,12 +505,12 @@ void lstm_backward(cn_layer *l)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r);
-        if (!launch_lstm_cluster(c->stream, c->f32, true, r, &c->xch_epoch)) {
+        if (!launch_lstm_cluster(c->stream, c->prec, true, r, &c->xch_epoch)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
             static const bool tail_on_side = getenv("CN_TAIL_ON_SIDE") != nullptr;
             hipEvent_t fork = (tail_on_side && !l->prev->trainable && !c->timing) ? fork_event(l) : nullptr;
-            launch_lstm_backward(c->stream, c->f32, r, fork);
+            launch_lstm_backward(c->stream, c->prec, r, fork);
             fork_attached = fork != nullptr;
         }
         HIP_CHECK(hipGetLastError());
@@ -521,7 +522,7 @@ void lstm_backward(cn_layer *l)
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = R;
         hipEvent_t fork = c->timing ? nullptr : fork_event(l);     // (timing mode records its own events around the kernel)
-        launch_gemm_nt(c->stream, c->f32, g, fork);
+        launch_gemm_nt(c->stream, c->prec, g, fork);
         fork_attached = fork != nullptr;
     }
     // K9 runs on the side stream: it only feeds weightUpdates, forked AFTER K8 so the critical-path GEMM has the chip to itself, and running beside the
@@ -547,7 +548,7 @@ void lstm_backward(cn_layer *l)
                     gs[ng++] = r;
                 }
             }
-            launch_gemm_tn_group(st, c->f32, gs, ng);      // the three products side by side in one launch
+            launch_gemm_tn_group(st, c->prec, gs, ng);      // the three products side by side in one launch
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -570,7 +571,7 @@ void ff_forward(cn_layer *l)
         g.C2 = (!c->f32 && !softmax) ? l->out_op : nullptr; g.ldc2 = l->Lp;
         g.bias = l->bias_p; g.act = ff_act(l->kind);
         g.M = c->N; g.N = l->Lp; g.K = l->Pp;
-        launch_gemm_nt(c->stream, c->f32, g);
+        launch_gemm_nt(c->stream, c->prec, g);
     }
     if (softmax) {
         Timed tm(c, KC_OTHER);
@@ -606,7 +607,7 @@ void ff_backward(cn_layer *l)
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = l->Lp;
         hipEvent_t fork = c->timing ? nullptr : fork_event(l);
-        launch_gemm_nt(c->stream, c->f32, g, fork);
+        launch_gemm_nt(c->stream, c->prec, g, fork);
         fork_attached = fork != nullptr;
     }
     on_side(l, [&](hipStream_t st, hipEvent_t join) {
@@ -615,7 +616,7 @@ void ff_backward(cn_layer *l)
             GemmTN g{};
             g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
-            launch_gemm_tn(st, c->f32, g);
+            launch_gemm_tn(st, c->prec, g);
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -659,7 +660,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
 {
     if (!out) { g_last_error = "cn_ctx_create: out is NULL"; return CN_ERR_BAD_ARG; }
     *out = nullptr;
-    if (precision != CN_PREC_F32 && precision != CN_PREC_BF16) { g_last_error = "cn_ctx_create: unknown precision"; return CN_ERR_BAD_ARG; }
+    if (precision != CN_PREC_F32 && precision != CN_PREC_BF16 && precision != CN_PREC_BF16X3) { g_last_error = "cn_ctx_create: unknown precision"; return CN_ERR_BAD_ARG; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         g_last_error = "cn_ctx_create: no HIP device available (this library has no CPU fallback)";
@@ -675,7 +676,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         if (arch.rfind("gfx950", 0) != 0)
             throw cn_error(CN_ERR_NO_DEVICE, "cn_ctx_create: device is " + arch + ", this library is built for gfx950 only");
         c = new cn_ctx;
-        c->device = device_id; c->arch = arch; c->f32 = (precision == CN_PREC_F32);
+        c->device = device_id; c->arch = arch; c->f32 = (precision != CN_PREC_BF16);
+        c->prec = precision == CN_PREC_BF16 ? P_BF16 : (precision == CN_PREC_BF16X3 ? P_X3 : P_F32);
         c->num_cus = prop.multiProcessorCount;
         if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
         else { HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
@@ -946,7 +948,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
             l->dWin = l->grad_block; l->dWrec = l->dWin + R * l->Pp; l->dbias = l->dWrec + R * l->Hp; l->dpeep = l->dbias + R;
             {   // exchange buffer of the multi-CU cluster kernels (layers whose W_rec exceeds one CU)
-                const size_t xb = lstm_cluster_xch_bytes(ctx->f32, l->Hp, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus);
+                const size_t xb = lstm_cluster_xch_bytes(ctx->prec, l->Hp, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus);
                 if (xb > ctx->xch_bytes) {
                     if (ctx->d_xch) HIP_CHECK(hipFree(ctx->d_xch));
                     HIP_CHECK(hipMalloc((void **)&ctx->d_xch, xb));
@@ -1583,13 +1585,13 @@ const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward)
     if (!layer || !layer->lstm) return name.c_str();
     cn_ctx *c = layer->ctx;
     const char *dirn = backward ? "bwd" : "fwd";
-    const int cs = lstm_cluster_size(c->f32, layer->Hp, layer->dirs, c->PSp, c->rpl, c->num_cus);
+    const int cs = lstm_cluster_size(c->prec, layer->Hp, layer->dirs, c->PSp, c->rpl, c->num_cus);
     char buf[160];
     if (c->d_xch && cs > 0)
         snprintf(buf, sizeof(buf), "lstm_%s_cluster_kernel<%d,%d,%d>", dirn, layer->Hp, layer->Hp / cs, c->rpl);
     else {
-        const bool resident = lstm_rec_resident(c->f32, layer->Hp);
-        snprintf(buf, sizeof(buf), "lstm_%s_kernel<%s,%d,1,%d>", dirn, c->f32 ? "true" : "false", resident ? layer->Hp : 0, c->rpl);
+        const bool resident = lstm_rec_resident(c->prec, layer->Hp);
+        snprintf(buf, sizeof(buf), "lstm_%s_kernel<%d,%d,1,%d>", dirn, c->prec, resident ? layer->Hp : 0, c->rpl);
     }
     name = buf;
     return name.c_str();
@@ -1615,7 +1617,7 @@ int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
         launch_pad_convert(ctx->stream, ctx->f32, dA, M, K, oA, K);
         launch_pad_convert(ctx->stream, ctx->f32, dB, N, K, oB, K);
         GemmNT g{}; g.A = oA; g.lda = K; g.B = oB; g.ldb = K; g.C = dC; g.ldc = N; g.bias = dbias; g.act = act; g.M = M; g.N = N; g.K = K;
-        launch_gemm_nt(ctx->stream, ctx->f32, g);
+        launch_gemm_nt(ctx->stream, ctx->prec, g);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1640,7 +1642,7 @@ int cn_dbg_gemm_tn(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
         launch_pad_convert(ctx->stream, ctx->f32, dA, K, M, oA, M);
         launch_pad_convert(ctx->stream, ctx->f32, dB, K, N, oB, N);
         GemmTN g{}; g.A = oA; g.lda = M; g.B = oB; g.ldb = N; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-        launch_gemm_tn(ctx->stream, ctx->f32, g);
+        launch_gemm_tn(ctx->stream, ctx->prec, g);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));

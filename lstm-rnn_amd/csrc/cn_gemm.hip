@@ -15,17 +15,15 @@
 //             Split-K over frames, fp32 atomics into the pre-zeroed gradient.
 // Operand type: bf16 (v_mfma_f32_32x32x16_bf16) or fp32 (v_mfma_f32_32x32x2_f32, exact fp32).
 #include "cn_internal.h"
+#include "cn_lstm_device.h"      // vector types, split_bf16
 
 #include <cstdlib>
 
 namespace cn {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 __device__ __forceinline__ float act_apply(int act, float x)
 {
@@ -56,6 +54,23 @@ __device__ __forceinline__ void mma32(f32x16 &acc, const u32x4 &a, const u32x4 &
     }
 }
 
+// split-bf16 product of one 16-element K-group of a 32x32 tile (P_X3): three bf16 MFMAs, small terms first
+__device__ __forceinline__ void mma32_x3(f32x16 &acc, const u32x4 &ah, const u32x4 &al, const u32x4 &bh, const u32x4 &bl)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+}
+// four fp32 -> 4 bf16 hi and 4 bf16 lo (8 bytes each)
+__device__ __forceinline__ void split4(const u32x4 &x, u32x2 &hi, u32x2 &lo)
+{
+    const f32x4 f = __builtin_bit_cast(f32x4, x);
+    bf16x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { __bf16 a, b; split_bf16(f[i], a, b); h[i] = a; l[i] = b; }
+    hi = __builtin_bit_cast(u32x2, h); lo = __builtin_bit_cast(u32x2, l);
+}
+
 // ---------------------------------------------------------------------------------------------
 // gemm_nt
 // ---------------------------------------------------------------------------------------------
@@ -69,11 +84,12 @@ constexpr int NT_NBUF = 1, NT_EPI_HALVES = 2;
 constexpr int NT_EPI_BYTES = NT_BM / NT_EPI_HALVES * (NT_BN * 4 + 16);
 constexpr int NT_LDS_BYTES = (2 * NT_NBUF * NT_TILE_BYTES > NT_EPI_BYTES) ? 2 * NT_NBUF * NT_TILE_BYTES : NT_EPI_BYTES;
 
-template <bool F32>
+template <int PREC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int nwg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ELT = F32 ? 4 : 2;
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3;
+    constexpr int ELT = PREC == P_BF16 ? 2 : 4;          // operand element in MEMORY (P_X3: fp32, split when it enters the LDS)
     constexpr int KB = NT_ROWB / ELT;          // k elements per tile row
     constexpr int CH = 16 / ELT;               // k elements per 16-byte chunk
 
@@ -112,8 +128,17 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = tid + 256 * j, row = c >> 3, kc = c & 7;
-            *(u32x4 *)(sa + row * NT_PITCH + kc * 16) = ra[j];
-            *(u32x4 *)(sb + row * NT_PITCH + kc * 16) = rb[j];
+            if constexpr (X3) {
+                // a tile row holds 32 k: [32 bf16 hi | 32 bf16 lo] in the same 128 bytes the fp32 row would take
+                u32x2 h, l;
+                split4(ra[j], h, l);
+                *(u32x2 *)(sa + row * NT_PITCH + kc * 8) = h; *(u32x2 *)(sa + row * NT_PITCH + 64 + kc * 8) = l;
+                split4(rb[j], h, l);
+                *(u32x2 *)(sb + row * NT_PITCH + kc * 8) = h; *(u32x2 *)(sb + row * NT_PITCH + 64 + kc * 8) = l;
+            } else {
+                *(u32x4 *)(sa + row * NT_PITCH + kc * 16) = ra[j];
+                *(u32x4 *)(sb + row * NT_PITCH + kc * 16) = rb[j];
+            }
         }
     };
 
@@ -132,6 +157,23 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
         const char *sa = smem + (kt % NT_NBUF) * 2 * NT_TILE_BYTES, *sb = sa + NT_TILE_BYTES;
+        if constexpr (X3) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                u32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+                    al[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + 64 + g * 32 + fh * 16);
+                    bh[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+                    bl[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + 64 + g * 32 + fh * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma32_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             u32x4 a[2], b[2];
@@ -144,6 +186,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) mma32<F32>(acc[i][j], a[i], b[j]);
+        }
         }
         if (NT_NBUF == 1) __syncthreads();
         if (kt + 1 < nk) lwrite((kt + 1) % NT_NBUF);
@@ -184,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
                 for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e] + bv[e]);
                 if (p.C) *(f32x4 *)(p.C + (long)m * p.ldc + n) = v;
                 if (p.C2) {
-                    if constexpr (F32) *(f32x4 *)((float *)p.C2 + (long)m * p.ldc2 + n) = v;
+                    if constexpr (ELT == 4) *(f32x4 *)((float *)p.C2 + (long)m * p.ldc2 + n) = v;
                     else {
                         const bf16x4 hh = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                         *(bf16x4 *)((__bf16 *)p.C2 + (long)m * p.ldc2 + n) = hh;
@@ -195,19 +238,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     }
 }
 
-void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done)
+void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 {
     if (g.M <= 0 || g.N <= 0) return;
-    if (gemm_nt_big_applies(f32, g)) { launch_gemm_nt_big(s, f32, g, done); return; }
+    if (gemm_nt_big_applies(prec, g)) { launch_gemm_nt_big(s, prec, g, done); return; }
     int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
     int nwg = tiles_m * tiles_n;
     static DeviceOnce attr_once;
     if (attr_once.first()) {   // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_X3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     }
-    if (f32) hipExtLaunchKernelGGL(gemm_nt_kernel<true>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
-    else     hipExtLaunchKernelGGL(gemm_nt_kernel<false>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    if (prec == P_F32)     hipExtLaunchKernelGGL(gemm_nt_kernel<P_F32>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    else if (prec == P_X3) hipExtLaunchKernelGGL(gemm_nt_kernel<P_X3>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    else                   hipExtLaunchKernelGGL(gemm_nt_kernel<P_BF16>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -220,13 +265,16 @@ constexpr int tn_bk(int bt) { return bt == 64 ? 64 : 32; }
 // one LDS buffer per operand, next k-tile in registers (as gemm_nt): more workgroups per CU; the 8000 x 1024 x 25 600
 // product gains 32 % (342 -> 450 TFLOP/s), the small split-K products are unchanged
 constexpr int TN_NBUF = 1;
-template <bool F32, int BT> struct TnGeom {
-    static constexpr int ELT = F32 ? 4 : 2;
+template <int PREC, int BT> struct TnGeom {
+    static constexpr int ELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory
+    static constexpr int LELT = PREC == P_F32 ? 4 : 2;     // element of an LDS plane (P_X3: two bf16 planes, hi and lo)
+    static constexpr int PLANES = PREC == P_X3 ? 2 : 1;
     static constexpr int BK = tn_bk(BT);
-    static constexpr int PITCH = BT * ELT + 64;            // K-major rows; 4 consecutive k rows hit distinct bank quarters
-    static constexpr int TILE = BK * PITCH;
+    static constexpr int PITCH = BT * LELT + 64;           // K-major rows; 4 consecutive k rows hit distinct bank quarters
+    static constexpr int PLANE = BK * PITCH;
+    static constexpr int TILE = PLANES * PLANE;
     static constexpr int LDS = 2 * TN_NBUF * TILE;         // (A,B) x TN_NBUF buffers
-    static constexpr int CPR = BT * ELT / 16;              // 16-byte chunks per tile row
+    static constexpr int CPR = BT * ELT / 16;              // 16-byte chunks per tile row (in memory)
     static constexpr int NLD = BK * CPR / 256;          // chunks per thread per operand
     static constexpr int WT = BT / 64;                     // 32x32 MFMA tiles per wave and dimension
 };
@@ -240,11 +288,12 @@ struct GemmTNGroup {
     int tiles_n[TN_GROUP], ntiles[TN_GROUP], kchunk[TN_GROUP], first_block[TN_GROUP + 1];
 };
 
-template <bool F32, int BT>
+template <int PREC, int BT>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = TnGeom<F32, BT>;
+    using G = TnGeom<PREC, BT>;
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3;
     constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD, WT = G::WT;
     constexpr int CH = 16 / ELT;
 
@@ -284,8 +333,16 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
-            *(u32x4 *)(sa + kr * PITCH + cc * 16) = ra[j];
-            *(u32x4 *)(sb + kr * PITCH + cc * 16) = rb[j];
+            if constexpr (X3) {
+                u32x2 h, l;
+                split4(ra[j], h, l);
+                *(u32x2 *)(sa + kr * PITCH + cc * 8) = h; *(u32x2 *)(sa + G::PLANE + kr * PITCH + cc * 8) = l;
+                split4(rb[j], h, l);
+                *(u32x2 *)(sb + kr * PITCH + cc * 8) = h; *(u32x2 *)(sb + G::PLANE + kr * PITCH + cc * 8) = l;
+            } else {
+                *(u32x4 *)(sa + kr * PITCH + cc * 16) = ra[j];
+                *(u32x4 *)(sb + kr * PITCH + cc * 16) = rb[j];
+            }
         }
     };
 
@@ -326,7 +383,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
             const int g16 = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
 #pragma unroll
             for (int ks = 0; ks < G::BK / 16; ++ks) {
-                bf16x8 a[WT], b[WT];
+                bf16x8 a[G::PLANES][WT], b[G::PLANES][WT];
+#pragma unroll
+                for (int pl = 0; pl < G::PLANES; ++pl)
 #pragma unroll
                 for (int i = 0; i < WT; ++i) {
 #pragma unroll
@@ -335,19 +394,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
                         int ma = wm * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
                         int nb = wn * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
                         s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3))) *)(sa + k * PITCH + ma * 2));
+                            (s16x4 __attribute__((address_space(3))) *)(sa + pl * G::PLANE + k * PITCH + ma * 2));
                         s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3))) *)(sb + k * PITCH + nb * 2));
+                            (s16x4 __attribute__((address_space(3))) *)(sb + pl * G::PLANE + k * PITCH + nb * 2));
                         bf16x4 ta = __builtin_bit_cast(bf16x4, va), tb = __builtin_bit_cast(bf16x4, vb);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[i][4 * jj + e] = ta[e]; b[i][4 * jj + e] = tb[e]; }
+                        for (int e = 0; e < 4; ++e) { a[pl][i][4 * jj + e] = ta[e]; b[pl][i][4 * jj + e] = tb[e]; }
                     }
                 }
 #pragma unroll
                 for (int i = 0; i < WT; ++i)
 #pragma unroll
-                    for (int j = 0; j < WT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < WT; ++j) {
+                        if constexpr (X3) {          // plane 0 = hi, plane 1 = lo; small terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
         if (TN_NBUF == 1) __syncthreads();
@@ -371,10 +435,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     }
 }
 
-template <bool F32, int BT>
+template <int PREC, int BT>
 static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
-    using G = TnGeom<F32, BT>;
+    using G = TnGeom<PREC, BT>;
     GemmTNGroup grp{};
     int blocks = 0;
     long all_tiles = 0;
@@ -402,8 +466,8 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
     }
     grp.first_block[TN_GROUP] = blocks;
     if (blocks == 0) return;
-    auto kern = gemm_tn_kernel<F32, BT>;
-    constexpr int lds = TnGeom<F32, BT>::LDS;
+    auto kern = gemm_tn_kernel<PREC, BT>;
+    constexpr int lds = TnGeom<PREC, BT>::LDS;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -418,22 +482,29 @@ static bool tn_big_tiles(const GemmTN &g)
     return (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 2048;
 }
 
-void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g)
+template <int BT> static void launch_tn_prec(hipStream_t s, int prec, const GemmTN *gs, int n)
 {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    if (tn_big_tiles(g)) { if (f32) launch_tn<true, 128>(s, &g, 1); else launch_tn<false, 128>(s, &g, 1); }
-    else                 { if (f32) launch_tn<true, 64>(s, &g, 1);  else launch_tn<false, 64>(s, &g, 1); }
+    if (prec == P_F32) launch_tn<P_F32, BT>(s, gs, n);
+    else if (prec == P_X3) launch_tn<P_X3, BT>(s, gs, n);
+    else launch_tn<P_BF16, BT>(s, gs, n);
 }
 
-void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n)
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g)
+{
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+    if (tn_big_tiles(g)) launch_tn_prec<128>(s, prec, &g, 1);
+    else                 launch_tn_prec<64>(s, prec, &g, 1);
+}
+
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n)
 {
     GemmTN small[TN_GROUP]; int ns = 0;
     for (int i = 0; i < n; ++i) {
         if (gs[i].M <= 0 || gs[i].N <= 0 || gs[i].K <= 0) continue;
-        if (tn_big_tiles(gs[i]) || ns == TN_GROUP) launch_gemm_tn(s, f32, gs[i]);      // (not grouped)
+        if (tn_big_tiles(gs[i]) || ns == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
         else small[ns++] = gs[i];
     }
-    if (ns) { if (f32) launch_tn<true, 64>(s, small, ns); else launch_tn<false, 64>(s, small, ns); }
+    if (ns) launch_tn_prec<64>(s, prec, small, ns);
 }
 
 }  // namespace cn

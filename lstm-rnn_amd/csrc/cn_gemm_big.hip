@@ -180,8 +180,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(GemmNT p, int tiles_n,
 
 // Does this product go to the 256 x 256 kernel?  K in whole k-tiles, and enough tiles to fill the chip about twice
 // (smaller outputs keep the 128 x 128 kernel: more, shorter workgroups).
-bool gemm_nt_big_applies(bool f32, const GemmNT &g)
+bool gemm_nt_big_applies(int prec, const GemmNT &g)
 {
+    const bool f32 = prec != P_BF16;     // the LDS-DMA kernel is bf16 only (P_F32 / P_X3 operands are fp32 in memory)
     static const bool off = getenv("CN_NO_BIG_GEMM") != nullptr;
     const int KB = BG_ROWB / (f32 ? 4 : 2);
     if (off || g.K % KB != 0 || g.K < 4 * KB) return false;
@@ -189,8 +190,9 @@ bool gemm_nt_big_applies(bool f32, const GemmNT &g)
     return tiles >= 384;
 }
 
-void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done)
+void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 {
+    const bool f32 = prec != P_BF16;
     const int tiles_m = (g.M + BG_BM - 1) / BG_BM, tiles_n = (g.N + BG_BN - 1) / BG_BN, nwg = tiles_m * tiles_n;
     static DeviceOnce attr_once;
     if (attr_once.first()) {

@@ -20,6 +20,15 @@ enum KClass { KC_REC_FWD = 0, KC_REC_BWD = 1, KC_GEMM_WIDE = 2, KC_GEMM_GRAD = 3
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Arithmetic of the MFMA products (`prec` arguments of the launchers below).  The values of P_BF16 / P_F32 equal
+// false / true, so a caller that only knows "fp32 operands or not" may pass a bool.
+//   P_BF16  bf16 operands in memory and in the MFMAs (throughput mode)
+//   P_F32   fp32 operands in memory, exact-fp32 MFMAs (v_mfma_f32_*_f32, 1/16 of the bf16 rate)
+//   P_X3    fp32 operands in memory; every operand is split in the kernel into bf16 hi + bf16 lo (x = hi + lo + O(2^-17 x))
+//           and a product is three bf16 MFMAs (hi*hi + lo*hi + hi*lo, fp32 accumulation): ~2^-16 relative per term, a third
+//           of the bf16 rate -- the parity mode that is fast (CN_PREC_BF16X3)
+enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
+
 // hipFuncSetAttribute (the > 64 KB dynamic LDS opt-in) is per device: a process may drive several GPUs
 struct DeviceOnce {
     std::atomic<unsigned long long> seen{0};
@@ -51,12 +60,12 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
 };
 // `done`: optional event that completes with the kernel itself (hipExtLaunchKernelGGL stop event): a fork point for
 // another stream without a marker packet on this stream (an hipEventRecord between two kernels costs the second one ~7 us)
-void launch_gemm_nt(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done = nullptr);
+void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
 // 256 x 256 LDS-DMA variant for the MFMA-bound shapes (cn_gemm_big.hip); launch_gemm_nt dispatches to it
-bool gemm_nt_big_applies(bool f32, const GemmNT &g);
-void launch_gemm_nt_big(hipStream_t s, bool f32, const GemmNT &g, hipEvent_t done = nullptr);
-void launch_gemm_tn(hipStream_t s, bool f32, const GemmTN &g);
-void launch_gemm_tn_group(hipStream_t s, bool f32, const GemmTN *gs, int n);      // up to 3 small products in one launch
+bool gemm_nt_big_applies(int prec, const GemmNT &g);
+void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g);
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n);      // up to 3 small products in one launch
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------
 struct LstmRec {
@@ -82,18 +91,18 @@ struct LstmRec {
     int *fault;                   // set to 1 by a bounded spin that gave up
     int num_cus;                  // CUs of the device: a cluster grid must be resident as a whole
 };
-size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T);       // dynamic LDS per workgroup of the single-CU kernels
-bool lstm_rec_resident(bool f32, int Hp);                                     // W_rec fragments register resident (single-CU kernels)
-void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p);
-void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
+size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T);        // dynamic LDS per workgroup of the single-CU kernels
+bool lstm_rec_resident(int prec, int Hp);                                      // W_rec fragments register resident (single-CU kernels)
+void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p);
+void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
 // `num_cus`: the CU count of the device; the spin-wait hand-off needs every member workgroup resident, so a grid larger
 // than the device (a partitioned or CU-masked part) does not take the cluster path
-size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus);
-int lstm_cluster_size(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus);     // CUs per cluster, 0 = path does not apply
+size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);
+int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);     // CUs per cluster, 0 = path does not apply
 // `epoch`: the context's granule-tag counter; the launcher hands tags epoch + 1 ... epoch + T to this launch and advances
 // the counter by T + 1, so no caller can forget to (stale granules of an earlier launch never match)
-bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch);
+bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned *epoch);
 void lstm_cluster_stream_gone(hipStream_t s);         // cn_ctx_destroy: the per-device launch gate forgets the stream
 
 // ---- element-wise / packing kernels -----------------------------------------------------------

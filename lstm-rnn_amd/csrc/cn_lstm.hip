@@ -85,11 +85,17 @@ __device__ __forceinline__ void build_dummy_table(unsigned char *dtab, const cha
 // UG  : unit groups (of 16) per wave
 // RPL : sequences per lane; a workgroup handles 4*RPL sequences: sequence s0 + 4*r + q sits in MFMA
 //       tile row 4*q + r (q = lane>>4, r < RPL), rows r >= RPL are zero padding
-template <bool F32, int HP, int UG, int RPL>
+// PREC : P_BF16 / P_F32 / P_X3 (cn_internal.h).  P_X3 keeps fp32 in memory like P_F32 and two bf16 planes (hi, lo) of the y
+//        tile in LDS; W_rec is split once, in the prologue, into hi and lo fragments (the registers the fp32 fragments take
+//        in P_F32), and a K chunk of the product is three bf16 MFMAs instead of eight fp32 ones.
+template <int PREC, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ELT = F32 ? 4 : 2;
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC != P_BF16;      // ACC: libm-grade activations
+    constexpr int MELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory (y, W_rec)
+    constexpr int ELT = F32 ? 4 : 2;                 // operand element in LDS / MFMA fragments
+    constexpr int PLANES = X3 ? 2 : 1;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
     const int pitch = lds_pitch(Hp * ELT);           // LDS row pitch of the y tile (bytes)
@@ -109,12 +115,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     const long crow = (long)dirs * Hp;               // cell / y row stride (elements)
 
     // zero both y tiles (y[prev] of the first processed step is 0; padding rows stay 0)
-    for (int i = threadIdx.x * 4; i < 2 * TROWS * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    const int plane = TROWS * pitch;                 // P_X3: hi plane, then lo plane
+    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
     u32x4 wreg[UG][4][KCR];
-    const char *Wd = (const char *)p.Wrec + (long)d * 4 * Hp * Hp * ELT;
+    [[maybe_unused]] u32x4 wlo[X3 ? UG : 1][4][KCR];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * Hp * Hp * MELT;
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
         unit[u] = 16 * (wave + u * nw) + c;
@@ -125,8 +133,13 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int kc = 0; kc < KCR; ++kc)
-                    wreg[u][g][kc] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+                for (int kc = 0; kc < KCR; ++kc) {
+                    if constexpr (X3) {
+                        const float *wp = (const float *)Wd + (long)(g * Hp + unit[u]) * Hp + kc * 32 + q * 8;
+                        split8(*(const f32x4 *)wp, *(const f32x4 *)(wp + 4), wreg[u][g][kc], wlo[u][g][kc]);
+                    } else
+                        wreg[u][g][kc] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+                }
         }
     }
 
@@ -174,8 +187,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     STAMP_DECL
     auto step = [&](int it, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
-        const char *ycur = smem + (it & 1) * TROWS * pitch;
-        char *ynxt = smem + ((it + 1) & 1) * TROWS * pitch;
+        const char *ycur = smem + (it & 1) * PLANES * plane;
+        char *ynxt = smem + ((it + 1) & 1) * PLANES * plane;
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         STAMP(0)
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
-        if constexpr (RES && UG > 1 && KCR <= 8) {
+        if constexpr (RES && UG > 1 && KCR <= 8 && !X3) {
             // unit group after unit group: the cell update of group u only needs that group's sums, so it can
             // run on the VALU while the MFMAs of group u+1 are in flight (one wave per SIMD in this shape)
             u32x4 a[KCR];
@@ -236,25 +249,41 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
                 u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+                [[maybe_unused]] u32x4 al;
+                if constexpr (X3) al = *(const u32x4 *)(ycur + plane + c * pitch + kc * 64 + q * 16);
 #ifdef CN_STAMP
                 if (kc == 0) { STAMP_FORCE(a[0]) STAMP(1) }
 #endif
 #pragma unroll
                 for (int u = 0; u < UG; ++u)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) mma16<F32>(acc[u][g], a, wreg[u][g][kc]);
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (X3) mma16_x3(acc[u][g], a, al, wreg[u][g][kc], wlo[u][g][kc]);
+                        else mma16<F32>(acc[u][g], a, wreg[u][g][kc]);
+                    }
             }
         } else {
             for (int kc = 0; kc < KC; ++kc) {
                 const u32x4 a = *(const u32x4 *)(ycur + rrow * pitch + kc * 64 + q * 16);
+                [[maybe_unused]] u32x4 al;
+                if constexpr (X3) al = *(const u32x4 *)(ycur + plane + rrow * pitch + kc * 64 + q * 16);
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
                     u32x4 b[4];
+                    [[maybe_unused]] u32x4 bl[4];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        b[g] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (X3) {       // fp32 W_rec from L2, split on the fly (functional fallback for wide layers)
+                            const float *wp = (const float *)Wd + (long)(g * Hp + unit[u]) * Hp + kc * 32 + q * 8;
+                            split8(*(const f32x4 *)wp, *(const f32x4 *)(wp + 4), b[g], bl[g]);
+                        } else
+                            b[g] = *(const u32x4 *)(Wd + ((long)(g * Hp + unit[u]) * Hp) * ELT + kc * 64 + q * 16);
+                    }
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) mma16<F32>(acc[u][g], a, b[g]);
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (X3) mma16_x3(acc[u][g], a, al, b[g], bl[g]);
+                        else mma16<F32>(acc[u][g], a, b[g]);
+                    }
                 }
             }
         }
@@ -268,12 +297,12 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 const bool dummy = dummy_[r];
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
-                const float ni = tanh_ref<F32>(acc[u][0][r] + g_[u][r][0]);
-                const float ig = logistic<F32>(acc[u][1][r] + g_[u][r][1] + cp * pi[u]);
-                const float fg = logistic<F32>(acc[u][2][r] + g_[u][r][2] + cp * pf[u]);
+                const float ni = tanh_ref<ACC>(acc[u][0][r] + g_[u][r][0]);
+                const float ig = logistic<ACC>(acc[u][1][r] + g_[u][r][1] + cp * pi[u]);
+                const float fg = logistic<ACC>(acc[u][2][r] + g_[u][r][2] + cp * pf[u]);
                 const float cs = ni * ig + cp * fg;
-                const float og = logistic<F32>(acc[u][3][r] + g_[u][r][3] + cs * po[u]);
-                const float y = tanh_ref<F32>(cs) * og;
+                const float og = logistic<ACC>(acc[u][3][r] + g_[u][r][3] + cs * po[u]);
+                const float y = tanh_ref<ACC>(cs) * og;
                 float yo = dummy ? 0.f : y;
                 const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
                 cst[u][r] = co;
@@ -281,11 +310,16 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(yo) STAMP(3) }
 #endif
                 if constexpr (F32) *(float *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 4) = yo;
-                else *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = (__bf16)yo;
+                else if constexpr (X3) {
+                    __bf16 yh, yl;
+                    split_bf16(yo, yh, yl);
+                    *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = yh;
+                    *(__bf16 *)(ynxt + plane + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = yl;
+                } else *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = (__bf16)yo;
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
                 *(f32x4 *)(actsT + oA[u][r]) = av;
                 cellT[oC[u][r]] = co;
-                if constexpr (F32) ((float *)p.y_op + t * stepC)[oC[u][r]] = yo;
+                if constexpr (MELT == 4) ((float *)p.y_op + t * stepC)[oC[u][r]] = yo;
                 else ((__bf16 *)p.y_op + t * stepC)[oC[u][r]] = (__bf16)yo;
             }
         }
@@ -329,11 +363,14 @@ template <int UG, int RPL> struct BwdPre {
     float cp[UG][RPL];       // cell state of prev(t)
 };
 
-template <bool F32, int HP, int UG, int RPL>
+template <int PREC, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ELT = F32 ? 4 : 2;
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC != P_BF16;
+    constexpr int MELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory (delta, W_rec^T)
+    constexpr int ELT = F32 ? 4 : 2;                 // operand element in LDS / MFMA fragments (P_X3: two bf16 planes)
+    constexpr int PLANES = X3 ? 2 : 1;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
     const int pitch = lds_pitch(4 * Hp * ELT);       // LDS row pitch of the delta tile, k = 4*unit + gate
@@ -352,17 +389,19 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     const long arow = (long)dirs * 4 * Hp;
     const long crow = (long)dirs * Hp;
 
-    for (int i = threadIdx.x * 4; i < 2 * TROWS * pitch; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    const int plane = TROWS * pitch;
+    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
     // dummy-slot table of this workgroup's sequences, read per step from LDS (LstmLayer.cu:224-234 with
     // checkPatType of :949,983); the forward kernel stages the pattern type through its register prefetch
     // instead, which measured faster there (0.47 vs 0.49 us per step) and slower here
-    unsigned char *dtab = (unsigned char *)smem + 2 * TROWS * pitch;
+    unsigned char *dtab = (unsigned char *)smem + 2 * PLANES * plane;
     build_dummy_table<RPL>(dtab, p.pat, T, p.Tmin, p.PS, (blockIdx.x / p.dirs) * (4 * RPL));
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
     u32x4 wreg[UG][KCR];
-    const char *Wd = (const char *)p.WrecT + (long)d * 4 * Hp * Hp * ELT;
+    [[maybe_unused]] u32x4 wlo[X3 ? UG : 1][KCR];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * Hp * Hp * MELT;
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
         unit[u] = 16 * (wave + u * nw) + c;
@@ -371,8 +410,13 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         po[u] = p.peep[(d * 3 + 2) * Hp + unit[u]];
         if constexpr (RES) {
 #pragma unroll
-            for (int kc = 0; kc < KCR; ++kc)
-                wreg[u][kc] = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
+            for (int kc = 0; kc < KCR; ++kc) {
+                if constexpr (X3) {
+                    const float *wp = (const float *)Wd + (long)unit[u] * 4 * Hp + kc * 32 + q * 8;
+                    split8(*(const f32x4 *)wp, *(const f32x4 *)(wp + 4), wreg[u][kc], wlo[u][kc]);
+                } else
+                    wreg[u][kc] = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
+            }
         }
     }
 
@@ -425,8 +469,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     STAMP_DECL
     auto step = [&](int it, BwdPre<UG, RPL> &pre) {
         const int t = d ? it : T - 1 - it;
-        const char *dcur = smem + (it & 1) * TROWS * pitch;
-        char *dnxt = smem + ((it + 1) & 1) * TROWS * pitch;
+        const char *dcur = smem + (it & 1) * PLANES * plane;
+        char *dnxt = smem + ((it + 1) & 1) * PLANES * plane;
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
         const unsigned bD = (unsigned)t * stepA;
@@ -467,32 +511,49 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
             // scheduler issues each read one chunk ahead, so every MFMA group waits most of an LDS round trip
             // (16 of them per step); reading everything up front costs 64 VGPRs and pushes W_rec into AGPRs.
             constexpr int LDS_AHEAD = KCR < 4 ? KCR : 4;
+            constexpr int MPC = (X3 ? 3 : (F32 ? 4 : 1)) * UG;      // MFMAs per K chunk
             u32x4 a[KCR];
+            [[maybe_unused]] u32x4 al[X3 ? KCR : 1];
 #pragma unroll
-            for (int kc = 0; kc < KCR; ++kc) a[kc] = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+            for (int kc = 0; kc < KCR; ++kc) {
+                a[kc] = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+                if constexpr (X3) al[kc] = *(const u32x4 *)(dcur + plane + c * pitch + kc * 64 + q * 16);
+            }
 #ifdef CN_STAMP
             STAMP_FORCE(a[0][0]) STAMP(1)
 #endif
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
 #pragma unroll
-                for (int u = 0; u < UG; ++u) mma16<F32>(acc[u], a[kc], wreg[u][kc]);
+                for (int u = 0; u < UG; ++u) {
+                    if constexpr (X3) mma16_x3(acc[u], a[kc], al[kc], wreg[u][kc], wlo[u][kc]);
+                    else mma16<F32>(acc[u], a[kc], wreg[u][kc]);
+                }
             }
 #ifndef CN_STAMP
-            __builtin_amdgcn_sched_group_barrier(0x100, LDS_AHEAD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, PLANES * LDS_AHEAD, 0);
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
-                __builtin_amdgcn_sched_group_barrier(0x008, UG, 0);
-                if (kc + LDS_AHEAD < KCR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MPC, 0);
+                if (kc + LDS_AHEAD < KCR) __builtin_amdgcn_sched_group_barrier(0x100, PLANES, 0);
             }
 #endif
         } else {
             for (int kc = 0; kc < KC; ++kc) {
                 const u32x4 a = *(const u32x4 *)(dcur + rrow * pitch + kc * 64 + q * 16);
+                [[maybe_unused]] u32x4 al;
+                if constexpr (X3) al = *(const u32x4 *)(dcur + plane + rrow * pitch + kc * 64 + q * 16);
 #pragma unroll
                 for (int u = 0; u < UG; ++u) {
-                    const u32x4 b = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
-                    mma16<F32>(acc[u], a, b);
+                    if constexpr (X3) {
+                        u32x4 b, bl;
+                        const float *wp = (const float *)Wd + (long)unit[u] * 4 * Hp + kc * 32 + q * 8;
+                        split8(*(const f32x4 *)wp, *(const f32x4 *)(wp + 4), b, bl);
+                        mma16_x3(acc[u], a, al, b, bl);
+                    } else {
+                        const u32x4 b = *(const u32x4 *)(Wd + ((long)unit[u] * 4 * Hp) * ELT + kc * 64 + q * 16);
+                        mma16<F32>(acc[u], a, b);
+                    }
                 }
             }
         }
@@ -507,7 +568,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 const float e = acc[u][r];
                 const float ni = a_[u][r][0], ig = a_[u][r][1], fg = a_[u][r][2], og = a_[u][r][3];
                 const float cs = ccur[u][r], cp = cp_[u][r];
-                const float th = tanh_ref<F32>(cs);
+                const float th = tanh_ref<ACC>(cs);
                 float dog = og * (1.0f - og) * th * e;
                 float ec = og * (1.0f - th * th) * e + po[u] * dog;
                 ec += fgn[u][r] * ecn[u][r] + pi[u] * dign[u][r] + pf[u] * dfgn[u][r];   // zero carry at firstCall
@@ -530,6 +591,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 if constexpr (F32) {
                     const f32x4 dv = {dni, dig, dfg, dog};
                     *(f32x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 16) = dv;
+                    *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
+                } else if constexpr (X3) {
+                    const f32x4 dv = {dni, dig, dfg, dog};
+                    bf16x4 dh, dl;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(dv[g], h_, l_); dh[g] = h_; dl[g] = l_; }
+                    *(bf16x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dh;
+                    *(bf16x4 *)(dnxt + plane + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dl;
                     *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
                 } else {
                     const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
@@ -588,14 +657,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <bool F32, bool BWD, int HP, int UG, int RPL>
+template <int PREC, bool BWD, int HP, int UG, int RPL>
 static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t done)
 {
-    const int ELT = F32 ? 4 : 2;
+    const int ELT = PREC == P_F32 ? 4 : 2, PLANES = PREC == P_X3 ? 2 : 1;
     const int nsg = p.PS / (4 * RPL);                // PS is padded to whole sequence groups
     const int pitch = lds_pitch((BWD ? 4 : 1) * p.Hp * ELT);
-    const size_t lds = 2 * (size_t)(HP ? 16 : 4 * RPL + 1) * pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
-    auto kern = BWD ? lstm_bwd_kernel<F32, HP, UG, RPL> : lstm_fwd_kernel<F32, HP, UG, RPL>;
+    const size_t lds = 2 * (size_t)PLANES * (HP ? 16 : 4 * RPL + 1) * pitch + (BWD ? (((size_t)p.T * 4 * RPL + 15) & ~(size_t)15) : 0);   // tiles (+ dummy-slot table)
+    auto kern = BWD ? lstm_bwd_kernel<PREC, HP, UG, RPL> : lstm_fwd_kernel<PREC, HP, UG, RPL>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -609,42 +678,45 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t d
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
 }
 
-template <bool F32, bool BWD, int HP, int UG>
+template <int PREC, bool BWD, int HP, int UG>
 static void launch_rpl(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t done)
 {
-    if (p.rpl == 1)      launch_one<F32, BWD, HP, UG, 1>(s, p, nwaves, done);
-    else if (p.rpl == 2) launch_one<F32, BWD, HP, UG, 2>(s, p, nwaves, done);
-    else               launch_one<F32, BWD, HP, UG, 4>(s, p, nwaves, done);
+    if (p.rpl == 1)      launch_one<PREC, BWD, HP, UG, 1>(s, p, nwaves, done);
+    else if (p.rpl == 2) launch_one<PREC, BWD, HP, UG, 2>(s, p, nwaves, done);
+    else               launch_one<PREC, BWD, HP, UG, 4>(s, p, nwaves, done);
 }
 
-template <bool F32, bool BWD>
+template <int PREC, bool BWD>
 static void launch_rec(hipStream_t s, const LstmRec &p, hipEvent_t done = nullptr)
 {
+    constexpr bool F32 = PREC != P_BF16;             // (register budget of the fragments: P_X3 = P_F32)
     const int groups = p.Hp / 16;
     switch (p.Hp) {
-    case 32:  launch_rpl<F32, BWD, 32, 1>(s, p, 2, done); return;
-    case 64:  launch_rpl<F32, BWD, 64, 1>(s, p, 4, done); return;
-    case 96:  launch_rpl<F32, BWD, 96, 1>(s, p, 6, done); return;
+    case 32:  launch_rpl<PREC, BWD, 32, 1>(s, p, 2, done); return;
+    case 64:  launch_rpl<PREC, BWD, 64, 1>(s, p, 4, done); return;
+    case 96:  launch_rpl<PREC, BWD, 96, 1>(s, p, 6, done); return;
     case 128:
         // 8 waves x 1 unit group (two waves per SIMD overlap each other's MFMA, VALU and scalar issue).  For the
         // backward kernel 4 waves x 2 unit groups (half the LDS operand reads: every wave reads the whole
         // 16 x 4Hp delta tile) used to win by 4 %; since the stage copies removed the latch stall it loses:
         // 0.64 vs 0.56 us per step (CN_BWD_UG2 keeps it selectable)
-        if (BWD && !F32 && getenv("CN_BWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4, done);
-        else if (!BWD && !F32 && getenv("CN_FWD_UG2")) launch_rpl<F32, BWD, 128, 2>(s, p, 4, done);   // measured slower: 0.63 vs 0.47 us per step
-        else launch_rpl<F32, BWD, 128, 1>(s, p, 8, done);
+        if constexpr (PREC == P_BF16) {
+            if (BWD && getenv("CN_BWD_UG2")) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }
+            if (!BWD && getenv("CN_FWD_UG2")) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }   // measured slower: 0.63 vs 0.47 us per step
+        }
+        launch_rpl<PREC, BWD, 128, 1>(s, p, 8, done);
         return;
     case 160:     // bf16 only: 200 / 288 KB of W_rec still fit one CU's registers (10 / 12 waves, three on some SIMDs)
-        if constexpr (!F32) { launch_rpl<F32, BWD, 160, 1>(s, p, 10, done); return; }
+        if constexpr (!F32) { launch_rpl<PREC, BWD, 160, 1>(s, p, 10, done); return; }
         break;
     case 192:
-        if constexpr (!F32) { launch_rpl<F32, BWD, 192, 1>(s, p, 12, done); return; }
+        if constexpr (!F32) { launch_rpl<PREC, BWD, 192, 1>(s, p, 12, done); return; }
         break;
     default: break;
     }
-    if (groups <= 16)      launch_rpl<F32, BWD, 0, 1>(s, p, groups, done);
-    else if (groups <= 32) launch_rpl<F32, BWD, 0, 2>(s, p, groups / 2, done);
-    else                   launch_rpl<F32, BWD, 0, 4>(s, p, groups / 4, done);
+    if (groups <= 16)      launch_rpl<PREC, BWD, 0, 1>(s, p, groups, done);
+    else if (groups <= 32) launch_rpl<PREC, BWD, 0, 2>(s, p, groups / 2, done);
+    else                   launch_rpl<PREC, BWD, 0, 4>(s, p, groups / 4, done);
 }
 
 #ifdef CN_STAMP
@@ -656,25 +728,29 @@ extern "C" int cn_dbg_read_stamps(unsigned long long *host)      // [2][16][8]
 
 // dynamic LDS of one workgroup of the single-CU kernels (launch_one): two operand tiles (+ the backward kernel's
 // dummy-slot table); resident shapes are those launch_rec dispatches on
-bool lstm_rec_resident(bool f32, int Hp)
+bool lstm_rec_resident(int prec, int Hp)
 {
-    return Hp == 32 || Hp == 64 || Hp == 96 || Hp == 128 || (!f32 && (Hp == 160 || Hp == 192));
+    return Hp == 32 || Hp == 64 || Hp == 96 || Hp == 128 || (prec == P_BF16 && (Hp == 160 || Hp == 192));
 }
-size_t lstm_rec_lds_bytes(bool f32, bool bwd, int Hp, int rpl, int T)
+size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T)
 {
-    const int ELT = f32 ? 4 : 2;
-    const bool resident = lstm_rec_resident(f32, Hp);
+    const int ELT = prec == P_F32 ? 4 : 2, PLANES = prec == P_X3 ? 2 : 1;
+    const bool resident = lstm_rec_resident(prec, Hp);
     const size_t pitch = (size_t)lds_pitch((bwd ? 4 : 1) * Hp * ELT);
-    return 2 * (size_t)(resident ? 16 : 4 * rpl + 1) * pitch + (bwd ? (((size_t)T * 4 * rpl + 15) & ~(size_t)15) : 0);
+    return 2 * (size_t)PLANES * (resident ? 16 : 4 * rpl + 1) * pitch + (bwd ? (((size_t)T * 4 * rpl + 15) & ~(size_t)15) : 0);
 }
 
-void launch_lstm_forward(hipStream_t s, bool f32, const LstmRec &p)
+void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p)
 {
-    if (f32) launch_rec<true, false>(s, p); else launch_rec<false, false>(s, p);
+    if (prec == P_F32) launch_rec<P_F32, false>(s, p);
+    else if (prec == P_X3) launch_rec<P_X3, false>(s, p);
+    else launch_rec<P_BF16, false>(s, p);
 }
-void launch_lstm_backward(hipStream_t s, bool f32, const LstmRec &p, hipEvent_t done)
+void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t done)
 {
-    if (f32) launch_rec<true, true>(s, p, done); else launch_rec<false, true>(s, p, done);
+    if (prec == P_F32) launch_rec<P_F32, true>(s, p, done);
+    else if (prec == P_X3) launch_rec<P_X3, true>(s, p, done);
+    else launch_rec<P_BF16, true>(s, p, done);
 }
 
 }  // namespace cn

@@ -437,17 +437,18 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
 static int cluster_size(int Hp) { return Hp == 256 ? 2 : (Hp == 512 ? 8 : 0); }
 
 // bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
-int lstm_cluster_size(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus)
+int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
 {
     const int CS = cluster_size(Hp);
+    const bool f32 = prec != P_BF16;                  // the cluster kernels are bf16 only
     if (f32 || CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     if ((nclusters + 7) / 8 * 8 * CS > num_cus) return 0;      // every member must be resident (one workgroup per CU)
     return CS;
 }
-size_t lstm_cluster_xch_bytes(bool f32, int Hp, int dirs, int PS, int rpl, int num_cus)
+size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
 {
-    const int CS = lstm_cluster_size(f32, Hp, dirs, PS, rpl, num_cus);
+    const int CS = lstm_cluster_size(prec, Hp, dirs, PS, rpl, num_cus);
     if (CS == 0) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     const int NT = (Hp / CS) * 4;
@@ -481,9 +482,9 @@ void lstm_cluster_stream_gone(hipStream_t s)
     if (gate.last_stream == s) gate.last_stream = nullptr;
 }
 
-bool launch_lstm_cluster(hipStream_t s, bool f32, bool bwd, LstmRec &p, unsigned *epoch)
+bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned *epoch)
 {
-    if (!p.xch || lstm_cluster_size(f32, p.Hp, p.dirs, p.PS, p.rpl, p.num_cus) == 0) return false;
+    if (!p.xch || lstm_cluster_size(prec, p.Hp, p.dirs, p.PS, p.rpl, p.num_cus) == 0) return false;
     p.xch_epoch = *epoch;
     *epoch += (unsigned)p.T + 1;
     ClusterGate &gate = cluster_gate();

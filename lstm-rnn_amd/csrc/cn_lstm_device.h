@@ -57,6 +57,35 @@ __host__ __device__ constexpr int lds_pitch(int row_bytes)
     return row_bytes + 16 * ((2 - (row_bytes / 16) % 4 + 4) % 4);
 }
 
+// ---- split-bf16 ("bf16x3") operands -----------------------------------------------------------------------------
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-17 |x| (two 8-bit significands, round to nearest):
+// a product a*b ~ ah*bh + al*bh + ah*bl drops al*bl (2^-18) and the two r terms (2^-17 each): ~2^-16 relative per term
+// with fp32 accumulation, against 2^-9 for plain bf16 operands and 2^-24 for fp32.
+__device__ __forceinline__ void split_bf16(float x, __bf16 &hi, __bf16 &lo)
+{
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+// eight consecutive fp32 (two 16-byte vectors) -> one MFMA fragment of 8 bf16 hi and one of 8 bf16 lo
+__device__ __forceinline__ void split8(const f32x4 &x0, const f32x4 &x1, u32x4 &hi, u32x4 &lo)
+{
+    bf16x8 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __bf16 a, b;
+        split_bf16(x0[i], a, b); h[i] = a; l[i] = b;
+        split_bf16(x1[i], a, b); h[4 + i] = a; l[4 + i] = b;
+    }
+    hi = __builtin_bit_cast(u32x4, h); lo = __builtin_bit_cast(u32x4, l);
+}
+// three bf16 MFMAs of one 32-element K chunk of a 16x16 tile product (small terms first)
+__device__ __forceinline__ void mma16_x3(f32x4 &acc, const u32x4 &ah, const u32x4 &al, const u32x4 &bh, const u32x4 &bl)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+}
+
 // workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
 // stay in flight across it (a __syncthreads() would drain vmcnt every step)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

@@ -37,7 +37,7 @@ const char *Configuration::usage()
 {
     return "Usage: currennt_hip [options] [options-file]\n"
            "  common:   --network F --parallel_sequences N --random_seed N --cuda B(ignored) --list_devices B\n"
-           "            --precision f32|bf16 --device N\n"
+           "            --precision f32|bf16|bf16x3 --device N\n"
            "            --gpus N (training only: data-parallel over N GPUs of this node, devices --device .. --device+N-1;\n"
            "                      parallel_sequences is per GPU; gradients are summed with RCCL)\n"
            "  training: --train B --stochastic B (= --hybrid_online_batch) --shuffle_fractions B --shuffle_sequences B\n"
@@ -98,6 +98,7 @@ void Configuration::apply(const std::string &key, const std::string &v)
     else if (key == "weights_normal_mean") m_weightsNormalMean = (real_t)atof(v.c_str());
     else if (key == "precision") {
         if (v == "f32" || v == "fp32") m_precision = CN_PREC_F32; else if (v == "bf16") m_precision = CN_PREC_BF16;
+        else if (v == "bf16x3") m_precision = CN_PREC_BF16X3;
         else throw std::runtime_error("Error while parsing the command line and/or options file: unknown precision '" + v + "'");
     }
     else if (key == "device") m_device = atoi(v.c_str());

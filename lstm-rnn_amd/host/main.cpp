@@ -412,7 +412,7 @@ int main(int argc, const char *argv[])
         }
         printf("Started in %s training mode.\n", config.hybridOnlineBatch() ? "hybrid online/batch" : "batch");   // Configuration.cpp:316
         printf("Computations run on the MI355X (libcurrennt_hip: %s, %s operands).\n", cn_version(),
-               config.precision() == CN_PREC_BF16 ? "bf16" : "fp32");
+               config.precision() == CN_PREC_BF16 ? "bf16" : (config.precision() == CN_PREC_BF16X3 ? "fp32 (split-bf16 x3 products)" : "fp32"));
         const bool forceDp = getenv("CN_DP_FORCE") != 0;       // test hook: --gpus 1 through the whole data-parallel path
         if (config.gpus() == 1 && !forceDp) return trainerMain(config);
         if (!config.trainingMode()) throw std::runtime_error("--gpus > 1 is a training option");

@@ -61,6 +61,16 @@ def test_config2_literal_chime_network_fp32(pkg, orc):
     net.close()
 
 
+def test_config2_literal_chime_network_bf16x3(pkg, orc):
+    """The same net and frames in CN_PREC_BF16X3, at the fp32 tolerances (H = 150 -> Hp = 160: streamed W_rec, split per step)."""
+    rng = np.random.RandomState(51)
+    layers = net_desc(39, CHIME_LAYERS, 51)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts, frac = chime_fraction(pkg)
+    ref, net = check_network(pkg, orc, layers, weights, frac, 10, precision=pkg.PREC_BF16X3)
+    net.close()
+
+
 def test_config2_literal_chime_network_bf16(pkg, orc):
     """The same net in the bf16 throughput mode (H = 78 / 150 / 51 -> the 6-, 10- and 4-wave register-resident kernels)."""
     rng = np.random.RandomState(51)
@@ -96,6 +106,13 @@ def test_config3_lvcsr_softmax8000_fp32(pkg, orc, depth):
         real = real_mask(frac)
         y = net.outputs().reshape(-1, C)
         assert np.abs(y[real].sum(1) - 1.0).max() < 1e-5
+
+
+def test_config3_lvcsr_softmax8000_bf16x3(pkg, orc):
+    """2 x blstm512 -> softmax 8000 in CN_PREC_BF16X3 at the fp32 tolerances."""
+    layers, weights, frac, PS, C = lvcsr_case(pkg, 2)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16X3)
+    net.close()
 
 
 def test_config3_lvcsr_softmax8000_bf16(pkg, orc):

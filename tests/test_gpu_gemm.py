@@ -23,7 +23,7 @@ def lib(pkg):
     return pkg.load_library(), B
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(60, 128, 32), (1000, 1024, 256), (130, 192, 96),
                                    (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024)])
 def test_gemm_nt(lib, prec, shape):
@@ -44,9 +44,12 @@ def test_gemm_nt(lib, prec, shape):
     tol = 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
     bad = np.abs(out - ref)
     assert bad.max() < tol, (bad.max(), tol, np.unravel_index(bad.argmax(), bad.shape))
+    if prec == 2:       # split-bf16 x3: ~2^-16 per term, random signs -> a few 1e-5 * sqrt(K) on N(0,1) operands (float64 reference)
+        ref64 = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
+        assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()
 
 
-@pytest.mark.parametrize("prec", [0, 1])
+@pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 32, 60), (1024, 256, 5000), (96, 160, 333), (4000, 2080, 700)])
 def test_gemm_tn(lib, prec, shape):
     L, B = lib
@@ -64,3 +67,6 @@ def test_gemm_tn(lib, prec, shape):
     ref = A.T @ Bm
     tol = 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
     assert np.abs(out - ref).max() < tol
+    if prec == 2:
+        ref64 = A.astype(np.float64).T @ Bm.astype(np.float64)
+        assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()

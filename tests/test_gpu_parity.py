@@ -30,8 +30,8 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-def check_network(pkg, orc, layers, weights, frac, PS, grad_tol=2e-4):
-    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS)
+def check_network(pkg, orc, layers, weights, frac, PS, grad_tol=2e-4, precision=0):
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision)
     try:
         real = real_mask(frac)
         C = layers[-1]["size"]
@@ -232,6 +232,72 @@ def test_bf16_mode_close(pkg, orc, hidden):
         assert abs(e - e_ref) < 1e-2 * e_ref
         for lay in net.trainable_layers():
             assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 5e-2, lay.name
+
+
+X3_CASES = {
+    # name: (P, hidden, C, lengths, PS, weight scale)
+    "uni_lstm128": (7, [("lstm", 128)], 5, [20, 17, 9], 3, 0.4),                         # register-resident, Hp = 128
+    "blstm_stack": (39, [("blstm", 50)] * 3, 183, [31, 30, 28, 25, 25, 12], 6, 0.1),      # Hp = 32 x 3 layers
+    "blstm250": (39, [("blstm", 250)], 183, [40, 38, 33, 33, 30, 29, 21, 20], 8, 0.1),    # the headline layer shape
+    "blstm320_streamed": (13, [("blstm", 320)], 9, [12, 12, 10, 7, 3], 5, 0.08),          # Hp = 160: W_rec streamed and split per step
+    "tanh_lstm_softmax700": (6, [("feedforward_tanh", 40), ("lstm", 24)], 700, [9, 7, 7, 4], 5, 0.3),
+    "two_sequences_per_lane": (4, [("blstm", 20)], 3, [6, 5] * 260, 520, 0.5),            # rpl = 2
+}
+
+
+@pytest.mark.parametrize("case", sorted(X3_CASES))
+def test_bf16x3_parity_mode(pkg, orc, case):
+    """CN_PREC_BF16X3 (operands split into bf16 hi + lo inside the kernels, three bf16 MFMAs per product, fp32
+    accumulation): the SAME tolerances as the exact-fp32 mode -- posteriors max-abs < 1e-4 (BASELINE.json), error 1e-4
+    relative, #correct exact, gradients and propagated errors within 2e-4 of the layer's max."""
+    P, hidden, C, lengths, PS, scale = X3_CASES[case]
+    rng = np.random.RandomState(71)
+    layers = net_desc(P, hidden, C)
+    weights = random_weights(layers, rng, scale)
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16X3)
+    net.close()
+
+
+def test_bf16x3_mode_stays_on_the_oracle_through_training(pkg, orc):
+    """Sixty momentum-SGD steps on a learnable task in CN_PREC_BF16X3 and in the oracle, from the same weights: after
+    training (error down by more than a third, posteriors far from uniform) the posteriors still agree to 1e-4 and the
+    trained weights to 2e-4 of their range -- a split-product error that compounded through recurrence or training
+    would show here, not at initial weights."""
+    rng = np.random.RandomState(21)
+    P, C, PS, T = 8, 4, 12, 24
+    layers = net_desc(P, [("blstm", 32)], C)
+    weights = random_weights(layers, rng, 0.1)
+    proj = rng.randn(2 * P, C)
+    fracs = []
+    for _ in range(4):
+        xs = [rng.randn(T - (i % 3), P).astype(np.float32) for i in range(PS)]
+        ts = []
+        for x in xs:
+            prev = np.vstack([np.zeros((1, P), np.float32), x[:-1]])
+            ts.append(np.argmax(np.hstack([x, prev]) @ proj, axis=1).astype(np.int32))
+        fracs.append(pkg.make_fraction(xs, ts, PS))
+    ref = orc.OracleNetwork(layers, weights, PS, T)
+    with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_BF16X3) as net:
+        errs = []
+        for step in range(60):
+            for n in (ref, net):
+                n.load_sequences(fracs[step % 4]); n.compute_forward_pass()
+            errs.append((ref.calculate_error(), net.calculate_error()))
+            for n in (ref, net):
+                n.compute_backward_pass(); n.update_weights(2e-3, 0.9)
+        for n in (ref, net):
+            n.load_sequences(fracs[0]); n.compute_forward_pass()
+        first, last = np.mean([e[0] for e in errs[:4]]), np.mean([e[0] for e in errs[-4:]])
+        assert last < 0.67 * first
+        real = real_mask(fracs[0])
+        y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+        assert yr.max() > 0.9 and np.abs(y - yr).max() < POSTERIOR_TOL, (yr.max(), np.abs(y - yr).max())
+        assert abs(errs[-1][1] - errs[-1][0]) < 1e-4 * errs[-1][0]
+        for lay in net.trainable_layers():
+            w, wr = lay.weights(), ref.layer(lay.name).weights
+            assert np.abs(w - wr).max() < 2e-4 * np.abs(wr).max(), (lay.name, np.abs(w - wr).max())
 
 
 def test_error_texts(pkg):
