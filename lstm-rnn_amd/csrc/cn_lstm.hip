@@ -35,6 +35,13 @@
 
 #include <cstdlib>
 
+#ifndef CN_FWD_GATE_MAJOR
+#define CN_FWD_GATE_MAJOR 0
+#endif
+#ifndef CN_X3_ACCURATE_ACT
+#define CN_X3_ACCURATE_ACT 0
+#endif
+
 namespace cn {
 
 // In-kernel segment timing (tools/stamps.py builds a second library with -DCN_STAMP; never defined in the
@@ -92,7 +99,9 @@ template <int PREC, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC != P_BF16;      // ACC: libm-grade activations
+    // ACC: libm-grade expf and IEEE division in the activations (exact-fp32 mode only: v_exp_f32 / v_rcp_f32 are good to
+    // ~1 ulp = 2^-23, far below the 2^-16 of the split products, and the accurate forms cost the P_X3 forward step 25 %)
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC == P_F32 || (X3 && CN_X3_ACCURATE_ACT);
     constexpr int MELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory (y, W_rec)
     constexpr int ELT = F32 ? 4 : 2;                 // operand element in LDS / MFMA fragments
     constexpr int PLANES = X3 ? 2 : 1;
@@ -245,6 +254,17 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
 #endif
+        } else if constexpr (RES && PREC == P_BF16 && UG == 1 && CN_FWD_GATE_MAJOR) {
+            // gate after gate: n, i and f are complete 12 / 8 / 4 MFMAs before the step's last one, so their activations and
+            // the new cell state run on the VALU under the remaining MFMAs; only the output gate's sigmoid and y = tanh(c) * o
+            // are left behind the last MFMA (kc-major, all four gates finish together and the whole update is exposed)
+            u32x4 a[KCR];
+#pragma unroll
+            for (int kc = 0; kc < KCR; ++kc) a[kc] = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int kc = 0; kc < KCR; ++kc) mma16<F32>(acc[0][g], a[kc], wreg[0][g][kc]);
         } else if constexpr (RES) {
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
@@ -367,7 +387,7 @@ template <int PREC, int HP, int UG, int RPL>
 __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC != P_BF16;
+    constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3, ACC = PREC == P_F32 || (X3 && CN_X3_ACCURATE_ACT);
     constexpr int MELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory (delta, W_rec^T)
     constexpr int ELT = F32 ? 4 : 2;                 // operand element in LDS / MFMA fragments (P_X3: two bf16 planes)
     constexpr int PLANES = X3 ? 2 : 1;
