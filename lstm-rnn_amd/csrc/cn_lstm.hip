@@ -35,9 +35,6 @@
 
 #include <cstdlib>
 
-#ifndef CN_FWD_GATE_MAJOR
-#define CN_FWD_GATE_MAJOR 0
-#endif
 #ifndef CN_X3_ACCURATE_ACT
 #define CN_X3_ACCURATE_ACT 0
 #endif
@@ -254,17 +251,6 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             }
 #endif
-        } else if constexpr (RES && PREC == P_BF16 && UG == 1 && CN_FWD_GATE_MAJOR) {
-            // gate after gate: n, i and f are complete 12 / 8 / 4 MFMAs before the step's last one, so their activations and
-            // the new cell state run on the VALU under the remaining MFMAs; only the output gate's sigmoid and y = tanh(c) * o
-            // are left behind the last MFMA (kc-major, all four gates finish together and the whole update is exposed)
-            u32x4 a[KCR];
-#pragma unroll
-            for (int kc = 0; kc < KCR; ++kc) a[kc] = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int kc = 0; kc < KCR; ++kc) mma16<F32>(acc[0][g], a[kc], wreg[0][g][kc]);
         } else if constexpr (RES) {
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {

@@ -1,6 +1,7 @@
 #include "Optimizer.hpp"
 
 #include <limits>
+#include <vector>
 
 namespace currennt_hip {
 namespace optimizers {
@@ -115,30 +116,52 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     return error;
 }
 
+// One epoch (Optimizer.cu:283-324): train, then -- on the epochs the options ask for -- score the validation and test sets,
+// keep the weights of the best validation epoch, and decide whether to stop.  Split into the three questions an epoch asks.
 bool Optimizer::train()
 {
-    if (!m_finished) {
-        ++m_curEpoch;
-        m_curTrainingError = _processDataSet(m_trainingSet, true, &m_curTrainingClassError);
-        if (!m_validationSet.empty() && m_curEpoch % m_validateEvery == 0) {
-            m_curValidationError = _processDataSet(m_validationSet, false, &m_curValidationClassError);
-            if (m_curValidationError < m_lowestValidationError) {
-                m_lowestValidationError = m_curValidationError;
-                m_epochsSinceLowestError = 0;
-                _storeWeights();
-            } else m_epochsSinceLowestError += m_validateEvery;
-        } else if (m_validationSet.empty()) {
-            m_epochsSinceLowestError = 0;
-            _storeWeights();
-        }
-        if (!m_testSet.empty() && m_curEpoch % m_testEvery == 0)
-            m_curTestError = _processDataSet(m_testSet, false, &m_curTestClassError);
-        if (m_epochsSinceLowestError >= m_maxEpochsNoBest || (m_maxEpochs >= 0 && m_curEpoch >= m_maxEpochs)) {
-            _restoreWeights();
-            m_finished = true;
-        }
+    if (m_finished) return true;
+    ++m_curEpoch;
+    m_curTrainingError = _processDataSet(m_trainingSet, true, &m_curTrainingClassError);
+    _scoreValidationSet();
+    if (_dueThisEpoch(m_testSet, m_testEvery)) m_curTestError = _processDataSet(m_testSet, false, &m_curTestClassError);
+    if (_shouldStop()) {
+        _restoreWeights();          // training ends on the best weights seen, not on the last ones
+        m_finished = true;
     }
     return m_finished;
+}
+
+bool Optimizer::_dueThisEpoch(const data_sets::DataSet &set, int every) const
+{
+    return !set.empty() && m_curEpoch % every == 0;
+}
+
+void Optimizer::_scoreValidationSet()
+{
+    if (m_validationSet.empty()) {
+        // nothing to select on: every epoch counts as the best so far
+        m_epochsSinceLowestError = 0;
+        _storeWeights();
+        return;
+    }
+    if (!_dueThisEpoch(m_validationSet, m_validateEvery)) return;
+    m_curValidationError = _processDataSet(m_validationSet, false, &m_curValidationClassError);
+    const bool improved = m_curValidationError < m_lowestValidationError;
+    if (improved) {
+        m_lowestValidationError = m_curValidationError;
+        m_epochsSinceLowestError = 0;
+        _storeWeights();
+    } else {
+        m_epochsSinceLowestError += m_validateEvery;
+    }
+}
+
+bool Optimizer::_shouldStop() const
+{
+    const bool noProgress = m_epochsSinceLowestError >= m_maxEpochsNoBest;
+    const bool outOfEpochs = m_maxEpochs >= 0 && m_curEpoch >= m_maxEpochs;
+    return noProgress || outOfEpochs;
 }
 
 void Optimizer::_exportWeights(json::Value *jsonDoc, const char *arrayName, const std::vector<Hip::real_vector> &weights)
@@ -165,32 +188,49 @@ void Optimizer::_importWeights(const json::Value &jsonDoc, const char *arrayName
     }
 }
 
+// Autosave state (Optimizer.cu:326-358; the JSON keys are the reference's file format).  One table names every scalar of
+// the state once; export and import both walk it.
+namespace {
+struct IntField  { const char *key; int Optimizer::*member; };
+struct RealField { const char *key; real_t Optimizer::*member; };
+}  // namespace
+
+struct Optimizer::StateTable {
+    static const std::vector<IntField> &ints()
+    {
+        static const std::vector<IntField> t = {
+            {"optimizer_cur_epoch", &Optimizer::m_curEpoch},
+            {"optimizer_epochs_since_lowest_error", &Optimizer::m_epochsSinceLowestError},
+        };
+        return t;
+    }
+    static const std::vector<RealField> &reals()
+    {
+        static const std::vector<RealField> t = {
+            {"optimizer_lowest_validation_error", &Optimizer::m_lowestValidationError},
+            {"optimizer_cur_training_error", &Optimizer::m_curTrainingError},
+            {"optimizer_cur_validation_error", &Optimizer::m_curValidationError},
+            {"optimizer_cur_test_error", &Optimizer::m_curTestError},
+            {"optimizer_cur_training_class_error", &Optimizer::m_curTrainingClassError},
+            {"optimizer_cur_validation_class_error", &Optimizer::m_curValidationClassError},
+            {"optimizer_cur_test_class_error", &Optimizer::m_curTestClassError},
+        };
+        return t;
+    }
+};
+
 void Optimizer::exportState(json::Value *jsonDoc) const
 {
     jsonDoc->addMember("optimizer_finished", json::Value(m_finished));
-    jsonDoc->addMember("optimizer_cur_epoch", json::Value(m_curEpoch));
-    jsonDoc->addMember("optimizer_epochs_since_lowest_error", json::Value(m_epochsSinceLowestError));
-    jsonDoc->addMember("optimizer_lowest_validation_error", json::Value((double)m_lowestValidationError));
-    jsonDoc->addMember("optimizer_cur_training_error", json::Value((double)m_curTrainingError));
-    jsonDoc->addMember("optimizer_cur_validation_error", json::Value((double)m_curValidationError));
-    jsonDoc->addMember("optimizer_cur_test_error", json::Value((double)m_curTestError));
-    jsonDoc->addMember("optimizer_cur_training_class_error", json::Value((double)m_curTrainingClassError));
-    jsonDoc->addMember("optimizer_cur_validation_class_error", json::Value((double)m_curValidationClassError));
-    jsonDoc->addMember("optimizer_cur_test_class_error", json::Value((double)m_curTestClassError));
+    for (const IntField &f : StateTable::ints()) jsonDoc->addMember(f.key, json::Value(this->*f.member));
+    for (const RealField &f : StateTable::reals()) jsonDoc->addMember(f.key, json::Value((double)(this->*f.member)));
     _exportWeights(jsonDoc, "optimizer_best_weights", m_bestWeights);
 }
 void Optimizer::importState(const json::Value &jsonDoc)
 {
     m_finished = jsonDoc["optimizer_finished"].getBool();
-    m_curEpoch = jsonDoc["optimizer_cur_epoch"].getInt();
-    m_epochsSinceLowestError = jsonDoc["optimizer_epochs_since_lowest_error"].getInt();
-    m_lowestValidationError = (real_t)jsonDoc["optimizer_lowest_validation_error"].getDouble();
-    m_curTrainingError = (real_t)jsonDoc["optimizer_cur_training_error"].getDouble();
-    m_curValidationError = (real_t)jsonDoc["optimizer_cur_validation_error"].getDouble();
-    m_curTestError = (real_t)jsonDoc["optimizer_cur_test_error"].getDouble();
-    m_curTrainingClassError = (real_t)jsonDoc["optimizer_cur_training_class_error"].getDouble();
-    m_curValidationClassError = (real_t)jsonDoc["optimizer_cur_validation_class_error"].getDouble();
-    m_curTestClassError = (real_t)jsonDoc["optimizer_cur_test_class_error"].getDouble();
+    for (const IntField &f : StateTable::ints()) this->*f.member = jsonDoc[f.key].getInt();
+    for (const RealField &f : StateTable::reals()) this->*f.member = (real_t)jsonDoc[f.key].getDouble();
     _importWeights(jsonDoc, "optimizer_best_weights", &m_bestWeights);
 }
 

@@ -42,6 +42,10 @@ public:
 protected:
     virtual void _updateWeights() = 0;
     real_t _processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates, real_t *classError);   // Optimizer.cu:37-104
+    void _scoreValidationSet();                                         // validation part of train()
+    bool _dueThisEpoch(const data_sets::DataSet &set, int every) const;
+    bool _shouldStop() const;
+    struct StateTable;                                                  // scalars of the autosave state (Optimizer.cpp)
     void _storeWeights();                                               // :151-158
     void _restoreWeights();                                             // :160-168
     NeuralNetwork &_neuralNetwork() { return m_neuralNetwork; }
