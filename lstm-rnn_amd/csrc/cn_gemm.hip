@@ -258,25 +258,31 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 // ---------------------------------------------------------------------------------------------
 // gemm_tn
 // ---------------------------------------------------------------------------------------------
-// BT x BT output tile (BT = 64 or 128), 4 waves as 2 x 2, each wave (BT/2) x (BT/2) in 32x32 MFMA tiles.
+// BM x BN output tile, WM x WN waves, each wave (BM/WM) x (BN/WN) in 32x32 MFMA tiles.  Shapes:
+//   64 x 64   (2 x 2 waves)  the small split-K products when the output is narrow (M < 256)
+//   128 x 128 (2 x 2 waves)  once the output alone fills the chip
+//   (256-row tiles with 4 x 2 waves were measured and rejected: see tn_shape)
 // rows of K per k-step: 64 for the 64 x 64 tiles (the small split-K products: 4-19 % faster than 32, fewer barriers per
-// byte), 32 for the 128 x 128 tiles (64 measured 3 % slower there)
-constexpr int tn_bk(int bt) { return bt == 64 ? 64 : 32; }
+// byte), 32 for the larger tiles (64 measured 3 % slower at 128 x 128)
+constexpr int tn_bk(int bm) { return bm == 64 ? 64 : 32; }
+constexpr int tn_threads(int bm) { return bm == 256 ? 512 : 256; }
 // one LDS buffer per operand, next k-tile in registers (as gemm_nt): more workgroups per CU; the 8000 x 1024 x 25 600
 // product gains 32 % (342 -> 450 TFLOP/s), the small split-K products are unchanged
 constexpr int TN_NBUF = 1;
-template <int PREC, int BT> struct TnGeom {
+template <int PREC, int BM, int BN> struct TnGeom {
     static constexpr int ELT = PREC == P_BF16 ? 2 : 4;     // operand element in memory
     static constexpr int LELT = PREC == P_F32 ? 4 : 2;     // element of an LDS plane (P_X3: two bf16 planes, hi and lo)
     static constexpr int PLANES = PREC == P_X3 ? 2 : 1;
-    static constexpr int BK = tn_bk(BT);
-    static constexpr int PITCH = BT * LELT + 64;           // K-major rows; 4 consecutive k rows hit distinct bank quarters
-    static constexpr int PLANE = BK * PITCH;
-    static constexpr int TILE = PLANES * PLANE;
-    static constexpr int LDS = 2 * TN_NBUF * TILE;         // (A,B) x TN_NBUF buffers
-    static constexpr int CPR = BT * ELT / 16;              // 16-byte chunks per tile row (in memory)
-    static constexpr int NLD = BK * CPR / 256;          // chunks per thread per operand
-    static constexpr int WT = BT / 64;                     // 32x32 MFMA tiles per wave and dimension
+    static constexpr int WM = BM == 256 ? 4 : 2, WN = 2, NT = 64 * WM * WN;
+    static constexpr int BK = tn_bk(BM);
+    static constexpr int PITCH_A = BM * LELT + 64, PITCH_B = BN * LELT + 64;   // K-major rows; 4 consecutive k rows hit distinct bank quarters
+    static constexpr int PLANE_A = BK * PITCH_A, PLANE_B = BK * PITCH_B;
+    static constexpr int TILE_A = PLANES * PLANE_A, TILE_B = PLANES * PLANE_B;
+    static constexpr int LDS = TN_NBUF * (TILE_A + TILE_B);
+    static constexpr int CPR_A = BM * ELT / 16, CPR_B = BN * ELT / 16;         // 16-byte chunks per tile row (in memory)
+    static constexpr int NCH_A = BK * CPR_A, NCH_B = BK * CPR_B;                // chunks of a k-tile
+    static constexpr int NLD_A = (NCH_A + NT - 1) / NT, NLD_B = (NCH_B + NT - 1) / NT;     // chunks per thread (the last round may be partial)
+    static constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;                 // 32x32 MFMA tiles per wave
 };
 
 // Up to TN_GROUP independent products in one launch (the three weight-gradient products of an LSTM layer): each
@@ -288,14 +294,14 @@ struct GemmTNGroup {
     int tiles_n[TN_GROUP], ntiles[TN_GROUP], kchunk[TN_GROUP], first_block[TN_GROUP + 1];
 };
 
-template <int PREC, int BT>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
+template <int PREC, int BM, int BN>
+__global__ __launch_bounds__(tn_threads(BM)) void gemm_tn_kernel(GemmTNGroup grp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using G = TnGeom<PREC, BT>;
+    using G = TnGeom<PREC, BM, BN>;
     constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3;
-    constexpr int ELT = G::ELT, PITCH = G::PITCH, TILE = G::TILE, CPR = G::CPR, NLD = G::NLD, WT = G::WT;
-    constexpr int CH = 16 / ELT;
+    constexpr int ELT = G::ELT, PA = G::PITCH_A, PB = G::PITCH_B, TI = G::TI, TJ = G::TJ, NT = G::NT;
+    constexpr int CH = 16 / ELT, RM = BM / G::WM, RN = BN / G::WN;      // rows / columns of the output a wave owns
 
     int gi = 0;
 #pragma unroll
@@ -305,52 +311,63 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     const int bid = blockIdx.x - grp.first_block[gi];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / G::WN, wn = wave % G::WN;
     const int tile = bid % ntiles, split = bid / ntiles;
-    const int m0 = (tile / tiles_n) * BT, n0 = (tile % tiles_n) * BT;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int kbeg = split * kchunk;
     const int kend = min(p.K, kbeg + kchunk);
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg + G::BK - 1) / G::BK;
 
     const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
-    u32x4 ra[NLD], rb[NLD];
+    u32x4 ra[G::NLD_A], rb[G::NLD_B];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
+        for (int j = 0; j < G::NLD_A; ++j) {
+            int c = tid + NT * j, kr = c / G::CPR_A, cc = c % G::CPR_A;
             int k = kbeg + kt * G::BK + kr;
             u32x4 z = {0u, 0u, 0u, 0u};
-            ra[j] = z; rb[j] = z;
-            if (k < kend) {
-                if (m0 + cc * CH < p.M) ra[j] = *(const u32x4 *)(Ab + ((long)k * p.lda + m0 + cc * CH) * ELT);
-                if (n0 + cc * CH < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)k * p.ldb + n0 + cc * CH) * ELT);
-            }
+            ra[j] = z;
+            if (c < G::NCH_A && k < kend && m0 + cc * CH < p.M) ra[j] = *(const u32x4 *)(Ab + ((long)k * p.lda + m0 + cc * CH) * ELT);
+        }
+#pragma unroll
+        for (int j = 0; j < G::NLD_B; ++j) {
+            int c = tid + NT * j, kr = c / G::CPR_B, cc = c % G::CPR_B;
+            int k = kbeg + kt * G::BK + kr;
+            u32x4 z = {0u, 0u, 0u, 0u};
+            rb[j] = z;
+            if (c < G::NCH_B && k < kend && n0 + cc * CH < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)k * p.ldb + n0 + cc * CH) * ELT);
         }
     };
     auto lwrite = [&](int buf) {
-        char *sa = smem + buf * 2 * TILE, *sb = sa + TILE;
+        char *sa = smem + buf * (G::TILE_A + G::TILE_B), *sb = sa + G::TILE_A;
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            int c = tid + 256 * j, kr = c / CPR, cc = c % CPR;
+        for (int j = 0; j < G::NLD_A; ++j) {
+            int c = tid + NT * j, kr = c / G::CPR_A, cc = c % G::CPR_A;
+            if (G::NCH_A % NT != 0 && c >= G::NCH_A) continue;
             if constexpr (X3) {
                 u32x2 h, l;
                 split4(ra[j], h, l);
-                *(u32x2 *)(sa + kr * PITCH + cc * 8) = h; *(u32x2 *)(sa + G::PLANE + kr * PITCH + cc * 8) = l;
+                *(u32x2 *)(sa + kr * PA + cc * 8) = h; *(u32x2 *)(sa + G::PLANE_A + kr * PA + cc * 8) = l;
+            } else *(u32x4 *)(sa + kr * PA + cc * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G::NLD_B; ++j) {
+            int c = tid + NT * j, kr = c / G::CPR_B, cc = c % G::CPR_B;
+            if (G::NCH_B % NT != 0 && c >= G::NCH_B) continue;
+            if constexpr (X3) {
+                u32x2 h, l;
                 split4(rb[j], h, l);
-                *(u32x2 *)(sb + kr * PITCH + cc * 8) = h; *(u32x2 *)(sb + G::PLANE + kr * PITCH + cc * 8) = l;
-            } else {
-                *(u32x4 *)(sa + kr * PITCH + cc * 16) = ra[j];
-                *(u32x4 *)(sb + kr * PITCH + cc * 16) = rb[j];
-            }
+                *(u32x2 *)(sb + kr * PB + cc * 8) = h; *(u32x2 *)(sb + G::PLANE_B + kr * PB + cc * 8) = l;
+            } else *(u32x4 *)(sb + kr * PB + cc * 16) = rb[j];
         }
     };
 
-    f32x16 acc[WT][WT];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -360,21 +377,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        const char *sa = smem + (kt % TN_NBUF) * 2 * TILE, *sb = sa + TILE;
+        const char *sa = smem + (kt % TN_NBUF) * (G::TILE_A + G::TILE_B), *sb = sa + G::TILE_A;
         if constexpr (F32) {
             // v_mfma_f32_32x32x2_f32: lane (r,h) holds A[m=r][k=2s+h] / B[k=2s+h][n=r]
 #pragma unroll 4
             for (int s2 = 0; s2 < G::BK / 2; ++s2) {
-                float a[WT], b[WT];
+                float a[TI], b[TJ];
 #pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    a[i] = *(const float *)(sa + (2 * s2 + fh) * PITCH + (wm * (BT / 2) + i * 32 + fr) * 4);
-                    b[i] = *(const float *)(sb + (2 * s2 + fh) * PITCH + (wn * (BT / 2) + i * 32 + fr) * 4);
-                }
+                for (int i = 0; i < TI; ++i) a[i] = *(const float *)(sa + (2 * s2 + fh) * PA + (wm * RM + i * 32 + fr) * 4);
 #pragma unroll
-                for (int i = 0; i < WT; ++i)
+                for (int j = 0; j < TJ; ++j) b[j] = *(const float *)(sb + (2 * s2 + fh) * PB + (wn * RN + j * 32 + fr) * 4);
 #pragma unroll
-                    for (int j = 0; j < WT; ++j)
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
@@ -383,29 +399,35 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
             const int g16 = lane >> 4, idx = lane & 15, q = idx >> 2, pp = idx & 3;
 #pragma unroll
             for (int ks = 0; ks < G::BK / 16; ++ks) {
-                bf16x8 a[G::PLANES][WT], b[G::PLANES][WT];
+                bf16x8 a[G::PLANES][TI], b[G::PLANES][TJ];
 #pragma unroll
                 for (int pl = 0; pl < G::PLANES; ++pl)
 #pragma unroll
-                for (int i = 0; i < WT; ++i) {
-#pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        int k = ks * 16 + 8 * (g16 >> 1) + 4 * jj + q;
-                        int ma = wm * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
-                        int nb = wn * (BT / 2) + i * 32 + 16 * (g16 & 1) + 4 * pp;
-                        s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3))) *)(sa + pl * G::PLANE + k * PITCH + ma * 2));
-                        s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (s16x4 __attribute__((address_space(3))) *)(sb + pl * G::PLANE + k * PITCH + nb * 2));
-                        bf16x4 ta = __builtin_bit_cast(bf16x4, va), tb = __builtin_bit_cast(bf16x4, vb);
+                        const int k = ks * 16 + 8 * (g16 >> 1) + 4 * jj + q;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[pl][i][4 * jj + e] = ta[e]; b[pl][i][4 * jj + e] = tb[e]; }
+                        for (int i = 0; i < TI; ++i) {
+                            const int ma = wm * RM + i * 32 + 16 * (g16 & 1) + 4 * pp;
+                            s16x4 va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3))) *)(sa + pl * G::PLANE_A + k * PA + ma * 2));
+                            bf16x4 ta = __builtin_bit_cast(bf16x4, va);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[pl][i][4 * jj + e] = ta[e];
+                        }
+#pragma unroll
+                        for (int j = 0; j < TJ; ++j) {
+                            const int nb = wn * RN + j * 32 + 16 * (g16 & 1) + 4 * pp;
+                            s16x4 vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (s16x4 __attribute__((address_space(3))) *)(sb + pl * G::PLANE_B + k * PB + nb * 2));
+                            bf16x4 tb = __builtin_bit_cast(bf16x4, vb);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) b[pl][j][4 * jj + e] = tb[e];
+                        }
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < WT; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int j = 0; j < WT; ++j) {
+                    for (int j = 0; j < TJ; ++j) {
                         if constexpr (X3) {          // plane 0 = hi, plane 1 = lo; small terms first
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1][i], b[0][j], acc[i][j], 0, 0, 0);
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
@@ -420,14 +442,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     }
 
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
-        const int n = n0 + wn * (BT / 2) + j * 32 + fr;
+    for (int j = 0; j < TJ; ++j) {
+        const int n = n0 + wn * RN + j * 32 + fr;
         if (n >= p.N) continue;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) {
+        for (int i = 0; i < TI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BT / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int m = m0 + wm * RM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= p.M) continue;
                 atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
             }
@@ -435,25 +457,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTNGroup grp)
     }
 }
 
-template <int PREC, int BT>
+template <int PREC, int BM, int BN>
 static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
-    using G = TnGeom<PREC, BT>;
+    using G = TnGeom<PREC, BM, BN>;
     GemmTNGroup grp{};
     int blocks = 0;
     long all_tiles = 0;
-    for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + BT - 1) / BT) * ((gs[i].N + BT - 1) / BT);
+    for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + BM - 1) / BM) * ((gs[i].N + BN - 1) / BN);
     for (int i = 0; i < TN_GROUP; ++i) {
         grp.first_block[i] = blocks;
         if (i >= n) { grp.first_block[i] = 0x7fffffff; continue; }
         const GemmTN &g = gs[i];
-        const int tiles_m = (g.M + BT - 1) / BT, tiles_n = (g.N + BT - 1) / BT, ntiles = tiles_m * tiles_n;
+        const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
         // K splits: enough workgroups (2-3 per CU at 64 rows of K per k-step) to hide the latency of the short per-workgroup K loops, but every
         // split ends in M*N fp32 atomics and the chip adds only ~1.3 TB/s of atomic bytes (MI355X_MICROARCH.md,
         // global float atomics): keep the atomic volume of one launch under ~32 MB and every split >= 4 K-tiles.
-        // (a group shares the ~576 workgroups: its products run side by side, and their atomics add up)
+        // (a group shares the workgroup budget: its products run side by side, and their atomics add up)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
-        static const int target = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 576;   // swept 256..2048 on the headline step: 512-640 best
+        // 576 four-wave workgroups swept best (256..2048) on the headline step for the 64 x 64 tiles
+        static const int target_env = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 0;
+        const int target = target_env ? target_env : 576;
         int splits = (int)((target + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * G::BK - 1) / (4 * G::BK);
         if (splits > maxsplit) splits = maxsplit;
@@ -466,45 +490,61 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
     }
     grp.first_block[TN_GROUP] = blocks;
     if (blocks == 0) return;
-    auto kern = gemm_tn_kernel<PREC, BT>;
-    constexpr int lds = TnGeom<PREC, BT>::LDS;
+    auto kern = gemm_tn_kernel<PREC, BM, BN>;
+    constexpr int lds = G::LDS;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, grp);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NT), lds, s, grp);
 }
 
-static bool tn_big_tiles(const GemmTN &g)
+// tile shape of one launch (all products of a group share it)
+// Measured and rejected (round 2, tools/probe/gemm_bench): 256 x 128 / 256 x 64 tiles (4 x 2 waves) for the LSTM gradient products.
+// They cut the operand bytes a launch requests from ~3.7x to ~1.6x the unique bytes (profiles/r01k_pmc.md: 180 MB for 48 MB), and
+// they are SLOWER at every workgroup budget (96..384): layer 2/3 group 48.0 vs 45.9 us, layer 1 group 35.6 vs 29.7 us.  The
+// re-reads of the 64 x 64 tiles are served by L2 / the Infinity Cache (the operands of one layer are 48 MB); what bounds these
+// products is the latency of their short per-workgroup K loops and the split-K atomics, and fewer, fatter workgroups have less
+// of both to overlap.  The template keeps rectangular tiles (BM x BN, WM x WN waves); only 64 x 64 and 128 x 128 are built.
+enum TnShape { TN_64, TN_128 };
+static TnShape tn_shape(const GemmTN *gs, int n)
 {
-    // weight matrices of this workload are small (<= 1024 x 256): 64 x 64 tiles give the grid enough workgroups
-    // without deep K splits; 128 x 128 tiles take over once the output alone fills the chip
-    return (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 2048;
+    // once the output alone fills the chip, 128 x 128 tiles and few splits (weight matrices of the LVCSR output layer)
+    for (int i = 0; i < n; ++i)
+        if ((long)((gs[i].M + 63) / 64) * ((gs[i].N + 63) / 64) >= 2048) return TN_128;
+    return TN_64;
 }
 
-template <int BT> static void launch_tn_prec(hipStream_t s, int prec, const GemmTN *gs, int n)
+static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n)
 {
-    if (prec == P_F32) launch_tn<P_F32, BT>(s, gs, n);
-    else if (prec == P_X3) launch_tn<P_X3, BT>(s, gs, n);
-    else launch_tn<P_BF16, BT>(s, gs, n);
+    const TnShape sh = tn_shape(gs, n);
+#define CN_TN_DISPATCH(P)                                                      \
+    switch (sh) {                                                              \
+    case TN_64:      launch_tn<P, 64, 64>(s, gs, n); break;                    \
+    case TN_128:     launch_tn<P, 128, 128>(s, gs, n); break;                  \
+    }
+    if (prec == P_F32) { CN_TN_DISPATCH(P_F32) }
+    else if (prec == P_X3) { CN_TN_DISPATCH(P_X3) }
+    else { CN_TN_DISPATCH(P_BF16) }
+#undef CN_TN_DISPATCH
 }
 
 void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g)
 {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    if (tn_big_tiles(g)) launch_tn_prec<128>(s, prec, &g, 1);
-    else                 launch_tn_prec<64>(s, prec, &g, 1);
+    launch_tn_any(s, prec, &g, 1);
 }
 
 void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n)
 {
-    GemmTN small[TN_GROUP]; int ns = 0;
+    GemmTN grp[TN_GROUP]; int ng = 0;
     for (int i = 0; i < n; ++i) {
         if (gs[i].M <= 0 || gs[i].N <= 0 || gs[i].K <= 0) continue;
-        if (tn_big_tiles(gs[i]) || ns == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
-        else small[ns++] = gs[i];
+        const bool huge = (long)((gs[i].M + 63) / 64) * ((gs[i].N + 63) / 64) >= 2048;
+        if (huge || ng == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
+        else grp[ng++] = gs[i];
     }
-    if (ns) launch_tn_prec<64>(s, prec, small, ns);
+    if (ng) launch_tn_any(s, prec, grp, ng);
 }
 
 }  // namespace cn

@@ -50,7 +50,8 @@ def test_gemm_nt(lib, prec, shape):
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
-@pytest.mark.parametrize("shape", [(128, 32, 60), (1024, 256, 5000), (96, 160, 333), (4000, 2080, 700)])
+@pytest.mark.parametrize("shape", [(128, 32, 60), (1024, 256, 5000), (96, 160, 333), (4000, 2080, 700),
+                                   (512, 64, 3000), (768, 96, 1111), (256, 416, 2000)])      # 256-row tiles: 256 x 64 (N < 128, partial N tile) and 256 x 128
 def test_gemm_tn(lib, prec, shape):
     L, B = lib
     M, N, K = shape

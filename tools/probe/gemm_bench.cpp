@@ -58,5 +58,29 @@ int main()
         printf("gemm_tn M=%5d N=%4d K=%5d  %7.1f us  %6.0f GB/s (operand bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     }
+    // the grouped launch of an LSTM layer's backward pass: dW_in + dW_rec per direction in ONE launch (cn_api.cpp: lstm_backward)
+    struct Grp { int P; const char *what; } grps[] = {{256, "layer 2/3 group (dW_in 1024x256 + 2 x dW_rec 512x128)"}, {64, "layer 1 group (dW_in 1024x64 + 2 x dW_rec 512x128)"}};
+    for (auto &gr : grps) {
+        const int K = 15600, R = 1024, Hp = 128, PS = 52;
+        void *delta = rnd((size_t)K * R), *x = rnd((size_t)K * gr.P), *y = rnd((size_t)K * 2 * Hp);
+        float *C; const size_t cfl = (size_t)R * gr.P + (size_t)R * Hp; CK(hipMalloc((void **)&C, cfl * 4)); CK(hipMemset(C, 0, cfl * 4));
+        GemmTN gs[3] = {};
+        gs[0].A = delta; gs[0].lda = R; gs[0].B = x; gs[0].ldb = gr.P; gs[0].C = C; gs[0].ldc = gr.P; gs[0].M = R; gs[0].N = gr.P; gs[0].K = K;
+        for (int d = 0; d < 2; ++d) {
+            GemmTN &r = gs[1 + d];
+            r.A = (char *)delta + (size_t)d * 4 * Hp * 2 + (d == 0 ? (size_t)PS * R * 2 : 0);
+            r.B = (char *)y + (size_t)d * Hp * 2 + (d == 1 ? (size_t)PS * 2 * Hp * 2 : 0);
+            r.lda = R; r.ldb = 2 * Hp; r.C = C + (size_t)R * gr.P + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = K - PS;
+        }
+        for (int i = 0; i < 3; ++i) launch_gemm_tn_group(s, false, gs, 3);
+        CK(hipEventRecord(e0, s));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch_gemm_tn_group(s, false, gs, 3);
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        double us = ms * 1e3 / reps, bytes = (double)K * (R + gr.P + 2 * Hp) * 2, fl = 2.0 * K * ((double)R * gr.P + (double)R * Hp);
+        printf("gemm_tn group  %7.1f us  %6.0f GB/s (unique operand bytes)  %6.1f TFLOP/s   %s\n", us, bytes / us * 1e-3, fl / us * 1e-6, gr.what);
+        CK(hipFree(delta)); CK(hipFree(x)); CK(hipFree(y)); CK(hipFree(C));
+    }
     return 0;
 }
