@@ -35,6 +35,9 @@
 
 #include <cstdlib>
 
+#ifndef CN_KQ_STACK
+#define CN_KQ_STACK 1
+#endif
 #ifndef CN_X3_ACCURATE_ACT
 #define CN_X3_ACCURATE_ACT 0
 #endif
@@ -104,9 +107,9 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     constexpr int PLANES = X3 ? 2 : 1;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
-    const int pitch = lds_pitch(Hp * ELT);           // LDS row pitch of the y tile (bytes)
     const int KC = Hp * ELT / 64;                    // 64-byte K chunks
     constexpr int KCR = RES ? HP * ELT / 64 : 1;
+    const int pitch = lds_pitch(Hp * ELT);           // LDS row pitch of the y tile (bytes)
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -315,13 +318,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #ifdef CN_STAMP
                 if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(yo) STAMP(3) }
 #endif
-                if constexpr (F32) *(float *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 4) = yo;
+                const int trow = RES ? 4 * q + r : q * RPL + r, tcol = unit[u];      // tile position of this lane's value
+                if constexpr (F32) *(float *)(ynxt + trow * pitch + tcol * 4) = yo;
                 else if constexpr (X3) {
                     __bf16 yh, yl;
                     split_bf16(yo, yh, yl);
-                    *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = yh;
-                    *(__bf16 *)(ynxt + plane + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = yl;
-                } else *(__bf16 *)(ynxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 2) = (__bf16)yo;
+                    *(__bf16 *)(ynxt + trow * pitch + tcol * 2) = yh;
+                    *(__bf16 *)(ynxt + plane + trow * pitch + tcol * 2) = yl;
+                } else *(__bf16 *)(ynxt + trow * pitch + tcol * 2) = (__bf16)yo;
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
                 *(f32x4 *)(actsT + oA[u][r]) = av;
                 cellT[oC[u][r]] = co;
@@ -379,9 +383,22 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     constexpr int PLANES = X3 ? 2 : 1;
     constexpr bool RES = HP != 0;
     const int Hp = RES ? HP : p.Hp;
-    const int pitch = lds_pitch(4 * Hp * ELT);       // LDS row pitch of the delta tile, k = 4*unit + gate
     const int KC = 4 * Hp * ELT / 64;
     constexpr int KCR = RES ? 4 * HP * ELT / 64 : 1;
+    // K-quarter stacking (KQS).  With one sequence per lane (RPL = 1) only rows 0, 4, 8, 12 of the 16-row MFMA operand tile
+    // are sequences; the other twelve were zero padding that every wave read from LDS every step.  Stacked, row 4q + r holds
+    // K-quarter r of sequence q: the tile is a quarter as wide and has no padding, a step reads a quarter of the operand
+    // bytes (Hp = 128: 4 instead of 16 ds_read_b128 per wave, 128 instead of 512 LDS cycles per CU and step), and the product
+    // for quarter r is A . W[quarter r] of which only rows 4q + r are wanted: the MFMA count is unchanged, quarter r goes to an
+    // accumulator of its own, and a lane finds its sequence's sum as acc_0[0] + acc_1[1] + acc_2[2] + acc_3[3] -- in its own
+    // registers (C/D layout: row 4q + r = lane quarter q, register r).
+    // Here K = 4*Hp with k = 4*unit + gate, so quarter r = units [r*Hp/4, (r+1)*Hp/4).  Measured: backward step 0.54 -> 0.50 us
+    // (rec_bwd 6.04 -> 5.67 ms per 30 launches, headline +2.7 %).  The same stacking in the FORWARD kernel (K = Hp, one read
+    // instead of four, sixteen accumulators) loses 13-20 % there, quarter-major or gate-major: its four reads were no
+    // bottleneck, sixteen accumulators and twelve extra adds are; it was taken out again.
+    constexpr bool KQS = RES && UG == 1 && RPL == 1 && (KCR % 4 == 0) && CN_KQ_STACK;
+    constexpr int KCQ = KCR / 4;
+    const int pitch = lds_pitch((KQS ? Hp : 4 * Hp) * ELT);       // LDS row pitch of the delta tile
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -512,7 +529,30 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         STAMP(0)
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
-        if constexpr (RES) {
+        if constexpr (KQS) {
+            f32x4 accq[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accq[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accq[0][0] = acc[0][0];                  // err enters as the C operand of quarter 0
+            u32x4 a[KCQ];
+            [[maybe_unused]] u32x4 al[X3 ? KCQ : 1];
+#pragma unroll
+            for (int kc = 0; kc < KCQ; ++kc) {
+                a[kc] = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+                if constexpr (X3) al[kc] = *(const u32x4 *)(dcur + plane + c * pitch + kc * 64 + q * 16);
+            }
+#ifdef CN_STAMP
+            STAMP_FORCE(a[0][0]) STAMP(1)
+#endif
+#pragma unroll
+            for (int kc = 0; kc < KCQ; ++kc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (X3) mma16_x3(accq[r], a[kc], al[kc], wreg[0][r * KCQ + kc], wlo[0][r * KCQ + kc]);
+                    else mma16<F32>(accq[r], a[kc], wreg[0][r * KCQ + kc]);
+                }
+            acc[0][0] = (accq[0][0] + accq[1][1]) + (accq[2][2] + accq[3][3]);
+        } else if constexpr (RES) {
             // A-operand reads run LDS_AHEAD chunks ahead of the MFMAs that consume them.  Left alone, the
             // scheduler issues each read one chunk ahead, so every MFMA group waits most of an LDS round trip
             // (16 of them per step); reading everything up front costs 64 VGPRs and pushes W_rec into AGPRs.
@@ -594,21 +634,24 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 // gradient sums (ComputeWeightUpdateFn bias / peephole cases, :392-408, :440-475)
                 sb[u][0] += dni; sb[u][1] += dig; sb[u][2] += dfg; sb[u][3] += dog;
                 spi[u] += cp * dig; spf[u] += cp * dfg; spo[u] += cs * dog;
+                // tile position of this lane's deltas: row of its sequence (KQS: row 4q + K-quarter of its unit), column of its unit
+                const int trow = KQS ? 4 * q + unit[u] / (Hp / 4) : (RES ? 4 * q + r : q * RPL + r);
+                const int tcol = KQS ? unit[u] % (Hp / 4) : unit[u];
                 if constexpr (F32) {
                     const f32x4 dv = {dni, dig, dfg, dog};
-                    *(f32x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 16) = dv;
+                    *(f32x4 *)(dnxt + trow * pitch + tcol * 16) = dv;
                     *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
                 } else if constexpr (X3) {
                     const f32x4 dv = {dni, dig, dfg, dog};
                     bf16x4 dh, dl;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(dv[g], h_, l_); dh[g] = h_; dl[g] = l_; }
-                    *(bf16x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dh;
-                    *(bf16x4 *)(dnxt + plane + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dl;
+                    *(bf16x4 *)(dnxt + trow * pitch + tcol * 8) = dh;
+                    *(bf16x4 *)(dnxt + plane + trow * pitch + tcol * 8) = dl;
                     *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
                 } else {
                     const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
-                    *(bf16x4 *)(dnxt + (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * 8) = dv;
+                    *(bf16x4 *)(dnxt + trow * pitch + tcol * 8) = dv;
                     *(bf16x4 *)&at32<__bf16>(p.delta_op, bD + oA[u][r]) = dv;
                 }
             }
