@@ -23,8 +23,13 @@
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
+#ifndef CN_KQ_STACK
+#define CN_KQ_STACK 1
+#endif
+
 #include <cstdlib>
 #include <map>
+#include <type_traits>
 #include <mutex>
 
 namespace cn {
@@ -248,7 +253,15 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CS = HP / UPC, NT = UPC * 4, KC = 4 * HP / 32;
-    constexpr int pitch = lds_pitch(4 * HP * 2);     // delta tile row: k = 4*unit + gate
+    // K-quarter stacking (cn_lstm.hip, backward kernel): with one sequence per lane the twelve padding rows of the operand tile
+    // carry the other three quarters of every member's part of K; a wave reads KC / 4 instead of KC chunks per step (Hp = 256:
+    // 8 instead of 32 ds_read_b128, 256 instead of 1024 LDS cycles per CU and step).  Member part p, quarter r, chunk kq of the
+    // tile is chunk p*KCO + r*KCO/4 + kq of the member-relative K order below.
+    // Measured: 8 CUs x 64 units (Hp = 512) backward step -20 % (longutt_5x1024: 51.0 -> 45.3 ms per fraction); 2 CUs x 128 units
+    // (Hp = 256) +35 %: that shape holds 128 VGPRs of W_rec per lane at two waves per SIMD and the three extra accumulators
+    // push the time loop into scratch.  On for the 64-unit members only.
+    constexpr bool KQS = RPL == 1 && UPC <= 64 && (KC / CS) % 4 == 0 && CN_KQ_STACK;
+    constexpr int pitch = lds_pitch((KQS ? HP : 4 * HP) * 2);     // delta tile row: k = 4*unit + gate
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
@@ -258,6 +271,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     const int d = cluster % dirs, s0 = (cluster / dirs) * (4 * RPL);
     const int lunit = 16 * wave + c, unit = member * UPC + lunit;
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+    // tile position of the deltas of local unit `lunit` of member part `part` (0 = own) for the sequence in lane quarter q
+    [[maybe_unused]] const int krow = KQS ? lunit / (UPC / 4) : 0;
+    auto tile_off = [&](int part, int r) {
+        return KQS ? (4 * q + krow) * pitch + (part * (UPC / 4) + lunit % (UPC / 4)) * 8
+                   : (4 * q + r) * pitch + (part * UPC + lunit) * 8;
+    };
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
     bool gaveup = false;
@@ -315,17 +334,40 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * 2 * NT);
 
         f32x4 acc, a_[RPL];
+        [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
         float cp_[RPL];
         char ptc[RPL];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (r < RPL) ? pre.e[r < RPL ? r : 0] : 0.f;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) { ptc[r] = pre.pt[r]; cp_[r] = hasprev_ ? pre.cp[r] : 0.f; a_[r] = pre.a[r]; }
+        // the product over member parts [p0, p1) of K
+        auto product = [&](auto p0_, auto p1_) {      // (compile-time bounds: wreg must stay in registers)
+            constexpr int p0 = decltype(p0_)::value, p1 = decltype(p1_)::value;
+            if constexpr (KQS) {
+                constexpr int KQ = KCO / 4;
 #pragma unroll
-        for (int j = 0; j < KCO; ++j) {
-            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
-            mma16<false>(acc, a, wreg[j]);
+                for (int pp = p0; pp < p1; ++pp)
+#pragma unroll
+                    for (int kq = 0; kq < KQ; ++kq) {
+                        const u32x4 a = *(const u32x4 *)(dcur + c * pitch + (pp * KQ + kq) * 64 + q * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mma16<false>(accq[r], a, wreg[pp * KCO + r * KQ + kq]);
+                    }
+            } else {
+#pragma unroll
+                for (int j = p0 * KCO; j < p1 * KCO; ++j) {
+                    const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
+                    mma16<false>(acc, a, wreg[j]);
+                }
+            }
+        };
+        if constexpr (KQS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accq[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accq[0][0] = acc[0];                     // err enters as the C operand of quarter 0
         }
+        product(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
         if (it > 0) {      // the partners' deltas of the previous step
             u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * 2 * NT);
             const u64 *slots[(CS - 1) * RPL * 2];
@@ -342,16 +384,13 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
-                    *(uint2 *)(const_cast<char *>(dcur) + (4 * q + r) * pitch + ((j + 1) * UPC + lunit) * 8) =
+                    *(uint2 *)(const_cast<char *>(dcur) + tile_off(j + 1, r)) =
                         make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
             lds_barrier();
         }
         prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt), see the forward kernel
-#pragma unroll
-        for (int j = KCO; j < KC; ++j) {
-            const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
-            mma16<false>(acc, a, wreg[j]);
-        }
+        product(std::integral_constant<int, 1>(), std::integral_constant<int, CS>());
+        if constexpr (KQS) acc[0] = (accq[0][0] + accq[1][1]) + (accq[2][2] + accq[3][3]);
 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
@@ -382,7 +421,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                 publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
                 publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
             }
-            *(bf16x4 *)(dnxt + (4 * q + r) * pitch + lunit * 8) = dv;        // member-relative tile: own units first
+            *(bf16x4 *)(dnxt + tile_off(0, r)) = dv;        // member-relative tile: own units first
             *(bf16x4 *)(deltaT + oA[r]) = dv;
         }
         lds_barrier();
