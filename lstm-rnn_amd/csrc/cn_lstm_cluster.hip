@@ -473,7 +473,13 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
 
 // cluster shapes: Hp = 256 -> 2 CUs x 128 units (8 waves each), Hp = 512 -> 8 CUs x 64 units (4 waves each; the slice of
 // W_rec a CU keeps in registers is 4*UPC*Hp operands = 256 KB in both cases)
-static int cluster_size(int Hp) { return Hp == 256 ? 2 : (Hp == 512 ? 8 : 0); }
+// CN_CLUSTER4=1: Hp = 256 as 4 CUs x 64 units (A/B; the 64-unit members have registers to spare and take the stacked
+// backward operand tile)
+static int cluster_size(int Hp)
+{
+    static const bool four = getenv("CN_CLUSTER4") != nullptr;
+    return Hp == 256 ? (four ? 4 : 2) : (Hp == 512 ? 8 : 0);
+}
 
 // bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
 int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
@@ -544,7 +550,10 @@ bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned
 
 static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p)
 {
-    if (p.Hp == 256) {
+    if (p.Hp == 256 && cluster_size(256) == 4) {
+        if (p.rpl == 1)      { if (bwd) launch_cluster<256, 64, 1, true>(s, p); else launch_cluster<256, 64, 1, false>(s, p); }
+        else                 { if (bwd) launch_cluster<256, 64, 2, true>(s, p); else launch_cluster<256, 64, 2, false>(s, p); }
+    } else if (p.Hp == 256) {
         if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
         else                 { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
     } else {
