@@ -74,24 +74,34 @@ __device__ __forceinline__ void split4(const u32x4 &x, u32x2 &hi, u32x2 &lo)
 // ---------------------------------------------------------------------------------------------
 // gemm_nt
 // ---------------------------------------------------------------------------------------------
-constexpr int NT_BM = 128, NT_BN = 128, NT_ROWB = 128, NT_PITCH = 144;
-constexpr int NT_TILE_BYTES = NT_BM * NT_PITCH;           // one operand tile
-// One LDS buffer per operand (the next k-tile waits in registers) and the epilogue staged in two halves of 64 rows:
-// 36.9 KB per workgroup, three workgroups per CU (VGPR-bound) instead of two with two buffers + a whole-tile
+constexpr int NT_BN = 128, NT_ROWB = 128, NT_PITCH = 144;
+// One LDS buffer per operand (the next k-tile waits in registers) and the epilogue staged in two halves:
+// 36.9 KB per workgroup at 128 rows, three workgroups per CU (VGPR-bound) instead of two with two buffers + a whole-tile
 // epilogue (73.7 KB).  Measured (tools/probe/gemm_bench): the small-K products of the headline step are unchanged to
 // -3 %, the MFMA-bound ones gain 7-9 % (M = 25 600: N = 8000, K = 1024 550 -> 589 TFLOP/s; N = 1024, K = 8000 607 -> 661).
 constexpr int NT_NBUF = 1, NT_EPI_HALVES = 2;
-constexpr int NT_EPI_BYTES = NT_BM / NT_EPI_HALVES * (NT_BN * 4 + 16);
-constexpr int NT_LDS_BYTES = (2 * NT_NBUF * NT_TILE_BYTES > NT_EPI_BYTES) ? 2 * NT_NBUF * NT_TILE_BYTES : NT_EPI_BYTES;
+// BM = 128 or 64 rows of C per workgroup (BN = 128 columns, 4 waves as 2 x 2).  The 64-row tile is for products whose 128-row
+// grid leaves the chip short of workgroups (N = 256: 244 tiles on 256 CUs, one 4-wave workgroup per CU and nothing to overlap
+// its load -> LDS -> MFMA -> store chain with).
+template <int BM> struct NtGeom {
+    static constexpr int A_BYTES = BM * NT_PITCH, B_BYTES = NT_BN * NT_PITCH;
+    static constexpr int EPI_BYTES = BM / NT_EPI_HALVES * (NT_BN * 4 + 16);
+    static constexpr int OPS = NT_NBUF * (A_BYTES + B_BYTES);
+    static constexpr int LDS_BYTES = OPS > EPI_BYTES ? OPS : EPI_BYTES;
+    static constexpr int TI = BM / 64;                      // 32-row MFMA tiles per wave (rows); 2 across the columns
+    static constexpr int NLD_A = BM * 8 / 256;              // 16-byte chunks per thread and k-tile
+};
 
-template <int PREC>
+template <int PREC, int BM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int nwg)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    using G = NtGeom<BM>;
     constexpr bool F32 = PREC == P_F32, X3 = PREC == P_X3;
     constexpr int ELT = PREC == P_BF16 ? 2 : 4;          // operand element in MEMORY (P_X3: fp32, split when it enters the LDS)
     constexpr int KB = NT_ROWB / ELT;          // k elements per tile row
     constexpr int CH = 16 / ELT;               // k elements per 16-byte chunk
+    constexpr int TI = G::TI, RW = BM / 2;     // rows of C a wave row owns
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -104,47 +114,50 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
     }
     const int tm = bid / tiles_n, tn = bid % tiles_n;
-    const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+    const int m0 = tm * BM, n0 = tn * NT_BN;
 
     const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
     const int nk = (p.K + KB - 1) / KB;
 
-    u32x4 ra[4], rb[4];
+    u32x4 ra[G::NLD_A], rb[4];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = tid + 256 * j, row = c >> 3, kc = c & 7;
             int k = kt * KB + kc * CH;
             u32x4 z = {0u, 0u, 0u, 0u};
-            ra[j] = z; rb[j] = z;
+            if (j < G::NLD_A) ra[j < G::NLD_A ? j : 0] = z;
+            rb[j] = z;
             if (k < p.K) {
-                if (m0 + row < p.M) ra[j] = *(const u32x4 *)(Ab + ((long)(m0 + row) * p.lda + k) * ELT);
+                if (j < G::NLD_A && m0 + row < p.M) ra[j < G::NLD_A ? j : 0] = *(const u32x4 *)(Ab + ((long)(m0 + row) * p.lda + k) * ELT);
                 if (n0 + row < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)(n0 + row) * p.ldb + k) * ELT);
             }
         }
     };
     auto lwrite = [&](int buf) {
-        char *sa = smem + buf * 2 * NT_TILE_BYTES, *sb = sa + NT_TILE_BYTES;
+        char *sa = smem + buf * (G::A_BYTES + G::B_BYTES), *sb = sa + G::A_BYTES;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int c = tid + 256 * j, row = c >> 3, kc = c & 7;
             if constexpr (X3) {
                 // a tile row holds 32 k: [32 bf16 hi | 32 bf16 lo] in the same 128 bytes the fp32 row would take
                 u32x2 h, l;
-                split4(ra[j], h, l);
-                *(u32x2 *)(sa + row * NT_PITCH + kc * 8) = h; *(u32x2 *)(sa + row * NT_PITCH + 64 + kc * 8) = l;
+                if (j < G::NLD_A) {
+                    split4(ra[j < G::NLD_A ? j : 0], h, l);
+                    *(u32x2 *)(sa + row * NT_PITCH + kc * 8) = h; *(u32x2 *)(sa + row * NT_PITCH + 64 + kc * 8) = l;
+                }
                 split4(rb[j], h, l);
                 *(u32x2 *)(sb + row * NT_PITCH + kc * 8) = h; *(u32x2 *)(sb + row * NT_PITCH + 64 + kc * 8) = l;
             } else {
-                *(u32x4 *)(sa + row * NT_PITCH + kc * 16) = ra[j];
+                if (j < G::NLD_A) *(u32x4 *)(sa + row * NT_PITCH + kc * 16) = ra[j < G::NLD_A ? j : 0];
                 *(u32x4 *)(sb + row * NT_PITCH + kc * 16) = rb[j];
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -156,37 +169,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload(kt + 1);
-        const char *sa = smem + (kt % NT_NBUF) * 2 * NT_TILE_BYTES, *sb = sa + NT_TILE_BYTES;
+        const char *sa = smem + (kt % NT_NBUF) * (G::A_BYTES + G::B_BYTES), *sb = sa + G::A_BYTES;
         if constexpr (X3) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                u32x4 ah[2], al[2], bh[2], bl[2];
+                u32x4 ah[TI], al[TI], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    ah[i] = *(const u32x4 *)(sa + (wm * RW + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+                    al[i] = *(const u32x4 *)(sa + (wm * RW + i * 32 + fr) * NT_PITCH + 64 + g * 32 + fh * 16);
+                }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    ah[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
-                    al[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + 64 + g * 32 + fh * 16);
                     bh[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
                     bl[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + 64 + g * 32 + fh * 16);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) mma32_x3(acc[i][j], ah[i], al[i], bh[j], bl[j]);
             }
         } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            u32x4 a[2], b[2];
+            for (int g = 0; g < 4; ++g) {
+                u32x4 a[TI], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *(const u32x4 *)(sa + (wm * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
-                b[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+                for (int i = 0; i < TI; ++i) a[i] = *(const u32x4 *)(sa + (wm * RW + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) b[i] = *(const u32x4 *)(sb + (wn * 64 + i * 32 + fr) * NT_PITCH + g * 32 + fh * 16);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma32<F32>(acc[i][j], a[i], b[j]);
             }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) mma32<F32>(acc[i][j], a[i], b[j]);
-        }
         }
         if (NT_NBUF == 1) __syncthreads();
         if (kt + 1 < nk) lwrite((kt + 1) % NT_NBUF);
@@ -196,25 +211,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5): a lane owns
     // single dwords of 16 different rows, and stored straight from the registers the tile leaves the CU as 64
     // dword stores per lane (2.3 TB/s of output at best, measured with K = 64).  The tile is transposed through
-    // the operand LDS instead (free after the last k step: 128 rows x 528 B) and written as whole 512-byte rows,
+    // the operand LDS instead (free after the last k step) and written as whole 512-byte rows,
     // 16 B per lane; bias and activation are applied on the way out, where a thread's four columns are fixed.
     constexpr int EP = NT_BN * 4 + 16;                 // staging row pitch (bytes)
-    constexpr int EH = NT_EPI_HALVES, ROWS = NT_BM / EH;           // staged rows per pass
-    static_assert(ROWS * EP <= NT_LDS_BYTES, "epilogue staging does not fit the operand buffers");
+    constexpr int EH = NT_EPI_HALVES, ROWS = BM / EH;           // staged rows per pass (= the rows of one wave row)
+    static_assert(ROWS * EP <= G::LDS_BYTES, "epilogue staging does not fit the operand buffers");
     const int c4 = tid & 31, n = n0 + c4 * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && n < p.N) bv = *(const f32x4 *)(p.bias + n);
 #pragma unroll
     for (int h = 0; h < EH; ++h) {
         if (h) __syncthreads();
-        if (EH == 1 || wm == h) {
+        if (wm == h) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        *(float *)(smem + ((EH == 1 ? wm * 64 : 0) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EP + (wn * 64 + j * 32 + fr) * 4) = acc[i][j][r];
+                        *(float *)(smem + (i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EP + (wn * 64 + j * 32 + fr) * 4) = acc[i][j][r];
         }
         __syncthreads();
         if (n < p.N) {
@@ -238,21 +253,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     }
 }
 
+template <int PREC, int BM>
+static void launch_nt(hipStream_t s, const GemmNT &g, hipEvent_t done)
+{
+    using G = NtGeom<BM>;
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + NT_BN - 1) / NT_BN, nwg = tiles_m * tiles_n;
+    auto kern = gemm_nt_kernel<PREC, BM>;
+    static DeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(256), G::LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+}
+
 void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 {
     if (g.M <= 0 || g.N <= 0) return;
     if (gemm_nt_big_applies(prec, g)) { launch_gemm_nt_big(s, prec, g, done); return; }
-    int tiles_m = (g.M + NT_BM - 1) / NT_BM, tiles_n = (g.N + NT_BN - 1) / NT_BN;
-    int nwg = tiles_m * tiles_n;
-    static DeviceOnce attr_once;
-    if (attr_once.first()) {   // > 64 KiB of dynamic LDS needs the opt-in
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)gemm_nt_kernel<P_X3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-    }
-    if (prec == P_F32)     hipExtLaunchKernelGGL(gemm_nt_kernel<P_F32>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
-    else if (prec == P_X3) hipExtLaunchKernelGGL(gemm_nt_kernel<P_X3>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
-    else                   hipExtLaunchKernelGGL(gemm_nt_kernel<P_BF16>, dim3(nwg), dim3(256), NT_LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    // 64-row tiles when the 128-row grid leaves the chip short of workgroups (< 400 tiles: the N = 256 / 192 products of the
+    // headline step, 244 tiles on 256 CUs) or the K loop is at most four k-tiles long (the input projections: a workgroup's
+    // fixed costs dominate).  tools/probe/gemm_bench, 128 -> 64 rows: error to the preceding layer 22.2 -> 20.7 us, softmax
+    // products 10.1 / 9.7 -> 9.0 / 8.8, input projections 16.2 / 23.3 -> 14.7 / 22.7; long-K products with 400+ tiles lose
+    // (N = 512, K = 2048: 48.6 -> 57.0 us) and keep 128 rows.  CN_NT_BM64_BELOW=<tiles> overrides the first threshold.
+    static const long below = getenv("CN_NT_BM64_BELOW") ? atol(getenv("CN_NT_BM64_BELOW")) : 400;
+    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + NT_BN - 1) / NT_BN);
+    const int elt = prec == P_BF16 ? 2 : 4;
+    const bool small = tiles128 < below || ((long)g.K * elt <= 4 * NT_ROWB && tiles128 < 1100);
+#define CN_NT_DISPATCH(P) { if (small) launch_nt<P, 64>(s, g, done); else launch_nt<P, 128>(s, g, done); }
+    if (prec == P_F32) CN_NT_DISPATCH(P_F32)
+    else if (prec == P_X3) CN_NT_DISPATCH(P_X3)
+    else CN_NT_DISPATCH(P_BF16)
+#undef CN_NT_DISPATCH
 }
 
 // ---------------------------------------------------------------------------------------------
