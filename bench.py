@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32", "bf16x3"],
                     help="bf16: throughput mode; f32: exact-fp32 MFMA parity mode; bf16x3: split-bf16 parity mode (fp32 tolerance at a third of the bf16 MFMA rate)")
     ap.add_argument("--no-also", action="store_true", help="skip the informational extra workloads of the default run")
+    ap.add_argument("--no-driver-leg", action="store_true", help="skip the end-to-end run of the C++ driver on a synthetic NetCDF file")
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--momentum", type=float, default=0.9)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -404,6 +405,8 @@ def main():
                                     "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
         if also:
             out["also"] = also
+        if world == 1 and not args.no_driver_leg:
+            out["driver_leg"] = driver_leg(wl, args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, wl, args, PRECISIONS)
         print(json.dumps(out))
@@ -424,6 +427,51 @@ def time_oracle_step(pkg, orc, wl, args, PS, tlo, thi):
     dt = time.perf_counter() - t0
     frames = pkg.fraction.real_frames(frac)
     return frames / dt, "1 fraction, %d sequences U[%d,%d] (%d frames), same topology, fp32, %.1f s" % (PS, tlo, thi, frames, dt)
+
+
+def driver_leg(wl, args):
+    """The same workload end to end through the C++ driver (lstm-rnn_amd/currennt_hip, host/main.cpp): a synthetic
+    NetCDF-3 file on disk -> reader -> length sort -> fraction packer (worker thread) -> cn_fraction_load (host buffers)
+    -> forward / backward / momentum SGD every fraction, error sums read once per epoch.  Fractions are cut from the
+    length-SORTED sequence list as the reference does (DataSet.cpp:603-605), so they pad less than the bench's
+    independently drawn ones; informational, never `value`."""
+    import re
+    import subprocess
+    import tempfile
+    from scipy.io import netcdf_file
+    binary = os.path.join(ROOT, "lstm-rnn_amd", "currennt_hip")
+    if not os.path.exists(binary):
+        return {"error": "driver not built"}
+    rng = np.random.RandomState(4321)
+    nseq, P, C = 3000, wl["P"], wl["C"]
+    lens = rng.randint(args.tmin, args.tmax + 1, nseq)
+    n = int(lens.sum())
+    with tempfile.TemporaryDirectory() as d:
+        nc = os.path.join(d, "train.nc")
+        f = netcdf_file(nc, "w")
+        f.createDimension("numSeqs", nseq); f.createDimension("numTimesteps", n); f.createDimension("inputPattSize", P)
+        f.createDimension("numLabels", C); f.createDimension("maxSeqTagLength", 16)
+        tags = f.createVariable("seqTags", "c", ("numSeqs", "maxSeqTagLength"))
+        tags[:] = np.array([list(("s%05d" % i).ljust(16, "\0")) for i in range(nseq)], "c")
+        f.createVariable("seqLengths", "i", ("numSeqs",))[:] = lens.astype(np.int32)
+        f.createVariable("targetClasses", "i", ("numTimesteps",))[:] = rng.randint(0, C, n).astype(np.int32)
+        f.createVariable("inputs", "f", ("numTimesteps", "inputPattSize"))[:] = rng.randn(n, P).astype(np.float32)
+        f.close()
+        net = os.path.join(d, "network.jsn")
+        json.dump({"layers": net_desc(P, wl["hidden"], C)}, open(net, "w"))
+        epochs = 4
+        cmd = [binary, "--train", "true", "--stochastic", "true", "--train_file", nc, "--network", net,
+               "--parallel_sequences", str(args.parallel_sequences), "--max_epochs", str(epochs), "--learning_rate", str(args.lr),
+               "--momentum", str(args.momentum), "--precision", args.precision, "--save_network", os.path.join(d, "trained.jsn"), "--random_seed", "1"]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, CN_DRIVER_TIMING="1"))
+    if out.returncode != 0:
+        return {"error": out.stdout[-300:]}
+    secs = [float(m.group(1)) for m in re.finditer(r"TIMING epoch \d+ ([\d.]+) s", out.stderr)]
+    if len(secs) < 2:
+        return {"error": "no epoch timings"}
+    med = float(np.median(secs[1:]))                       # the first epoch carries allocation and first-touch costs
+    return {"value": n / med, "unit": "frames/s", "epoch_seconds": secs, "frames_per_epoch": n, "sequences": nseq,
+            "note": "C++ driver end to end from a NetCDF file (length-sorted fractions, cn_fraction_load from host buffers, error read once per epoch); informational"}
 
 
 def cpu_baseline(pkg, wl, args, precisions):

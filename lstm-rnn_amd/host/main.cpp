@@ -298,6 +298,9 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
                 finished = optimizer.train();
                 double duration = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 infoRows += printfRow("%8.1lf |", duration);
+                // CN_DRIVER_TIMING=1: the epoch's wall time with microsecond resolution on stderr (the table above keeps the
+                // reference's format, one decimal); bench.py's driver leg reads it
+                if (getenv("CN_DRIVER_TIMING")) fprintf(stderr, "TIMING epoch %d %.6f s %d frames\n", optimizer.currentEpoch(), duration, trainingSet->totalTimesteps());
                 if (classificationTask) infoRows += printfRow(errFormat, (double)optimizer.curTrainingClassError() * 100.0, (double)optimizer.curTrainingError());
                 else infoRows += printfRow(errFormat, (double)optimizer.curTrainingError());
                 const bool validated = !validationSet->empty() && optimizer.currentEpoch() % config.validateEvery() == 0;

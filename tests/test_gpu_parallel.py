@@ -40,7 +40,7 @@ def test_arena_aliases_weight_updates(pkg):
 def test_bench_under_torchrun_one_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+           "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
@@ -55,7 +55,7 @@ def test_bench_per_layer_allreduce_path_matches_plain_path():
     identity: same accumulated error and the same weight movement as the plain path."""
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
     args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--parallel-sequences", "8",
-            "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+            "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"]
     sums = {}
     for mode in ("plain", "overlap"):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_MIN_SECONDS="0")
@@ -79,13 +79,13 @@ def test_bench_gpus_flag_without_launcher():
     n = torch.cuda.device_count() + 1
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
-                          "--no-cpu-baseline", "--no-roofline-pass"], capture_output=True, text=True, timeout=900, env=env)
+                          "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout[-500:]
     assert "needs %d GPUs" % n in out.stderr + out.stdout
     # and with N = 1 the flag path is the plain single-process run
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--parallel-sequences", "8",
-                          "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-also"],
+                          "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg", "--no-also"],
                          capture_output=True, text=True, timeout=900, env=dict(env, CN_BENCH_MIN_SECONDS="0"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
@@ -163,7 +163,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
     the flat exchange; barrier; max-over-ranks timing) runs with real sums.  Replicas must end bit-identical."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29300 + os.getpid() % 250 + int(flat)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
-           "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass"]
+           "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND="gloo", CN_BENCH_MIN_SECONDS="0")   # one repetition
     if flat:
         env["CN_BENCH_FLAT_ALLREDUCE"] = "1"

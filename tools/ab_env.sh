@@ -3,7 +3,7 @@
 for wl in timit_3x500_blstm_H250 lvcsr_4x512_blstm_8000; do
   for mode in base "$1"; do
     if [ "$mode" = base ]; then envs=""; else envs="$mode"; fi
-    env $envs CN_BENCH_MIN_SECONDS=0.2 python bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline --no-also 2>&1 | tail -1 | \
+    env $envs CN_BENCH_MIN_SECONDS=0.2 python bench.py --workload $wl --steps 6 --warmup 2 --no-cpu-baseline --no-also --no-driver-leg 2>&1 | tail -1 | \
       python -c "import sys,json,os; d=json.loads(sys.stdin.read()); print('%-28s %-18s %10.0f frames/s %8.3f ms  %s' % ('$wl', '$mode', d['value'], d['ms_per_step'], d.get('roofline',{}).get('note','')[-100:]))"
   done
 done

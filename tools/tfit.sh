@@ -3,7 +3,7 @@
 # usage: tools/tfit.sh lib.so [lib2.so ...]
 for lib in "$@"; do
   for T in 150 300; do
-    CURRENNT_HIP_LIB=$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also --tmin $T --tmax $T 2>&1 | tail -1 > /tmp/tfit_$T.json
+    CURRENNT_HIP_LIB=$lib python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-driver-leg --tmin $T --tmax $T 2>&1 | tail -1 > /tmp/tfit_$T.json
   done
   python - "$lib" <<'PY'
 import json, re, sys, os

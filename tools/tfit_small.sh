@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for T in 16 48; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tfs_$T -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-roofline-pass --tmin $T --tmax $T > gpurun_out/tfs_$T.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/tfs_$T -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-also --no-driver-leg --no-roofline-pass --tmin $T --tmax $T > gpurun_out/tfs_$T.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob
