@@ -10,6 +10,13 @@
 // Two LDS buffers (128 KB): the fill of k-tile t+1 is in flight while k-tile t is multiplied; one barrier per k-tile.
 // (Measured and rejected: four k-tiles of 64-byte rows with counted vmcnt waits and a raw barrier -- fills never drain,
 // but a barrier every 16 MFMAs per wave instead of every 32: 646 / 770 / 624 vs 694 / 828 / 693 TFLOP/s on the LVCSR shapes.)
+// (Round 2, measured and rejected as well: a four-phase k-tile after cdna_hip_programming.md section 5 -- 8 MFMAs per wave and
+// phase, one 16 KB half-tile filled per phase up to 1.75 k-tiles ahead, ONE counted `s_waitcnt vmcnt(6)` per k-tile that leaves
+// three half-tiles in flight across every raw s_barrier, s_setprio around the MFMA clusters; 230 VGPRs, no compiler-inserted
+// vmcnt(0) in the loop, bit-identical results: 600 / 671 / 690 / 719 / 795 / 664 TFLOP/s against 635 / 669 / 697 / 730 / 796 /
+// 686 of this kernel on the six MFMA-bound shapes of tools/probe/gemm_bench.  PMC (tools/pmc_l2.sh): L2 hit rate 0.63-0.72,
+// fabric reads 9x the unique operand bytes at ~1.1 TB/s, L2 requests ~8.6 TB/s -- neither is a roof; a k-tile takes 3x its
+// MFMA time with either schedule.  The guide's own example source, with its two staggered wave groups, is not available here.)
 // The epilogue transposes the accumulators through the (then free) LDS in four passes of 64 rows and writes whole
 // 1 KB rows, 16 B per lane, as gemm_nt_kernel does.
 #include "cn_internal.h"
