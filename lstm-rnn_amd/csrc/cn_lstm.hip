@@ -38,6 +38,9 @@
 #ifndef CN_KQ_STACK
 #define CN_KQ_STACK 1
 #endif
+#ifndef CN_SPARSE
+#define CN_SPARSE 1
+#endif
 #ifndef CN_X3_ACCURATE_ACT
 #define CN_X3_ACCURATE_ACT 0
 #endif
@@ -106,10 +109,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     constexpr int ELT = F32 ? 4 : 2;                 // operand element in LDS / MFMA fragments
     constexpr int PLANES = X3 ? 2 : 1;
     constexpr bool RES = HP != 0;
+    // SP: 2:4 row-pair products (cn_lstm_device.h): with at most two sequences per lane every sequence takes two tile rows and
+    // a K = 64 chunk is one v_smfmac_f32_16x16x64_bf16 instead of two dense MFMAs; the tile rows are half as long
+    constexpr bool SP = RES && UG == 1 && RPL <= 2 && !F32 && HP % 64 == 0 && CN_SPARSE;
+    constexpr int KCS = SP ? HP / 64 : 1;            // 64-value K chunks of the sparse product
     const int Hp = RES ? HP : p.Hp;
     const int KC = Hp * ELT / 64;                    // 64-byte K chunks
     constexpr int KCR = RES ? HP * ELT / 64 : 1;
-    const int pitch = lds_pitch(Hp * ELT);           // LDS row pitch of the y tile (bytes)
+    const int pitch = lds_pitch(SP ? Hp * ELT / 2 : Hp * ELT);   // LDS row pitch of the y tile (bytes)
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -129,8 +136,10 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
-    u32x4 wreg[UG][4][KCR];
-    [[maybe_unused]] u32x4 wlo[X3 ? UG : 1][4][KCR];
+    [[maybe_unused]] u32x4 wreg[UG][4][SP ? 1 : KCR];
+    [[maybe_unused]] u32x4 wlo[X3 && !SP ? UG : 1][4][SP ? 1 : KCR];
+    [[maybe_unused]] u32x8 wsp[SP ? 4 : 1][KCS], wsl[SP && X3 ? 4 : 1][KCS];
+    [[maybe_unused]] const int spidx = sp_index(c);
     const char *Wd = (const char *)p.Wrec + (long)d * 4 * Hp * Hp * MELT;
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
@@ -138,7 +147,16 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         pi[u] = p.peep[(d * 3 + 0) * Hp + unit[u]];
         pf[u] = p.peep[(d * 3 + 1) * Hp + unit[u]];
         po[u] = p.peep[(d * 3 + 2) * Hp + unit[u]];
-        if constexpr (RES) {
+        if constexpr (SP) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int kc = 0; kc < KCS; ++kc) {
+                    const long w0 = (long)(g * Hp + unit[u]) * Hp + kc * 64 + q * 16;     // 16 consecutive K values per lane
+                    if constexpr (X3) sp_load_split((const float *)Wd + w0, wsp[g][kc], wsl[g][kc]);
+                    else wsp[g][kc] = sp_load_bf16(Wd + w0 * 2);
+                }
+        } else if constexpr (RES) {
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
     // base pointer, so a step costs no 64-bit per-lane address arithmetic)
     // PS is padded to a multiple of 4*RPL on the device (pad slots are permanent dummies), so every lane
     // owns real memory: no lane predication, no divergent branch inside the time loop.
-    int oP[RPL], oA[UG][RPL], oC[UG][RPL];
+    unsigned oP[RPL], oA[UG][RPL], oC[UG][RPL];     // unsigned: base (SGPR pair) + 32-bit lane offset, no 64-bit VALU add per access
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int sv = s0 + 4 * r + q;
@@ -168,6 +186,17 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         }
     }
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    // tile position of this lane's y (byte offset of the bf16 / fp32 value inside one tile plane)
+    int oT[UG][RPL];
+#pragma unroll
+    for (int u = 0; u < UG; ++u)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+            if constexpr (SP) {
+                const int k = unit[u] & 63;
+                oT[u][r] = (4 * q + 2 * r + sp_parity(k)) * pitch + ((unit[u] >> 6) * 32 + sp_pos(k)) * 2;
+            } else oT[u][r] = (RES ? 4 * q + r : q * RPL + r) * pitch + unit[u] * ELT;
+        }
 
     float cst[UG][RPL];
 #pragma unroll
@@ -187,11 +216,19 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            pt[r] = (unsigned char)patT[oP[r]];
+            pt[r] = (unsigned char)at32<char>(patT, oP[r]);
 #pragma unroll
-            for (int u = 0; u < UG; ++u) pre[u][r] = *(const f32x4 *)(actsT + oA[u][r]);
+            for (int u = 0; u < UG; ++u) pre[u][r] = *(const f32x4 *)&at32<float>(actsT, oA[u][r]);
         }
     };
+
+    // SP: the accumulators live across steps.  The sparse MFMA accumulates in place (no C operand that could be the inline
+    // constant 0), so every step would clear sixteen registers; kept alive, the even row of a sequence is loaded with the
+    // staged pre-activation (the copy the dense path makes anyway), its odd row is cleared, and with one sequence per lane the
+    // rows of the unused pair are never touched again: their tile rows are zero, they stay what they are.
+    [[maybe_unused]] f32x4 accp[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     STAMP_DECL
     auto step = [&](int it, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
@@ -201,6 +238,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
+        char *yT = (char *)p.y_op + t * stepC * MELT;
 
         // accumulators start at 0 (inline constant, nothing to set up before the first MFMA); the gate
         // pre-activation of the N-wide GEMM is added to the real rows afterwards
@@ -217,18 +255,40 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
             for (int r = 0; r < RPL; ++r)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(g_[u][r][g]) : "v"(pre[u][r][g]));
+                for (int g = 0; g < 4; ++g) {
+                    float v_;
+                    asm volatile("v_mov_b32 %0, %1" : "=&v"(v_) : "v"(pre[u][r][g]));
+                    if constexpr (SP) { accp[g][2 * r] = v_; accp[g][2 * r + 1] = 0.f; g_[u][r][g] = 0.f; }
+                    else g_[u][r][g] = v_;
+                }
+            if constexpr (!SP) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[u][g][r] = 0.f;
+                    for (int r = 0; r < 4; ++r) acc[u][g][r] = 0.f;
+            }
         }
 
         prefetch(d ? t - 2 : t + 2, pre, pt);
         STAMP(0)
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates at once
-        if constexpr (RES && UG > 1 && KCR <= 8 && !X3) {
+        if constexpr (SP) {
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc) {
+                u32x4 a = *(const u32x4 *)(ycur + c * pitch + kc * 64 + q * 16);
+                [[maybe_unused]] u32x4 al;
+                if constexpr (X3) al = *(const u32x4 *)(ycur + plane + c * pitch + kc * 64 + q * 16);
+#ifdef CN_STAMP
+                if (kc == 0) { STAMP_FORCE(a[0]) STAMP(1) }
+#endif
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (X3) smma16_x3(accp[g], a, al, wsp[g][kc], wsl[g][kc], spidx);
+                    else smma16(accp[g], a, wsp[g][kc], spidx);
+                }
+            }
+        } else if constexpr (RES && UG > 1 && KCR <= 8 && !X3) {
             // unit group after unit group: the cell update of group u only needs that group's sums, so it can
             // run on the VALU while the MFMAs of group u+1 are in flight (one wave per SIMD in this shape)
             u32x4 a[KCR];
@@ -297,7 +357,9 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
             }
         }
 
-        STAMP_FORCE(acc[UG - 1][3][0]) STAMP(2)
+#ifdef CN_STAMP
+        { float f_ = SP ? accp[3][0] : acc[UG - 1][3][0]; STAMP_FORCE(f_) STAMP(2) }
+#endif
         // cell update: C/D map of the 16x16 MFMA: col = lane&15 (unit), row = 4*(lane>>4)+reg
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
@@ -306,11 +368,15 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 const bool dummy = dummy_[r];
                 const float cp = cst[u][r];
                 // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
-                const float ni = tanh_ref<ACC>(acc[u][0][r] + g_[u][r][0]);
-                const float ig = logistic<ACC>(acc[u][1][r] + g_[u][r][1] + cp * pi[u]);
-                const float fg = logistic<ACC>(acc[u][2][r] + g_[u][r][2] + cp * pf[u]);
+                float s_[4];                             // recurrent sums of this sequence (SP: its two tile rows)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)          // SP: the pre-activation entered through the even row's accumulator
+                    s_[g] = SP ? accp[g][(2 * r) & 3] + accp[g][(2 * r + 1) & 3] : acc[u][g][r] + g_[u][r][g];
+                const float ni = tanh_ref<ACC>(s_[0]);
+                const float ig = logistic<ACC>(s_[1] + cp * pi[u]);
+                const float fg = logistic<ACC>(s_[2] + cp * pf[u]);
                 const float cs = ni * ig + cp * fg;
-                const float og = logistic<ACC>(acc[u][3][r] + g_[u][r][3] + cs * po[u]);
+                const float og = logistic<ACC>(s_[3] + cs * po[u]);
                 const float y = tanh_ref<ACC>(cs) * og;
                 float yo = dummy ? 0.f : y;
                 const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
@@ -318,19 +384,18 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #ifdef CN_STAMP
                 if (u == UG - 1 && r == RPL - 1) { STAMP_FORCE(yo) STAMP(3) }
 #endif
-                const int trow = RES ? 4 * q + r : q * RPL + r, tcol = unit[u];      // tile position of this lane's value
-                if constexpr (F32) *(float *)(ynxt + trow * pitch + tcol * 4) = yo;
+                if constexpr (F32) *(float *)(ynxt + oT[u][r]) = yo;
                 else if constexpr (X3) {
                     __bf16 yh, yl;
                     split_bf16(yo, yh, yl);
-                    *(__bf16 *)(ynxt + trow * pitch + tcol * 2) = yh;
-                    *(__bf16 *)(ynxt + plane + trow * pitch + tcol * 2) = yl;
-                } else *(__bf16 *)(ynxt + trow * pitch + tcol * 2) = (__bf16)yo;
+                    *(__bf16 *)(ynxt + oT[u][r]) = yh;
+                    *(__bf16 *)(ynxt + plane + oT[u][r]) = yl;
+                } else *(__bf16 *)(ynxt + oT[u][r]) = (__bf16)yo;
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
-                *(f32x4 *)(actsT + oA[u][r]) = av;
-                cellT[oC[u][r]] = co;
-                if constexpr (MELT == 4) ((float *)p.y_op + t * stepC)[oC[u][r]] = yo;
-                else ((__bf16 *)p.y_op + t * stepC)[oC[u][r]] = (__bf16)yo;
+                *(f32x4 *)&at32<float>(actsT, oA[u][r]) = av;
+                at32<float>(cellT, oC[u][r]) = co;
+                if constexpr (MELT == 4) at32<float>(yT, oC[u][r]) = yo;
+                else at32<__bf16>(yT, oC[u][r]) = (__bf16)yo;
             }
         }
         STAMP(4)
@@ -396,9 +461,17 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
     // (rec_bwd 6.04 -> 5.67 ms per 30 launches, headline +2.7 %).  The same stacking in the FORWARD kernel (K = Hp, one read
     // instead of four, sixteen accumulators) loses 13-20 % there, quarter-major or gate-major: its four reads were no
     // bottleneck, sixteen accumulators and twelve extra adds are; it was taken out again.
-    constexpr bool KQS = RES && UG == 1 && RPL == 1 && (KCR % 4 == 0) && CN_KQ_STACK;
+    // SP: 2:4 row-pair products (cn_lstm_device.h) in the bf16 and split-bf16 modes: a sequence takes two tile rows, a K = 64
+    // chunk is one sparse MFMA.  KHS: with one sequence per lane the other two rows of its quad hold the second K half (the
+    // stacking idea above with two accumulators instead of four): e = accA[0] + accA[1] + accB[2] + accB[3].
+    // Hp = 128: 4 ds_read_b128 and 8 MFMA-pipe slots per wave and step (KQS: 4 and 16; plain: 16 and 16).
+    constexpr bool SP = RES && UG == 1 && RPL <= 2 && !F32 && CN_SPARSE;
+    constexpr bool KHS = SP && RPL == 1;
+    constexpr int KCS = SP ? 4 * HP / 64 : 1;        // 64-value K chunks of the sparse product
+    constexpr int KCH = KHS ? KCS / 2 : KCS;         // chunks per tile row
+    constexpr bool KQS = !SP && RES && UG == 1 && RPL == 1 && (KCR % 4 == 0) && CN_KQ_STACK;
     constexpr int KCQ = KCR / 4;
-    const int pitch = lds_pitch((KQS ? Hp : 4 * Hp) * ELT);       // LDS row pitch of the delta tile
+    const int pitch = lds_pitch(SP ? KCH * 64 : (KQS ? Hp : 4 * Hp) * ELT);       // LDS row pitch of the delta tile
     const int nw = blockDim.x >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -422,8 +495,10 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
 
     int unit[UG];
     float pi[UG], pf[UG], po[UG];
-    u32x4 wreg[UG][KCR];
-    [[maybe_unused]] u32x4 wlo[X3 ? UG : 1][KCR];
+    [[maybe_unused]] u32x4 wreg[UG][SP ? 1 : KCR];
+    [[maybe_unused]] u32x4 wlo[X3 && !SP ? UG : 1][SP ? 1 : KCR];
+    [[maybe_unused]] u32x8 wsp[KCS], wsl[SP && X3 ? KCS : 1];
+    [[maybe_unused]] const int spidx = sp_index(c);
     const char *Wd = (const char *)p.WrecT + (long)d * 4 * Hp * Hp * MELT;
 #pragma unroll
     for (int u = 0; u < UG; ++u) {
@@ -431,7 +506,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         pi[u] = p.peep[(d * 3 + 0) * Hp + unit[u]];
         pf[u] = p.peep[(d * 3 + 1) * Hp + unit[u]];
         po[u] = p.peep[(d * 3 + 2) * Hp + unit[u]];
-        if constexpr (RES) {
+        if constexpr (SP) {
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc) {
+                const long w0 = (long)unit[u] * 4 * Hp + kc * 64 + q * 16;             // 16 consecutive K values per lane
+                if constexpr (X3) sp_load_split((const float *)Wd + w0, wsp[kc], wsl[kc]);
+                else wsp[kc] = sp_load_bf16(Wd + w0 * 2);
+            }
+        } else if constexpr (RES) {
 #pragma unroll
             for (int kc = 0; kc < KCR; ++kc) {
                 if constexpr (X3) {
@@ -455,6 +537,15 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         }
     }
     const unsigned stepA = (unsigned)PS * (unsigned)arow, stepC = (unsigned)PS * (unsigned)crow;   // elements per time step
+    // SP: tile position of this lane's deltas.  K index k = 4*unit + gate, so the gates (n, i) of a unit are two neighbouring
+    // stored values of the even row of its sequence and (f, o) the same two positions of the odd row.
+    [[maybe_unused]] int oT[RPL];
+    if constexpr (SP) {
+        const int uh = KHS ? unit[0] % (Hp / 2) : unit[0], half = KHS ? unit[0] / (Hp / 2) : 0;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r)
+            oT[r] = (4 * q + 2 * (KHS ? half : r)) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2;
+    }
 
     // carried across steps (values of the step processed just before = next(t) in time)
     float fgn[UG][RPL], ecn[UG][RPL], dign[UG][RPL], dfgn[UG][RPL], ccur[UG][RPL];
@@ -529,7 +620,43 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         STAMP(0)
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*Hp
-        if constexpr (KQS) {
+        if constexpr (SP) {
+            u32x4 a[KCH];
+            [[maybe_unused]] u32x4 al[X3 ? KCH : 1];
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
+                a[kc] = *(const u32x4 *)(dcur + c * pitch + kc * 64 + q * 16);
+                if constexpr (X3) al[kc] = *(const u32x4 *)(dcur + plane + c * pitch + kc * 64 + q * 16);
+            }
+#ifdef CN_STAMP
+            STAMP_FORCE(a[0][0]) STAMP(1)
+#endif
+            if constexpr (KHS) {
+                f32x4 accA = {acc[0][0], 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};      // err enters as the C operand
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) {
+                    if constexpr (X3) {
+                        smma16_x3(accA, a[kc], al[kc], wsp[kc], wsl[kc], spidx);
+                        smma16_x3(accB, a[kc], al[kc], wsp[KCH + kc], wsl[KCH + kc], spidx);
+                    } else {
+                        smma16(accA, a[kc], wsp[kc], spidx);
+                        smma16(accB, a[kc], wsp[KCH + kc], spidx);
+                    }
+                }
+                acc[0][0] = (accA[0] + accA[1]) + (accB[2] + accB[3]);
+            } else {
+                f32x4 accs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) accs[2 * r] = acc[0][r];
+#pragma unroll
+                for (int kc = 0; kc < KCH; ++kc) {
+                    if constexpr (X3) smma16_x3(accs, a[kc], al[kc], wsp[kc], wsl[kc], spidx);
+                    else smma16(accs, a[kc], wsp[kc], spidx);
+                }
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) acc[0][r] = accs[2 * r] + accs[2 * r + 1];
+            }
+        } else if constexpr (KQS) {
             f32x4 accq[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) accq[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -641,6 +768,21 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                     const f32x4 dv = {dni, dig, dfg, dog};
                     *(f32x4 *)(dnxt + trow * pitch + tcol * 16) = dv;
                     *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
+                } else if constexpr (SP && X3) {
+                    const f32x4 dv = {dni, dig, dfg, dog};
+                    bf16x4 dh, dl;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(dv[g], h_, l_); dh[g] = h_; dl[g] = l_; }
+                    *(bf16x2 *)(dnxt + oT[r]) = bf16x2{dh[0], dh[1]};
+                    *(bf16x2 *)(dnxt + oT[r] + pitch) = bf16x2{dh[2], dh[3]};
+                    *(bf16x2 *)(dnxt + plane + oT[r]) = bf16x2{dl[0], dl[1]};
+                    *(bf16x2 *)(dnxt + plane + oT[r] + pitch) = bf16x2{dl[2], dl[3]};
+                    *(f32x4 *)&at32<float>(p.delta_op, bD + oA[u][r]) = dv;
+                } else if constexpr (SP) {
+                    const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+                    *(bf16x2 *)(dnxt + oT[r]) = bf16x2{dv[0], dv[1]};
+                    *(bf16x2 *)(dnxt + oT[r] + pitch) = bf16x2{dv[2], dv[3]};
+                    *(bf16x4 *)&at32<__bf16>(p.delta_op, bD + oA[u][r]) = dv;
                 } else if constexpr (X3) {
                     const f32x4 dv = {dni, dig, dfg, dog};
                     bf16x4 dh, dl;

@@ -8,8 +8,11 @@ namespace cn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(8))) unsigned u32x8;
+typedef __attribute__((ext_vector_type(16))) __bf16 bf16x16;
 
 #define LOG2E 1.4426950408889634f
 
@@ -84,6 +87,49 @@ __device__ __forceinline__ void mma16_x3(f32x4 &acc, const u32x4 &ah, const u32x
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+}
+
+// ---- 2:4 "row pair" products (v_smfmac_f32_16x16x64_bf16) -----------------------------------------------------------
+// The 16-row A tile of a recurrent step holds 4*RPL sequences, so with RPL <= 2 at least half of its rows are padding and
+// the dense MFMA spends its cycles on them.  The sparse MFMA multiplies a 16 x 64 A whose rows keep 2 of every 4 K
+// positions (8 stored values + eight 2-bit positions per lane) with a dense 64 x 16 B in the cycles of the dense
+// 16x16x32 (measured, tools/probe/smfmac_probe.hip: 17-18 cycles per instruction on 1, 2 or 8 accumulators).  Two tile
+// rows share one sequence: the even row keeps positions {0,1} of every group of four, the odd row {2,3}; both are fully
+// dense in their stored values, so nothing is pruned -- the product is exact, the K = 64 chunk costs one instruction
+// instead of two, and the sequence's sum is D[even row] + D[odd row], both in the lane's own registers.
+// Operand pairing (measured with unit impulses, same probe): A lane (row = lane & 15, j = lane >> 4), stored slot s with
+// position field v meets B lane (col = lane & 15, j' = 2*(j & 1) + (s >> 2)) slot 8*(j >> 1) + 4*((s >> 1) & 1) + v; the
+// position fields of a lane are bits [15:0] of the index register (ABID = 0).  With B lane j' slot i holding k' = 16*j' + i
+// (16 consecutive K values per lane, two 16-byte loads), value k' of a sequence belongs in tile row parity (k' >> 1) & 1 at
+// stored position sp_pos(k') of its 32-value row chunk; a reader lane takes its 8 slots with one ds_read_b128 at
+// row*pitch + 64*chunk + 16*j, the same expression as for the dense tile.
+__device__ __forceinline__ constexpr int sp_parity(int k) { return (k >> 1) & 1; }
+__device__ __forceinline__ constexpr int sp_pos(int k)
+{
+    return 16 * ((k >> 3) & 1) + 8 * ((k >> 5) & 1) + 4 * ((k >> 4) & 1) + 2 * ((k >> 2) & 1) + (k & 1);
+}
+// index register of a reader lane: even tile rows keep positions {0,1}, odd rows {2,3} of every group
+__device__ __forceinline__ int sp_index(int row) { return (row & 1) ? (int)0xEEEEEEEEu : 0x44444444; }
+__device__ __forceinline__ u32x8 sp_join(const u32x4 &lo, const u32x4 &hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ void smma16(f32x4 &acc, const u32x4 &a, const u32x8 &b, int idx)
+{
+    acc = __builtin_amdgcn_smfmac_f32_16x16x64_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x16, b), acc, idx, 0, 0);
+}
+// split operands (P_X3): small terms first, as mma16_x3
+__device__ __forceinline__ void smma16_x3(f32x4 &acc, const u32x4 &ah, const u32x4 &al, const u32x8 &bh, const u32x8 &bl, int idx)
+{
+    smma16(acc, al, bh, idx);
+    smma16(acc, ah, bl, idx);
+    smma16(acc, ah, bh, idx);
+}
+// 16 consecutive K values of one B column as a sparse-product fragment: bf16 in memory, or fp32 split into hi and lo
+__device__ __forceinline__ u32x8 sp_load_bf16(const void *p) { return sp_join(*(const u32x4 *)p, *((const u32x4 *)p + 1)); }
+__device__ __forceinline__ void sp_load_split(const float *p, u32x8 &hi, u32x8 &lo)
+{
+    u32x4 h0, l0, h1, l1;
+    split8(*(const f32x4 *)p, *(const f32x4 *)(p + 4), h0, l0);
+    split8(*(const f32x4 *)(p + 8), *(const f32x4 *)(p + 12), h1, l1);
+    hi = sp_join(h0, h1); lo = sp_join(l0, l1);
 }
 
 // workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
