@@ -19,12 +19,16 @@
 // it is given), and launches of different contexts on one device are serialised (cluster_gate) so that two half-resident
 // grids cannot wait for each other.
 //
-// Arithmetic is identical to cn_lstm.hip (same MFMA tiles, same cell update); bf16 operand mode only.
+// Arithmetic is identical to cn_lstm.hip (same MFMA tiles -- the 2:4 row-pair sparse products included --, same cell update);
+// bf16 operand mode only.
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
 #ifndef CN_KQ_STACK
 #define CN_KQ_STACK 1
+#endif
+#ifndef CN_SPARSE
+#define CN_SPARSE 1
 #endif
 
 #include <cstdlib>
@@ -104,8 +108,11 @@ template <int HP, int UPC, int RPL>
 __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CS = HP / UPC, NT = UPC * 4, KC = HP / 32;
-    constexpr int pitch = lds_pitch(HP * 2);
+    // SP: 2:4 row-pair products (cn_lstm_device.h): a sequence takes two tile rows, a K = 64 chunk is one sparse MFMA and the
+    // tile rows are half as long; a member part is UPC / 64 chunks of 32 stored values per row
+    constexpr bool SP = CN_SPARSE && UPC % 64 == 0;
+    constexpr int CS = HP / UPC, NT = UPC * 4, KC = SP ? HP / 64 : HP / 32;
+    constexpr int pitch = lds_pitch(SP ? HP : HP * 2);
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
@@ -115,6 +122,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
     const int d = cluster % dirs, s0 = (cluster / dirs) * (4 * RPL);
     const int lunit = 16 * wave + c, unit = member * UPC + lunit;      // unit inside the slice / the direction
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+    // tile position of y of local unit `lunit` of member part `part` (0 = own) for sequence r of lane quarter q
+    auto tile_off = [&](int part, int r) {
+        return SP ? (4 * q + 2 * r + sp_parity(lunit & 63)) * pitch + part * UPC + ((lunit >> 6) * 32 + sp_pos(lunit & 63)) * 2
+                  : (4 * q + r) * pitch + (part * UPC + lunit) * 2;
+    };
+    [[maybe_unused]] const int spidx = sp_index(c);
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
     bool gaveup = false;
@@ -122,7 +135,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
     // K chunks in the order they are used: first the KCO chunks of this member's own units (their y is in LDS as soon
     // as the step starts), then the partners' (which have to cross L2 first).  kch[j] is the chunk behind wreg[.][j].
     constexpr int KCO = KC / CS;
-    u32x4 wreg[4][KC];
+    [[maybe_unused]] u32x4 wreg[4][SP ? 1 : KC];
+    [[maybe_unused]] u32x8 wsp[4][SP ? KC : 1];
     int kch[KC];
     const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
 #pragma unroll
@@ -130,8 +144,10 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < KC; ++j)
-            wreg[g][j] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kch[j] * 64 + q * 16);
+        for (int j = 0; j < KC; ++j) {
+            if constexpr (SP) wsp[g][j] = sp_load_bf16(Wd + ((long)(g * HP + unit) * HP + kch[j] * 64 + q * 16) * 2);
+            else wreg[g][j] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kch[j] * 64 + q * 16);
+        }
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
 
     int oP[RPL], oA[RPL], oC[RPL];
@@ -179,7 +195,10 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         for (int j = 0; j < KCO; ++j) {
             const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][j]);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
+                else mma16<false>(acc[g], a, wreg[g][j]);
+            }
         }
         // y[t-1] of the partners' units: published at the end of their previous step, so its trip through L2 has been
         // running beside the products above (it used to be waited for at the end of the step, on the critical path)
@@ -197,7 +216,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
-                    *(unsigned short *)(const_cast<char *>(ycur) + (4 * q + r) * pitch + ((j + 1) * UPC + lunit) * 2) = (unsigned short)vals[j * RPL + r];
+                    *(unsigned short *)(const_cast<char *>(ycur) + tile_off(j + 1, r)) = (unsigned short)vals[j * RPL + r];
             lds_barrier();
         }
         // (the poll above drains vmcnt: the prefetch is issued behind it so that it has a whole step to land)
@@ -206,26 +225,32 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         for (int j = KCO; j < KC; ++j) {
             const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) mma16<false>(acc[g], a, wreg[g][j]);
+            for (int g = 0; g < 4; ++g) {
+                if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
+                else mma16<false>(acc[g], a, wreg[g][j]);
+            }
         }
 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
             const bool dummy = check && ptc[r] == 0;
             const float cp = cst[r];
+            float s_[4];                                 // recurrent sums of this sequence (SP: its two tile rows)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) s_[g] = SP ? acc[g][(2 * r) & 3] + acc[g][(2 * r + 1) & 3] : acc[g][r];
             // ComputeBlockOutputFn, LstmLayer.cu:87-136
-            const float ni = tanh_ref<false>(acc[0][r] + g_[r][0]);
-            const float ig = logistic<false>(acc[1][r] + g_[r][1] + cp * pi);
-            const float fg = logistic<false>(acc[2][r] + g_[r][2] + cp * pf);
+            const float ni = tanh_ref<false>(s_[0] + g_[r][0]);
+            const float ig = logistic<false>(s_[1] + g_[r][1] + cp * pi);
+            const float fg = logistic<false>(s_[2] + g_[r][2] + cp * pf);
             const float cs = ni * ig + cp * fg;
-            const float og = logistic<false>(acc[3][r] + g_[r][3] + cs * po);
+            const float og = logistic<false>(s_[3] + g_[r][3] + cs * po);
             const float y = tanh_ref<false>(cs) * og;
             const float co = dummy ? 0.f : cs;
             const __bf16 yb = (__bf16)(dummy ? 0.f : y);
             cst[r] = co;
             // hand y[t] of this unit to the partners first (it is on their critical path), then keep it here
             publish(xslot + (long)member * (RPL * NT) + r * NT + tid, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned short, yb));
-            *(__bf16 *)(ynxt + (4 * q + r) * pitch + lunit * 2) = yb;       // the tile is member-relative: own units first
+            *(__bf16 *)(ynxt + tile_off(0, r)) = yb;       // the tile is member-relative: own units first
             const f32x4 av = {ni, ig, fg, og};
             *(f32x4 *)(actsT + oA[r]) = av;
             cellT[oC[r]] = co;
@@ -252,7 +277,12 @@ template <int HP, int UPC, int RPL>
 __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CS = HP / UPC, NT = UPC * 4, KC = 4 * HP / 32;
+    // SP: 2:4 row-pair products (cn_lstm_device.h); KHS: with one sequence per lane the other row pair of its quad holds the
+    // second half of every member part (two accumulators, half the operand reads), see cn_lstm.hip.  KHS on the 64-unit
+    // members only: measured on the 128-unit members (reading B / LVCSR) the backward kernel is 5 % slower with it.
+    constexpr bool SP = CN_SPARSE;
+    constexpr bool KHS = SP && RPL == 1 && UPC <= 64;
+    constexpr int CS = HP / UPC, NT = UPC * 4, KC = SP ? 4 * HP / 64 : 4 * HP / 32;
     // K-quarter stacking (cn_lstm.hip, backward kernel): with one sequence per lane the twelve padding rows of the operand tile
     // carry the other three quarters of every member's part of K; a wave reads KC / 4 instead of KC chunks per step (Hp = 256:
     // 8 instead of 32 ds_read_b128, 256 instead of 1024 LDS cycles per CU and step).  Member part p, quarter r, chunk kq of the
@@ -260,8 +290,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     // Measured: 8 CUs x 64 units (Hp = 512) backward step -20 % (longutt_5x1024: 51.0 -> 45.3 ms per fraction); 2 CUs x 128 units
     // (Hp = 256) +35 %: that shape holds 128 VGPRs of W_rec per lane at two waves per SIMD and the three extra accumulators
     // push the time loop into scratch.  On for the 64-unit members only.
-    constexpr bool KQS = RPL == 1 && UPC <= 64 && (KC / CS) % 4 == 0 && CN_KQ_STACK;
-    constexpr int pitch = lds_pitch((KQS ? HP : 4 * HP) * 2);     // delta tile row: k = 4*unit + gate
+    constexpr bool KQS = !SP && RPL == 1 && UPC <= 64 && (KC / CS) % 4 == 0 && CN_KQ_STACK;
+    constexpr int pitch = lds_pitch(SP ? (KHS ? 2 * HP : 4 * HP) : (KQS ? HP : 4 * HP) * 2);     // delta tile row: k = 4*unit + gate
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
@@ -273,22 +303,32 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
     // tile position of the deltas of local unit `lunit` of member part `part` (0 = own) for the sequence in lane quarter q
     [[maybe_unused]] const int krow = KQS ? lunit / (UPC / 4) : 0;
+    // (SP: offset of the gate pair (n, i) in the even row of the sequence; (f, o) sit at the same offset one row further)
     auto tile_off = [&](int part, int r) {
-        return KQS ? (4 * q + krow) * pitch + (part * (UPC / 4) + lunit % (UPC / 4)) * 8
-                   : (4 * q + r) * pitch + (part * UPC + lunit) * 8;
+        if constexpr (SP) {
+            const int uh = KHS ? lunit % (UPC / 2) : lunit, rp = KHS ? lunit / (UPC / 2) : r;
+            return (4 * q + 2 * rp) * pitch + (part * (KHS ? UPC / 32 : UPC / 16) + (uh >> 4)) * 64 + sp_pos(4 * (uh & 15)) * 2;
+        } else
+            return KQS ? (4 * q + krow) * pitch + (part * (UPC / 4) + lunit % (UPC / 4)) * 8
+                       : (4 * q + r) * pitch + (part * UPC + lunit) * 8;
     };
+    [[maybe_unused]] const int spidx = sp_index(c);
 
     for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
     bool gaveup = false;
 
     constexpr int KCO = KC / CS;       // own units' K chunks first, see the forward kernel
-    u32x4 wreg[KC];
+    [[maybe_unused]] u32x4 wreg[SP ? 1 : KC];
+    [[maybe_unused]] u32x8 wsp[SP ? KC : 1];
     int kch[KC];
     const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
 #pragma unroll
     for (int j = 0; j < KC; ++j) kch[j] = ((member + j / KCO) % CS) * KCO + j % KCO;
 #pragma unroll
-    for (int j = 0; j < KC; ++j) wreg[j] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kch[j] * 64 + q * 16);
+    for (int j = 0; j < KC; ++j) {
+        if constexpr (SP) wsp[j] = sp_load_bf16(Wd + ((long)unit * 4 * HP + kch[j] * 64 + q * 16) * 2);
+        else wreg[j] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kch[j] * 64 + q * 16);
+    }
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
 
     int oP[RPL], oA[RPL], oC[RPL];
@@ -335,6 +375,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 
         f32x4 acc, a_[RPL];
         [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
+        [[maybe_unused]] f32x4 accs, acch;           // SP: the row-pair accumulator (KHS: first half) and the second half's
         float cp_[RPL];
         char ptc[RPL];
 #pragma unroll
@@ -344,7 +385,23 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         // the product over member parts [p0, p1) of K
         auto product = [&](auto p0_, auto p1_) {      // (compile-time bounds: wreg must stay in registers)
             constexpr int p0 = decltype(p0_)::value, p1 = decltype(p1_)::value;
-            if constexpr (KQS) {
+            if constexpr (KHS) {
+                constexpr int KH = KCO / 2;
+#pragma unroll
+                for (int pp = p0; pp < p1; ++pp)
+#pragma unroll
+                    for (int kq = 0; kq < KH; ++kq) {
+                        const u32x4 a = *(const u32x4 *)(dcur + c * pitch + (pp * KH + kq) * 64 + q * 16);
+                        smma16(accs, a, wsp[pp * KCO + kq], spidx);
+                        smma16(acch, a, wsp[pp * KCO + KH + kq], spidx);
+                    }
+            } else if constexpr (SP) {
+#pragma unroll
+                for (int j = p0 * KCO; j < p1 * KCO; ++j) {
+                    const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
+                    smma16(accs, a, wsp[j], spidx);
+                }
+            } else if constexpr (KQS) {
                 constexpr int KQ = KCO / 4;
 #pragma unroll
                 for (int pp = p0; pp < p1; ++pp)
@@ -367,6 +424,11 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             for (int r = 0; r < 4; ++r) accq[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             accq[0][0] = acc[0];                     // err enters as the C operand of quarter 0
         }
+        if constexpr (SP) {                          // err enters through the even row of each sequence
+            accs = f32x4{0.f, 0.f, 0.f, 0.f}; acch = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) accs[2 * r] = acc[r];
+        }
         product(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
         if (it > 0) {      // the partners' deltas of the previous step
             u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * 2 * NT);
@@ -384,13 +446,23 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
-                    *(uint2 *)(const_cast<char *>(dcur) + tile_off(j + 1, r)) =
-                        make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
+                {
+                    char *dst = const_cast<char *>(dcur) + tile_off(j + 1, r);
+                    if constexpr (SP) {
+                        *(unsigned *)dst = vals[(j * RPL + r) * 2];                     // (n, i): even row
+                        *(unsigned *)(dst + pitch) = vals[(j * RPL + r) * 2 + 1];       // (f, o): odd row
+                    } else *(uint2 *)dst = make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
+                }
             lds_barrier();
         }
         prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt), see the forward kernel
         product(std::integral_constant<int, 1>(), std::integral_constant<int, CS>());
         if constexpr (KQS) acc[0] = (accq[0][0] + accq[1][1]) + (accq[2][2] + accq[3][3]);
+        if constexpr (KHS) acc[0] = (accs[0] + accs[1]) + (acch[2] + acch[3]);
+        else if constexpr (SP) {
+#pragma unroll
+            for (int r = 0; r < RPL; ++r) acc[r] = accs[2 * r] + accs[2 * r + 1];
+        }
 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
@@ -421,7 +493,10 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                 publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
                 publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
             }
-            *(bf16x4 *)(dnxt + tile_off(0, r)) = dv;        // member-relative tile: own units first
+            if constexpr (SP) {                              // member-relative tile: own units first
+                *(unsigned *)(dnxt + tile_off(0, r)) = (unsigned)bits;
+                *(unsigned *)(dnxt + tile_off(0, r) + pitch) = (unsigned)(bits >> 32);
+            } else *(bf16x4 *)(dnxt + tile_off(0, r)) = dv;
             *(bf16x4 *)(deltaT + oA[r]) = dv;
         }
         lds_barrier();
