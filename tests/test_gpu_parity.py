@@ -352,6 +352,51 @@ def test_cluster_kernel_matches_streaming_kernel(pkg, orc, size, scale):
         assert rel_err(a, lay.weightUpdates) < 6e-2, lay.name
 
 
+@pytest.mark.parametrize("T", [1, 3, 8])
+@pytest.mark.parametrize("rpl", [1, 2])
+@pytest.mark.parametrize("kind,size", [("blstm", 128), ("lstm", 125), ("blstm", 250)])
+def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, rpl, T):
+    """The 2:4 row-pair MFMA path of the register-resident kernels (bf16 and split-bf16 modes, at most two sequences per
+    lane, Hp = 64 / 128): one and two sequences per lane (CN_RPL), loop shapes T = 1, 3, 8, ragged lengths, a partly filled
+    last sequence group, one- and two-directional.  Checked in the split-bf16 mode at the fp32 tolerances, which a misplaced
+    operand element cannot meet."""
+    monkeypatch.setenv("CN_RPL", str(rpl))
+    rng = np.random.RandomState(300 + T + rpl + size)
+    P, C, PS = 6, 4, 13
+    layers = net_desc(P, [(kind, size)], C)
+    weights = random_weights(layers, rng, 0.15)
+    lengths = [max(1, T - (i % 3)) for i in range(PS)]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net = check_network(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16X3)
+    with net:
+        Hp = 64 if size == 128 else 128
+        assert net.recurrent_kernel(False) == "lstm_fwd_kernel<2,%d,1,%d>" % (Hp, rpl)
+        assert net.recurrent_kernel(True) == "lstm_bwd_kernel<2,%d,1,%d>" % (Hp, rpl)
+
+
+@pytest.mark.parametrize("size,rpl,kernel", [(384, 1, "lstm_fwd_kernel<0,192,1,1>"), (384, 2, "lstm_fwd_kernel<0,192,1,2>"),
+                                             (500, 2, "lstm_fwd_cluster_kernel<256,128,2>"), (1024, 2, "lstm_fwd_cluster_kernel<512,64,2>")])
+def test_row_pair_sparse_products_bf16_shapes(pkg, orc, monkeypatch, size, rpl, kernel):
+    """Shapes that exist in bf16 mode only: Hp = 192 register resident (one and two sequences per lane) and the 2-CU / 8-CU
+    clusters with two sequences per lane.  bf16 tolerances: these catch a misplaced operand (errors of order one), not
+    rounding."""
+    monkeypatch.setenv("CN_RPL", str(rpl))
+    rng = np.random.RandomState(41 + size + rpl)
+    P, C, T, PS = 10, 6, 9, 13
+    layers = net_desc(P, [("blstm", size)], C)
+    weights = random_weights(layers, rng, 0.05)
+    xs, ts = random_sequences(rng, [max(1, T - (i % 4)) for i in range(PS)], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net, (e_ref, _), (e, _) = run_both(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16)
+    with net:
+        assert net.recurrent_kernel(False) == kernel
+        assert np.abs(net.outputs() - ref.outputs()).max() < 3e-2
+        assert abs(e - e_ref) < 1e-2 * e_ref
+        for lay in net.trainable_layers():
+            assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 5e-2, lay.name
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
 @pytest.mark.parametrize("PS", [3, 520, 1100])
 def test_short_sequences_and_sequences_per_lane(pkg, orc, T, PS):
