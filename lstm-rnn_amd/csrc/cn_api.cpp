@@ -926,8 +926,11 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             // W_rec from L2 every time step costs an order of magnitude more
             if (!ctx->f32 && l->Hp > 192 && l->Hp < 512 && l->Hp != 256) {
                 const int hc = l->Hp < 256 ? 256 : 512;
-                if (lstm_cluster_xch_bytes(false, hc, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus) > 0) l->Hp = hc;
+                if (lstm_cluster_xch_bytes(P_BF16, hc, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus) > 0) l->Hp = hc;
             }
+            // split-bf16 mode: the same between the register-resident shapes (<= 128) and its one cluster shape (256)
+            if (ctx->prec == P_X3 && l->Hp > 128 && l->Hp < 256 &&
+                lstm_cluster_xch_bytes(P_X3, 256, l->dirs, ctx->PSp, ctx->rpl, ctx->num_cus) > 0) l->Hp = 256;
             l->Lp = l->dirs * l->Hp;
             const size_t R = (size_t)l->dirs * 4 * l->Hp;
             // the recurrent kernels address every per-frame buffer with 32-bit byte offsets from its base
@@ -1588,7 +1591,7 @@ const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward)
     const int cs = lstm_cluster_size(c->prec, layer->Hp, layer->dirs, c->PSp, c->rpl, c->num_cus);
     char buf[160];
     if (c->d_xch && cs > 0)
-        snprintf(buf, sizeof(buf), "lstm_%s_cluster_kernel<%d,%d,%d>", dirn, layer->Hp, layer->Hp / cs, c->rpl);
+        snprintf(buf, sizeof(buf), "lstm_%s_cluster_kernel<%d,%d,%d,%d>", dirn, c->prec, layer->Hp, layer->Hp / cs, c->rpl);
     else {
         const bool resident = lstm_rec_resident(c->prec, layer->Hp);
         snprintf(buf, sizeof(buf), "lstm_%s_kernel<%d,%d,1,%d>", dirn, c->prec, resident ? layer->Hp : 0, c->rpl);

@@ -104,13 +104,18 @@ __device__ __forceinline__ void cluster_of(int &cluster, int &member)
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int HP, int UPC, int RPL>
+// PREC: P_BF16, or P_X3 (fp32 in memory and in the exchange granules; two bf16 planes (hi, lo) of the tile in LDS, W_rec split once
+// into hi and lo fragments, three sparse MFMAs per chunk -- cn_lstm.hip; 64-unit members only: the fragments take 256 VGPRs)
+template <int PREC, int HP, int UPC, int RPL>
 __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool X3 = PREC == P_X3;
+    constexpr int MELT = X3 ? 4 : 2, PLANES = X3 ? 2 : 1;
     // SP: 2:4 row-pair products (cn_lstm_device.h): a sequence takes two tile rows, a K = 64 chunk is one sparse MFMA and the
     // tile rows are half as long; a member part is UPC / 64 chunks of 32 stored values per row
-    constexpr bool SP = CN_SPARSE && UPC % 64 == 0;
+    constexpr bool SP = (CN_SPARSE || X3) && UPC % 64 == 0;
+    static_assert(!X3 || SP, "the split-bf16 cluster kernels exist in the row-pair form only");
     constexpr int CS = HP / UPC, NT = UPC * 4, KC = SP ? HP / 64 : HP / 32;
     constexpr int pitch = lds_pitch(SP ? HP : HP * 2);
     int cluster, member;
@@ -129,23 +134,25 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
     };
     [[maybe_unused]] const int spidx = sp_index(c);
 
-    for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    constexpr int plane = 16 * pitch;                // P_X3: hi plane, then lo plane
+    for (int i = tid * 4; i < 2 * PLANES * plane; i += NT * 4) *(unsigned *)(smem + i) = 0u;
     bool gaveup = false;
 
     // K chunks in the order they are used: first the KCO chunks of this member's own units (their y is in LDS as soon
     // as the step starts), then the partners' (which have to cross L2 first).  kch[j] is the chunk behind wreg[.][j].
     constexpr int KCO = KC / CS;
     [[maybe_unused]] u32x4 wreg[4][SP ? 1 : KC];
-    [[maybe_unused]] u32x8 wsp[4][SP ? KC : 1];
+    [[maybe_unused]] u32x8 wsp[4][SP ? KC : 1], wsl[4][X3 ? KC : 1];
     int kch[KC];
-    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * MELT;
 #pragma unroll
     for (int j = 0; j < KC; ++j) kch[j] = ((member + j / KCO) % CS) * KCO + j % KCO;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
-            if constexpr (SP) wsp[g][j] = sp_load_bf16(Wd + ((long)(g * HP + unit) * HP + kch[j] * 64 + q * 16) * 2);
+            if constexpr (X3) sp_load_split((const float *)Wd + (long)(g * HP + unit) * HP + kch[j] * 64 + q * 16, wsp[g][j], wsl[g][j]);
+            else if constexpr (SP) wsp[g][j] = sp_load_bf16(Wd + ((long)(g * HP + unit) * HP + kch[j] * 64 + q * 16) * 2);
             else wreg[g][j] = *(const u32x4 *)(Wd + ((long)(g * HP + unit) * HP) * 2 + kch[j] * 64 + q * 16);
         }
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
@@ -175,11 +182,11 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 
     auto step = [&](int it, f32x4 (&pre)[RPL], char (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
-        const char *ycur = smem + (it & 1) * 16 * pitch;
-        char *ynxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const char *ycur = smem + (it & 1) * PLANES * plane;
+        char *ynxt = smem + ((it + 1) & 1) * PLANES * plane;
         const bool check = t >= p.Tmin;
         float *actsT = p.acts + t * stepA, *cellT = p.cell + t * stepC;
-        __bf16 *yT = (__bf16 *)p.y_op + t * stepC;
+        char *yT = (char *)p.y_op + t * stepC * MELT;
         u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * NT);
 
         f32x4 acc[4], g_[RPL];
@@ -191,15 +198,22 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
         // own units' part of the recurrent product: needs nothing from the partners
+        auto product = [&](auto j0_, auto j1_) {          // K chunks [j0, j1) of the member-relative order
+            constexpr int j0 = decltype(j0_)::value, j1 = decltype(j1_)::value;
 #pragma unroll
-        for (int j = 0; j < KCO; ++j) {
-            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
+            for (int j = j0; j < j1; ++j) {
+                const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
+                [[maybe_unused]] u32x4 al;
+                if constexpr (X3) al = *(const u32x4 *)(ycur + plane + c * pitch + j * 64 + q * 16);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
-                else mma16<false>(acc[g], a, wreg[g][j]);
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (X3) smma16_x3(acc[g], a, al, wsp[g][j], wsl[g][j], spidx);
+                    else if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
+                    else mma16<false>(acc[g], a, wreg[g][j]);
+                }
             }
-        }
+        };
+        product(std::integral_constant<int, 0>(), std::integral_constant<int, KCO>());
         // y[t-1] of the partners' units: published at the end of their previous step, so its trip through L2 has been
         // running beside the products above (it used to be waited for at the end of the step, on the critical path)
         if (it > 0) {
@@ -216,20 +230,19 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
-                    *(unsigned short *)(const_cast<char *>(ycur) + tile_off(j + 1, r)) = (unsigned short)vals[j * RPL + r];
+                {
+                    char *dst = const_cast<char *>(ycur) + tile_off(j + 1, r);
+                    if constexpr (X3) {
+                        __bf16 yh, yl;
+                        split_bf16(__builtin_bit_cast(float, vals[j * RPL + r]), yh, yl);
+                        *(__bf16 *)dst = yh; *(__bf16 *)(dst + plane) = yl;
+                    } else *(unsigned short *)dst = (unsigned short)vals[j * RPL + r];
+                }
             lds_barrier();
         }
         // (the poll above drains vmcnt: the prefetch is issued behind it so that it has a whole step to land)
         prefetch(d ? t - 2 : t + 2, pre, pt);
-#pragma unroll
-        for (int j = KCO; j < KC; ++j) {
-            const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
-                else mma16<false>(acc[g], a, wreg[g][j]);
-            }
-        }
+        product(std::integral_constant<int, KCO>(), std::integral_constant<int, KC>());
 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
@@ -246,15 +259,24 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const float og = logistic<false>(s_[3] + g_[r][3] + cs * po);
             const float y = tanh_ref<false>(cs) * og;
             const float co = dummy ? 0.f : cs;
-            const __bf16 yb = (__bf16)(dummy ? 0.f : y);
+            const float yo = dummy ? 0.f : y;
+            const __bf16 yb = (__bf16)yo;
             cst[r] = co;
             // hand y[t] of this unit to the partners first (it is on their critical path), then keep it here
-            publish(xslot + (long)member * (RPL * NT) + r * NT + tid, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned short, yb));
-            *(__bf16 *)(ynxt + tile_off(0, r)) = yb;       // the tile is member-relative: own units first
+            u64 *mine = xslot + (long)member * (RPL * NT) + r * NT + tid;
+            if constexpr (X3) {
+                publish(mine, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned, yo));
+                __bf16 yh, yl;
+                split_bf16(yo, yh, yl);
+                *(__bf16 *)(ynxt + tile_off(0, r)) = yh; *(__bf16 *)(ynxt + plane + tile_off(0, r)) = yl;
+            } else {
+                publish(mine, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned short, yb));
+                *(__bf16 *)(ynxt + tile_off(0, r)) = yb;       // the tile is member-relative: own units first
+            }
             const f32x4 av = {ni, ig, fg, og};
             *(f32x4 *)(actsT + oA[r]) = av;
             cellT[oC[r]] = co;
-            yT[oC[r]] = yb;
+            if constexpr (X3) ((float *)yT)[oC[r]] = yo; else ((__bf16 *)yT)[oC[r]] = yb;
         }
         lds_barrier();
     };
@@ -273,14 +295,17 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 // ---------------------------------------------------------------------------------------------
 template <int RPL> struct ClBwdPre { f32x4 a[RPL]; float e[RPL], cp[RPL]; char pt[RPL]; };
 
-template <int HP, int UPC, int RPL>
+template <int PREC, int HP, int UPC, int RPL>
 __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool X3 = PREC == P_X3;
+    constexpr int MELT = X3 ? 4 : 2, PLANES = X3 ? 2 : 1;
+    constexpr int G = X3 ? 4 : 2;                    // exchange granules per lane and sequence: four fp32 deltas, or two bf16 pairs
     // SP: 2:4 row-pair products (cn_lstm_device.h); KHS: with one sequence per lane the other row pair of its quad holds the
     // second half of every member part (two accumulators, half the operand reads), see cn_lstm.hip.  KHS on the 64-unit
     // members only: measured on the 128-unit members (reading B / LVCSR) the backward kernel is 5 % slower with it.
-    constexpr bool SP = CN_SPARSE;
+    constexpr bool SP = CN_SPARSE || X3;
     constexpr bool KHS = SP && RPL == 1 && UPC <= 64;
     constexpr int CS = HP / UPC, NT = UPC * 4, KC = SP ? 4 * HP / 64 : 4 * HP / 32;
     // K-quarter stacking (cn_lstm.hip, backward kernel): with one sequence per lane the twelve padding rows of the operand tile
@@ -314,19 +339,21 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     };
     [[maybe_unused]] const int spidx = sp_index(c);
 
-    for (int i = tid * 4; i < 2 * 16 * pitch; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    constexpr int plane = 16 * pitch;                // P_X3: hi plane, then lo plane
+    for (int i = tid * 4; i < 2 * PLANES * plane; i += NT * 4) *(unsigned *)(smem + i) = 0u;
     bool gaveup = false;
 
     constexpr int KCO = KC / CS;       // own units' K chunks first, see the forward kernel
     [[maybe_unused]] u32x4 wreg[SP ? 1 : KC];
-    [[maybe_unused]] u32x8 wsp[SP ? KC : 1];
+    [[maybe_unused]] u32x8 wsp[SP ? KC : 1], wsl[X3 ? KC : 1];
     int kch[KC];
-    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * MELT;
 #pragma unroll
     for (int j = 0; j < KC; ++j) kch[j] = ((member + j / KCO) % CS) * KCO + j % KCO;
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
-        if constexpr (SP) wsp[j] = sp_load_bf16(Wd + ((long)unit * 4 * HP + kch[j] * 64 + q * 16) * 2);
+        if constexpr (X3) sp_load_split((const float *)Wd + (long)unit * 4 * HP + kch[j] * 64 + q * 16, wsp[j], wsl[j]);
+        else if constexpr (SP) wsp[j] = sp_load_bf16(Wd + ((long)unit * 4 * HP + kch[j] * 64 + q * 16) * 2);
         else wreg[j] = *(const u32x4 *)(Wd + ((long)unit * 4 * HP) * 2 + kch[j] * 64 + q * 16);
     }
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         oP[r] = sv; oA[r] = sv * (int)arow + (d * HP + unit) * 4; oC[r] = sv * (int)crow + d * HP + unit;
     }
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
-    u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * 2 * NT);
+    u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * G * NT);
 
     float fgn[RPL], ecn[RPL], dign[RPL], dfgn[RPL], ccur[RPL];
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
@@ -365,13 +392,13 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 
     auto step = [&](int it, ClBwdPre<RPL> &pre) {
         const int t = d ? it : T - 1 - it;
-        const char *dcur = smem + (it & 1) * 16 * pitch;
-        char *dnxt = smem + ((it + 1) & 1) * 16 * pitch;
+        const char *dcur = smem + (it & 1) * PLANES * plane;
+        char *dnxt = smem + ((it + 1) & 1) * PLANES * plane;
         const bool check = t >= p.Tmin;
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;
-        __bf16 *deltaT = (__bf16 *)p.delta_op + t * stepA;
-        u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * 2 * NT);
+        char *deltaT = (char *)p.delta_op + t * stepA * MELT;
+        u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * G * NT);
 
         f32x4 acc, a_[RPL];
         [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
@@ -392,14 +419,23 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 #pragma unroll
                     for (int kq = 0; kq < KH; ++kq) {
                         const u32x4 a = *(const u32x4 *)(dcur + c * pitch + (pp * KH + kq) * 64 + q * 16);
-                        smma16(accs, a, wsp[pp * KCO + kq], spidx);
-                        smma16(acch, a, wsp[pp * KCO + KH + kq], spidx);
+                        if constexpr (X3) {
+                            const u32x4 al = *(const u32x4 *)(dcur + plane + c * pitch + (pp * KH + kq) * 64 + q * 16);
+                            smma16_x3(accs, a, al, wsp[pp * KCO + kq], wsl[pp * KCO + kq], spidx);
+                            smma16_x3(acch, a, al, wsp[pp * KCO + KH + kq], wsl[pp * KCO + KH + kq], spidx);
+                        } else {
+                            smma16(accs, a, wsp[pp * KCO + kq], spidx);
+                            smma16(acch, a, wsp[pp * KCO + KH + kq], spidx);
+                        }
                     }
             } else if constexpr (SP) {
 #pragma unroll
                 for (int j = p0 * KCO; j < p1 * KCO; ++j) {
                     const u32x4 a = *(const u32x4 *)(dcur + c * pitch + j * 64 + q * 16);
-                    smma16(accs, a, wsp[j], spidx);
+                    if constexpr (X3) {
+                        const u32x4 al = *(const u32x4 *)(dcur + plane + c * pitch + j * 64 + q * 16);
+                        smma16_x3(accs, a, al, wsp[j], wsl[j], spidx);
+                    } else smma16(accs, a, wsp[j], spidx);
                 }
             } else if constexpr (KQS) {
                 constexpr int KQ = KCO / 4;
@@ -431,24 +467,36 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         }
         product(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
         if (it > 0) {      // the partners' deltas of the previous step
-            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * 2 * NT);
-            const u64 *slots[(CS - 1) * RPL * 2];
-            unsigned vals[(CS - 1) * RPL * 2];
+            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * G * NT);
+            const u64 *slots[(CS - 1) * RPL * G];
+            unsigned vals[(CS - 1) * RPL * G];
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) {
-                    const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * 2 * NT) + (r * 2) * NT + tid;
-                    slots[(j * RPL + r) * 2] = theirs; slots[(j * RPL + r) * 2 + 1] = theirs + NT;
+                    const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * G * NT) + (r * G) * NT + tid;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) slots[(j * RPL + r) * G + i] = theirs + i * NT;
                 }
-            consume_all<(CS - 1) * RPL * 2>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
+            consume_all<(CS - 1) * RPL * G>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r)
                 {
                     char *dst = const_cast<char *>(dcur) + tile_off(j + 1, r);
-                    if constexpr (SP) {
+                    if constexpr (X3) {
+                        bf16x4 dh, dl;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            __bf16 h_, l_;
+                            split_bf16(__builtin_bit_cast(float, vals[(j * RPL + r) * G + g]), h_, l_);
+                            dh[g] = h_; dl[g] = l_;
+                        }
+                        const uint2 hb = __builtin_bit_cast(uint2, dh), lb = __builtin_bit_cast(uint2, dl);
+                        *(unsigned *)dst = hb.x; *(unsigned *)(dst + pitch) = hb.y;
+                        *(unsigned *)(dst + plane) = lb.x; *(unsigned *)(dst + plane + pitch) = lb.y;
+                    } else if constexpr (SP) {
                         *(unsigned *)dst = vals[(j * RPL + r) * 2];                     // (n, i): even row
                         *(unsigned *)(dst + pitch) = vals[(j * RPL + r) * 2 + 1];       // (f, o): odd row
                     } else *(uint2 *)dst = make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
@@ -486,18 +534,34 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             ccur[r] = cp;
             sb[0] += dni; sb[1] += dig; sb[2] += dfg; sb[3] += dog;
             spi += cp * dig; spf += cp * dfg; spo += cs * dog;
-            const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
-            const u64 bits = __builtin_bit_cast(u64, dv);
-            {
-                u64 *mine = xslot + (long)member * (RPL * 2 * NT) + (r * 2) * NT + tid;
+            u64 *mine = xslot + (long)member * (RPL * G * NT) + (r * G) * NT + tid;
+            if constexpr (X3) {
+                const f32x4 dv = {dni, dig, dfg, dog};
+                const float ds[4] = {dni, dig, dfg, dog};       // (scalars: a bit_cast of an ext_vector element picks element 0)
+                bf16x4 dh, dl;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    publish(mine + g * NT, p.xch_epoch + it + 1, __float_as_uint(ds[g]));
+                    __bf16 h_, l_;
+                    split_bf16(ds[g], h_, l_);
+                    dh[g] = h_; dl[g] = l_;
+                }
+                const uint2 hb = __builtin_bit_cast(uint2, dh), lb = __builtin_bit_cast(uint2, dl);
+                char *dst = dnxt + tile_off(0, r);
+                *(unsigned *)dst = hb.x; *(unsigned *)(dst + pitch) = hb.y;
+                *(unsigned *)(dst + plane) = lb.x; *(unsigned *)(dst + plane + pitch) = lb.y;
+                *(f32x4 *)((float *)deltaT + oA[r]) = dv;
+            } else {
+                const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+                const u64 bits = __builtin_bit_cast(u64, dv);
                 publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
                 publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
+                if constexpr (SP) {                              // member-relative tile: own units first
+                    *(unsigned *)(dnxt + tile_off(0, r)) = (unsigned)bits;
+                    *(unsigned *)(dnxt + tile_off(0, r) + pitch) = (unsigned)(bits >> 32);
+                } else *(bf16x4 *)(dnxt + tile_off(0, r)) = dv;
+                *(bf16x4 *)((__bf16 *)deltaT + oA[r]) = dv;
             }
-            if constexpr (SP) {                              // member-relative tile: own units first
-                *(unsigned *)(dnxt + tile_off(0, r)) = (unsigned)bits;
-                *(unsigned *)(dnxt + tile_off(0, r) + pitch) = (unsigned)(bits >> 32);
-            } else *(bf16x4 *)(dnxt + tile_off(0, r)) = dv;
-            *(bf16x4 *)(deltaT + oA[r]) = dv;
         }
         lds_barrier();
     };
@@ -526,19 +590,17 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 // ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
-template <int HP, int UPC, int RPL, bool BWD>
+template <int PREC, int HP, int UPC, int RPL, bool BWD>
 static void launch_cluster(hipStream_t s, const LstmRec &p)
 {
     constexpr int CS = HP / UPC, NT = UPC * 4;
     const int nclusters = p.dirs * (p.PS / (4 * RPL));
     const int grid = (nclusters + 7) / 8 * 8 * CS;
-    const size_t lds = 2 * 16 * (size_t)lds_pitch((BWD ? 4 : 1) * HP * 2);
-    const size_t xbytes = (size_t)nclusters * 2 * CS * RPL * (BWD ? 2 : 1) * NT * sizeof(u64);
+    const size_t lds = 2 * (PREC == P_X3 ? 2 : 1) * 16 * (size_t)lds_pitch((BWD ? 4 : 1) * HP * 2);     // (upper bound: the row-pair tiles are narrower)
     // (no clearing per launch: tags continue from LstmRec::xch_epoch, which the caller advances by T + 1 per launch, so
     // the granules a previous launch left behind never match; the memset kernel and its stream bubble cost ~7 us per
     // layer pass)
-    (void)xbytes;
-    auto kern = BWD ? lstm_bwd_cluster_kernel<HP, UPC, RPL> : lstm_fwd_cluster_kernel<HP, UPC, RPL>;
+    auto kern = BWD ? lstm_bwd_cluster_kernel<PREC, HP, UPC, RPL> : lstm_fwd_cluster_kernel<PREC, HP, UPC, RPL>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -550,18 +612,21 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
 // W_rec a CU keeps in registers is 4*UPC*Hp operands = 256 KB in both cases)
 // CN_CLUSTER4=1: Hp = 256 as 4 CUs x 64 units (A/B; the 64-unit members have registers to spare and take the stacked
 // backward operand tile)
-static int cluster_size(int Hp)
+// P_X3 (fp32 tolerances): Hp = 256 as 4 CUs x 64 units (hi and lo fragments: 256 VGPRs per lane at one wave per SIMD); wider
+// layers stream W_rec in that mode
+static int cluster_size(int prec, int Hp)
 {
     static const bool four = getenv("CN_CLUSTER4") != nullptr;
+    if (prec == P_X3) return Hp == 256 ? 4 : 0;
+    if (prec != P_BF16) return 0;
     return Hp == 256 ? (four ? 4 : 2) : (Hp == 512 ? 8 : 0);
 }
 
 // bytes of exchange buffer a layer of this shape needs (0 = the cluster path does not apply)
 int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
 {
-    const int CS = cluster_size(Hp);
-    const bool f32 = prec != P_BF16;                  // the cluster kernels are bf16 only
-    if (f32 || CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
+    const int CS = cluster_size(prec, Hp);
+    if (CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     if ((nclusters + 7) / 8 * 8 * CS > num_cus) return 0;      // every member must be resident (one workgroup per CU)
     return CS;
@@ -572,7 +637,7 @@ size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int n
     if (CS == 0) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     const int NT = (Hp / CS) * 4;
-    return (size_t)nclusters * 2 * CS * rpl * 2 * NT * sizeof(u64);
+    return (size_t)nclusters * 2 * CS * rpl * (prec == P_X3 ? 4 : 2) * NT * sizeof(u64);     // (the backward kernel's granules)
 }
 
 // Cluster launches of one device go through one gate: a cluster kernel needs ALL its workgroups resident, and two such
@@ -592,7 +657,7 @@ static ClusterGate &cluster_gate()
     return *g;
 }
 
-static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p);
+static void launch_cluster_shape(hipStream_t s, int prec, bool bwd, const LstmRec &p);
 
 // a context is going away (its stream has been synchronised): the gate must not name the stream any more
 void lstm_cluster_stream_gone(hipStream_t s)
@@ -617,24 +682,25 @@ bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned
     } else if (gate.multi && gate.last_stream != s) {
         (void)hipStreamWaitEvent(s, gate.last, 0);
     }
-    launch_cluster_shape(s, bwd, p);
+    launch_cluster_shape(s, prec, bwd, p);
     if (gate.multi) (void)hipEventRecord(gate.last, s);
     gate.last_stream = s;
     return true;
 }
 
-static void launch_cluster_shape(hipStream_t s, bool bwd, const LstmRec &p)
+template <int PREC, int HP, int UPC>
+static void launch_cluster_rpl(hipStream_t s, bool bwd, const LstmRec &p)
 {
-    if (p.Hp == 256 && cluster_size(256) == 4) {
-        if (p.rpl == 1)      { if (bwd) launch_cluster<256, 64, 1, true>(s, p); else launch_cluster<256, 64, 1, false>(s, p); }
-        else                 { if (bwd) launch_cluster<256, 64, 2, true>(s, p); else launch_cluster<256, 64, 2, false>(s, p); }
-    } else if (p.Hp == 256) {
-        if (p.rpl == 1)      { if (bwd) launch_cluster<256, 128, 1, true>(s, p); else launch_cluster<256, 128, 1, false>(s, p); }
-        else                 { if (bwd) launch_cluster<256, 128, 2, true>(s, p); else launch_cluster<256, 128, 2, false>(s, p); }
-    } else {
-        if (p.rpl == 1)      { if (bwd) launch_cluster<512, 64, 1, true>(s, p); else launch_cluster<512, 64, 1, false>(s, p); }
-        else                 { if (bwd) launch_cluster<512, 64, 2, true>(s, p); else launch_cluster<512, 64, 2, false>(s, p); }
-    }
+    if (p.rpl == 1) { if (bwd) launch_cluster<PREC, HP, UPC, 1, true>(s, p); else launch_cluster<PREC, HP, UPC, 1, false>(s, p); }
+    else            { if (bwd) launch_cluster<PREC, HP, UPC, 2, true>(s, p); else launch_cluster<PREC, HP, UPC, 2, false>(s, p); }
+}
+
+static void launch_cluster_shape(hipStream_t s, int prec, bool bwd, const LstmRec &p)
+{
+    if (prec == P_X3)                                       launch_cluster_rpl<P_X3, 256, 64>(s, bwd, p);
+    else if (p.Hp == 256 && cluster_size(prec, 256) == 4)   launch_cluster_rpl<P_BF16, 256, 64>(s, bwd, p);
+    else if (p.Hp == 256)                                   launch_cluster_rpl<P_BF16, 256, 128>(s, bwd, p);
+    else                                                    launch_cluster_rpl<P_BF16, 512, 64>(s, bwd, p);
 }
 
 }  // namespace cn

@@ -242,6 +242,8 @@ X3_CASES = {
     "blstm320_streamed": (13, [("blstm", 320)], 9, [12, 12, 10, 7, 3], 5, 0.08),          # Hp = 160: W_rec streamed and split per step
     "tanh_lstm_softmax700": (6, [("feedforward_tanh", 40), ("lstm", 24)], 700, [9, 7, 7, 4], 5, 0.3),
     "two_sequences_per_lane": (4, [("blstm", 20)], 3, [6, 5] * 260, 520, 0.5),            # rpl = 2
+    "blstm500_cluster": (20, [("blstm", 500)], 12, [25, 25, 24, 22, 22, 20, 17, 15, 9, 4], 10, 0.06),   # Hp = 256: 4 CUs x 64 units
+    "blstm440_padded_to_cluster": (20, [("blstm", 440), ("blstm", 500)], 12, [14, 13, 13, 9, 2], 5, 0.06),
 }
 
 
@@ -257,7 +259,10 @@ def test_bf16x3_parity_mode(pkg, orc, case):
     xs, ts = random_sequences(rng, lengths, P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)
     ref, net = check_network(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16X3)
-    net.close()
+    with net:
+        if "cluster" in case:
+            assert net.recurrent_kernel(False) == "lstm_fwd_cluster_kernel<2,256,64,1>"
+            assert net.recurrent_kernel(True) == "lstm_bwd_cluster_kernel<2,256,64,1>"
 
 
 def test_bf16x3_mode_stays_on_the_oracle_through_training(pkg, orc):
@@ -376,7 +381,7 @@ def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, rpl, T):
 
 
 @pytest.mark.parametrize("size,rpl,kernel", [(384, 1, "lstm_fwd_kernel<0,192,1,1>"), (384, 2, "lstm_fwd_kernel<0,192,1,2>"),
-                                             (500, 2, "lstm_fwd_cluster_kernel<256,128,2>"), (1024, 2, "lstm_fwd_cluster_kernel<512,64,2>")])
+                                             (500, 2, "lstm_fwd_cluster_kernel<0,256,128,2>"), (1024, 2, "lstm_fwd_cluster_kernel<0,512,64,2>")])
 def test_row_pair_sparse_products_bf16_shapes(pkg, orc, monkeypatch, size, rpl, kernel):
     """Shapes that exist in bf16 mode only: Hp = 192 register resident (one and two sequences per lane) and the 2-CU / 8-CU
     clusters with two sequences per lane.  bf16 tolerances: these catch a misplaced operand (errors of order one), not
