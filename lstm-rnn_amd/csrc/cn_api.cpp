@@ -147,7 +147,7 @@ struct cn_layer {
     float *targets = nullptr;             // sse: [maxN][size]
 
     // lstm internals
-    float *acts = nullptr, *cell = nullptr;
+    float *acts = nullptr, *cell = nullptr, *th = nullptr;
     void *delta_op = nullptr;
 
     // parameters (flat reference layout, inside the ctx arena)
@@ -451,7 +451,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     cn_ctx *c = l->ctx;
     r.H = l->H; r.Hp = l->Hp; r.dirs = l->dirs; r.PS = c->PSp; r.T = c->T; r.Tmin = c->Tmin;
     r.pat = c->d_pat;
-    r.acts = l->acts; r.cell = l->cell; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
+    r.acts = l->acts; r.cell = l->cell; r.th = l->th; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
     r.rpl = c->rpl;
@@ -942,6 +942,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->err = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
             l->acts = (float *)dalloc(l, maxN * R * sizeof(float));
             l->cell = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->th = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
             l->delta_op = dalloc(l, maxN * R * e);
             l->Win = dalloc(l, R * l->Pp * e); l->WinT = dalloc(l, R * l->Pp * e);
             l->Wrec = dalloc(l, R * l->Hp * e); l->WrecT = dalloc(l, R * l->Hp * e);

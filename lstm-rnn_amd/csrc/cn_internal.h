@@ -74,6 +74,7 @@ struct LstmRec {
     // forward
     float *acts;                  // [N][dirs][Hp][4] fp32: pre-activations in, n/i/f/o activations out (gate innermost)
     float *cell;                  // [N][dirs][Hp]    fp32
+    float *th;                    // [N][dirs][Hp]    fp32 tanh(cell state), kept by the forward pass for the backward pass
     void  *y_op;                  // [N][dirs*Hp]     op  (layer output, GEMM operand)
     const void *Wrec;             // [dirs][4*Hp][Hp] op  (k = source unit contiguous)
     const float *peep;            // [dirs][3][Hp]

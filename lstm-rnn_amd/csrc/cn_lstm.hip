@@ -41,6 +41,9 @@
 #ifndef CN_SPARSE
 #define CN_SPARSE 1
 #endif
+#ifndef CN_TH_STORE
+#define CN_TH_STORE 1
+#endif
 #ifndef CN_X3_ACCURATE_ACT
 #define CN_X3_ACCURATE_ACT 0
 #endif
@@ -178,7 +181,11 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
     for (int r = 0; r < RPL; ++r) {
         const int sv = s0 + 4 * r + q;
-        oP[r] = sv;
+        // pattern types travel as the aligned dword of the four sequences of a tile row group (PS and s0 are multiples of 4);
+        // the offset is formally per lane (vzero) so that it stays a vector load: a scalar load would share lgkmcnt with the LDS
+        unsigned vzero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+        oP[r] = (unsigned)(s0 + 4 * r) / 4 + vzero;
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
             oA[u][r] = sv * (int)arow + (d * Hp + unit[u]) * 4;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         const char *patT = p.pat + (long)t * PS;
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
-            pt[r] = (unsigned char)at32<char>(patT, oP[r]);
+            pt[r] = (int)at32<unsigned>(patT, oP[r]);
 #pragma unroll
             for (int u = 0; u < UG; ++u) pre[u][r] = *(const f32x4 *)&at32<float>(actsT, oA[u][r]);
         }
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
     for (int g = 0; g < 4; ++g) accp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const unsigned ptmask = 0xffu << (8 * q);        // this lane's byte of a pattern-type dword
     STAMP_DECL
     auto step = [&](int it, f32x4 (&pre)[UG][RPL], int (&pt)[RPL]) {
         const int t = d ? T - 1 - it : it;
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
+        [[maybe_unused]] float *thT = p.th + t * stepC;
         char *yT = (char *)p.y_op + t * stepC * MELT;
 
         // accumulators start at 0 (inline constant, nothing to set up before the first MFMA); the gate
@@ -246,7 +255,14 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
         f32x4 g_[UG][RPL];
         bool dummy_[RPL];
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) dummy_[r] = check && pt[r] == 0;
+        for (int r = 0; r < RPL; ++r) {
+            // (staged like the pre-activations, through an asm instruction that stays in this step and picks this lane's byte:
+            // hipcc otherwise evaluates the OTHER stage's pattern type one step early, behind an s_waitcnt for a load that was
+            // issued only a step before)
+            int ptc;
+            asm volatile("v_and_b32 %0, %1, %2" : "=&v"(ptc) : "v"(pt[r]), "v"(ptmask));
+            dummy_[r] = check && ptc == 0;
+        }
 #pragma unroll
         for (int u = 0; u < UG; ++u) {
             // the staged values move to registers of their own (early-clobber asm copy) so that the prefetch
@@ -377,7 +393,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 const float fg = logistic<ACC>(s_[2] + cp * pf[u]);
                 const float cs = ni * ig + cp * fg;
                 const float og = logistic<ACC>(s_[3] + cs * po[u]);
-                const float y = tanh_ref<ACC>(cs) * og;
+                const float th = tanh_ref<ACC>(cs);
+                const float y = th * og;
                 float yo = dummy ? 0.f : y;
                 const float co = dummy ? 0.f : cs;     // :78-85 (zeroed in both directions here)
                 cst[u][r] = co;
@@ -394,6 +411,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
                 const f32x4 av = {ni, ig, fg, og};       // (dummy slots: never read back)
                 *(f32x4 *)&at32<float>(actsT, oA[u][r]) = av;
                 at32<float>(cellT, oC[u][r]) = co;
+                at32<float>(thT, oC[u][r]) = th;          // the backward pass reads it back instead of recomputing it (dummy slots: never used)
                 if constexpr (MELT == 4) at32<float>(yT, oC[u][r]) = yo;
                 else at32<__bf16>(yT, oC[u][r]) = (__bf16)yo;
             }
@@ -436,6 +454,7 @@ template <int UG, int RPL> struct BwdPre {
     f32x4 a[UG][RPL];        // n, i, f, o of step t
     float e[UG][RPL];        // outputErrors of step t
     float cp[UG][RPL];       // cell state of prev(t)
+    float th[UG][RPL];       // tanh(cell state) of step t (CN_TH_STORE)
 };
 
 template <int PREC, int HP, int UG, int RPL>
@@ -576,6 +595,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 pre.e[u][r] = at32<float>(p.err, bC + oC[u][r]);
                 pre.a[u][r] = *(const f32x4 *)&at32<float>(p.acts, bA + oA[u][r]);
                 pre.cp[u][r] = at32<float>(p.cell, bCp + oC[u][r]);     // raw; masked with lastCall when consumed (no wait here)
+                if constexpr (CN_TH_STORE) pre.th[u][r] = at32<float>(p.th, bC + oC[u][r]);
             }
         }
     };
@@ -593,6 +613,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
         f32x4 acc[UG];
         f32x4 a_[UG][RPL];
         float cp_[UG][RPL];
+        [[maybe_unused]] float th_[UG][RPL];
         unsigned char dmy[RPL];                      // dummy-slot flags of this step (LDS table, see the forward kernel)
 #pragma unroll
         for (int r = 0; r < RPL; ++r) dmy[r] = dtab[t * (4 * RPL) + 4 * r + q];
@@ -610,6 +631,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 asm volatile("v_mov_b32 %0, %1" : "=&v"(c_) : "v"(pre.cp[u][r]));
 #pragma unroll
                 for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(a_[u][r][g]) : "v"(pre.a[u][r][g]));
+                if constexpr (CN_TH_STORE) asm volatile("v_mov_b32 %0, %1" : "=&v"(th_[u][r]) : "v"(pre.th[u][r]));
                 acc[u][r] = e_;                                                             // err enters as the MFMA C operand
                 cp_[u][r] = hasprev_ ? c_ : 0.f;
             }
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 const float e = acc[u][r];
                 const float ni = a_[u][r][0], ig = a_[u][r][1], fg = a_[u][r][2], og = a_[u][r][3];
                 const float cs = ccur[u][r], cp = cp_[u][r];
-                const float th = tanh_ref<ACC>(cs);
+                const float th = CN_TH_STORE ? th_[u][r] : tanh_ref<ACC>(cs);      // (the forward pass's value, same function of the same cs)
                 float dog = og * (1.0f - og) * th * e;
                 float ec = og * (1.0f - th * th) * e + po[u] * dog;
                 ec += fgn[u][r] * ecn[u][r] + pi[u] * dign[u][r] + pf[u] * dfgn[u][r];   // zero carry at firstCall

@@ -30,6 +30,9 @@
 #ifndef CN_SPARSE
 #define CN_SPARSE 1
 #endif
+#ifndef CN_TH_STORE
+#define CN_TH_STORE 1
+#endif
 
 #include <cstdlib>
 #include <map>
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         const char *ycur = smem + (it & 1) * PLANES * plane;
         char *ynxt = smem + ((it + 1) & 1) * PLANES * plane;
         const bool check = t >= p.Tmin;
-        float *actsT = p.acts + t * stepA, *cellT = p.cell + t * stepC;
+        float *actsT = p.acts + t * stepA, *cellT = p.cell + t * stepC, *thT = p.th + t * stepC;
         char *yT = (char *)p.y_op + t * stepC * MELT;
         u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * NT);
 
@@ -257,7 +260,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const float fg = logistic<false>(s_[2] + g_[r][2] + cp * pf);
             const float cs = ni * ig + cp * fg;
             const float og = logistic<false>(s_[3] + g_[r][3] + cs * po);
-            const float y = tanh_ref<false>(cs) * og;
+            const float th = tanh_ref<false>(cs);
+            const float y = th * og;
             const float co = dummy ? 0.f : cs;
             const float yo = dummy ? 0.f : y;
             const __bf16 yb = (__bf16)yo;
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const f32x4 av = {ni, ig, fg, og};
             *(f32x4 *)(actsT + oA[r]) = av;
             cellT[oC[r]] = co;
+            thT[oC[r]] = th;                                 // for the backward pass (cn_lstm.hip)
             if constexpr (X3) ((float *)yT)[oC[r]] = yo; else ((__bf16 *)yT)[oC[r]] = yb;
         }
         lds_barrier();
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-template <int RPL> struct ClBwdPre { f32x4 a[RPL]; float e[RPL], cp[RPL]; char pt[RPL]; };
+template <int RPL> struct ClBwdPre { f32x4 a[RPL]; float e[RPL], cp[RPL], th[RPL]; char pt[RPL]; };
 
 template <int PREC, int HP, int UPC, int RPL>
 __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
@@ -302,6 +307,9 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     constexpr bool X3 = PREC == P_X3;
     constexpr int MELT = X3 ? 4 : 2, PLANES = X3 ? 2 : 1;
     constexpr int G = X3 ? 4 : 2;                    // exchange granules per lane and sequence: four fp32 deltas, or two bf16 pairs
+    // tanh(cell state) read back from the forward pass instead of recomputed: on the 64-unit members; the 128-unit members run two
+    // waves per SIMD at the register limit, where the extra staged value costs more than the five instructions (measured: +7 %)
+    constexpr bool TH = CN_TH_STORE && UPC <= 64;
     // SP: 2:4 row-pair products (cn_lstm_device.h); KHS: with one sequence per lane the other row pair of its quad holds the
     // second half of every member part (two accumulators, half the operand reads), see cn_lstm.hip.  KHS on the 64-unit
     // members only: measured on the 128-unit members (reading B / LVCSR) the backward kernel is 5 % slower with it.
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             pre.e[r] = errT[oC[r]];
             pre.a[r] = *(const f32x4 *)(actsT + oA[r]);
             pre.cp[r] = cellP[oC[r]];
+            if constexpr (TH) pre.th[r] = (p.th + t * stepC)[oC[r]];
         }
     };
 
@@ -404,11 +413,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
         [[maybe_unused]] f32x4 accs, acch;           // SP: the row-pair accumulator (KHS: first half) and the second half's
         float cp_[RPL];
+        [[maybe_unused]] float th_[RPL];
         char ptc[RPL];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (r < RPL) ? pre.e[r < RPL ? r : 0] : 0.f;
 #pragma unroll
-        for (int r = 0; r < RPL; ++r) { ptc[r] = pre.pt[r]; cp_[r] = hasprev_ ? pre.cp[r] : 0.f; a_[r] = pre.a[r]; }
+        for (int r = 0; r < RPL; ++r) { ptc[r] = pre.pt[r]; cp_[r] = hasprev_ ? pre.cp[r] : 0.f; a_[r] = pre.a[r]; if constexpr (TH) th_[r] = pre.th[r]; }
         // the product over member parts [p0, p1) of K
         auto product = [&](auto p0_, auto p1_) {      // (compile-time bounds: wreg must stay in registers)
             constexpr int p0 = decltype(p0_)::value, p1 = decltype(p1_)::value;
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             const float e = acc[r];
             const float ni = a_[r][0], ig = a_[r][1], fg = a_[r][2], og = a_[r][3];
             const float cs = ccur[r], cp = cp_[r];
-            const float th = tanh_ref<false>(cs);
+            const float th = TH ? th_[r] : tanh_ref<false>(cs);
             float dog = og * (1.0f - og) * th * e;
             float ec = og * (1.0f - th * th) * e + po * dog;
             ec += fgn[r] * ecn[r] + pi * dign[r] + pf * dfgn[r];
