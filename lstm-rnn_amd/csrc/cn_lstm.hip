@@ -16,8 +16,11 @@
 //   * the four gates are packed into one tile row: wave w owns hidden units [16w, 16w+16) and
 //     the 4 gate tiles of those units, so after the MFMAs every lane holds n/i/f/o of one unit
 //     and the cell update needs no cross-lane traffic.  Gate pre-activations from the N-wide input
-//     GEMM (bias already added) enter as the MFMA C operand; they are stored [frame][unit][gate] so
-//     a lane moves them with one 16-byte access.
+//     GEMM (bias already added) are stored [frame][unit][gate] so a lane moves them with one 16-byte
+//     access; they are added after the MFMAs (dense path) or seed the accumulators (row-pair path).
+//   * bf16 / split-bf16 modes with at most two sequences per lane: the recurrent products run on the 2:4 sparse
+//     MFMA with every sequence spread over two tile rows ("row pairs", cn_lstm_device.h) -- half the MFMA-pipe
+//     time and half the operand reads of the dense tile, nothing pruned.
 //   * W_rec fragments stay in registers for the whole pass when 4*Hp*Hp operands fit one CU's
 //     register file (Hp <= 128), otherwise they are streamed from L2 every step.
 //   * y[t] (forward) / the four deltas (backward) are exchanged between the waves of the workgroup

@@ -12,15 +12,16 @@
 // (sc1, write-through); the consumer re-reads the granule with relaxed agent-scope atomic loads (sc1, bypasses
 // the per-CU L1) until the tag matches -- no fences, placement independent.  Granule slots alternate with the
 // step parity (tags count on across launches, LstmRec::xch_epoch): a producer can only overwrite slot p at step t+2 after it has consumed its partners' step t+1,
-// which they published after consuming its step t from that very slot.  The exchange buffer is zeroed before
-// every launch (tags restart at 1); every spin is bounded and reports through a fault word instead of hanging.
+// which they published after consuming its step t from that very slot.  Tags count on across launches (the buffer is cleared
+// only at allocation and long before the 32-bit tags would wrap); every spin is bounded and reports through a fault word instead
+// of hanging.
 // Cluster members sit 8 block ids apart (same XCD under round-robin placement: speed only, never correctness);
 // the launcher only uses this path when the whole grid is resident (<= one workgroup per CU of the device, whose CU count
 // it is given), and launches of different contexts on one device are serialised (cluster_gate) so that two half-resident
 // grids cannot wait for each other.
 //
-// Arithmetic is identical to cn_lstm.hip (same MFMA tiles -- the 2:4 row-pair sparse products included --, same cell update);
-// bf16 operand mode only.
+// Arithmetic is identical to cn_lstm.hip (same MFMA tiles -- the 2:4 row-pair sparse products included --, same cell update).
+// Modes: CN_PREC_BF16 (Hp = 256 as 2 x 128 units, Hp = 512 as 8 x 64) and CN_PREC_BF16X3 (Hp = 256 as 4 x 64: hi and lo fragments).
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
