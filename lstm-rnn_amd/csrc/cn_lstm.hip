@@ -71,6 +71,13 @@ __device__ unsigned long long cn_stamp_buf[2][16][8];
 #endif
 
 // element `elem` of an array of T at a wave-uniform base: the byte offset stays a 32-bit VGPR (saddr form)
+// Keeps every lane of an MFMA accumulator tuple allocated until `after` (a value computed from the tuple's results) exists.
+// Lanes whose rows are never read are dead to the register allocator, which may hand them to another value while the MFMA
+// that will still write them is in flight.  For ordinary instructions the hazard recognizer then inserts the wait states; the
+// staged-operand copies of these kernels are inline asm, which it does not look into: observed once (an experimental build,
+// T = 1 path): `v_smfmac v[140:143]` followed by the asm copy `v_mov_b32 v142, ...`, overwritten when the MFMA retired.
+#define KEEP_TUPLE(tuple, after) asm volatile("" :: "v"(tuple), "v"(after))
+
 template <typename T> __device__ __forceinline__ T &at32(const void *base, unsigned elem)
 {
     return *(T *)((char *)base + elem * (unsigned)sizeof(T));
@@ -391,6 +398,10 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_fwd_kernel(LstmR
 #pragma unroll
                 for (int g = 0; g < 4; ++g)          // SP: the pre-activation entered through the even row's accumulator
                     s_[g] = SP ? accp[g][(2 * r) & 3] + accp[g][(2 * r + 1) & 3] : acc[u][g][r] + g_[u][r][g];
+                if (r == RPL - 1) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { if constexpr (SP) KEEP_TUPLE(accp[g], s_[g]); else KEEP_TUPLE(acc[u][g], s_[g]); }
+                }
                 const float ni = tanh_ref<ACC>(s_[0]);
                 const float ig = logistic<ACC>(s_[1] + cp * pi[u]);
                 const float fg = logistic<ACC>(s_[2] + cp * pf[u]);
@@ -669,6 +680,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                     }
                 }
                 acc[0][0] = (accA[0] + accA[1]) + (accB[2] + accB[3]);
+                KEEP_TUPLE(accA, acc[0][0]); KEEP_TUPLE(accB, acc[0][0]);
             } else {
                 f32x4 accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -680,6 +692,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 }
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) acc[0][r] = accs[2 * r] + accs[2 * r + 1];
+                KEEP_TUPLE(accs, acc[0][RPL - 1]);
             }
         } else if constexpr (KQS) {
             f32x4 accq[4];
@@ -704,6 +717,8 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                     else mma16<F32>(accq[r], a[kc], wreg[0][r * KCQ + kc]);
                 }
             acc[0][0] = (accq[0][0] + accq[1][1]) + (accq[2][2] + accq[3][3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) KEEP_TUPLE(accq[r], acc[0][0]);
         } else if constexpr (RES) {
             // A-operand reads run LDS_AHEAD chunks ahead of the MFMAs that consume them.  Left alone, the
             // scheduler issues each read one chunk ahead, so every MFMA group waits most of an LDS round trip
@@ -768,6 +783,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
                 const float cs = ccur[u][r], cp = cp_[u][r];
                 const float th = CN_TH_STORE ? th_[u][r] : tanh_ref<ACC>(cs);      // (the forward pass's value, same function of the same cs)
                 float dog = og * (1.0f - og) * th * e;
+                if constexpr (!SP && !KQS) { if (r == RPL - 1) KEEP_TUPLE(acc[u], dog); }      // (the dense tile's padding rows)
                 float ec = og * (1.0f - th * th) * e + po[u] * dog;
                 ec += fgn[u][r] * ecn[u][r] + pi[u] * dign[u][r] + pf[u] * dfgn[u][r];   // zero carry at firstCall
                 float dni = ig * (1.0f - ni * ni) * ec;
