@@ -339,7 +339,8 @@ def main():
     # informational extra lines: the Graves-literal reading of "3x250" and the parity (fp32-tolerance) arithmetic mode
     also_spec = [a for a in args.also.split(",") if a]
     if not args.also and world == 1 and args.workload == "timit_3x250_blstm_H125" and not args.no_also:
-        also_spec = ["timit_3x500_blstm_H250"] + (["timit_3x250_blstm_H125:bf16x3"] if "bf16x3" in PRECISIONS else []) + ["timit_3x250_blstm_H125:f32"]
+        also_spec = (["timit_3x500_blstm_H250"] + (["timit_3x250_blstm_H125:bf16x3", "timit_3x500_blstm_H250:bf16x3"] if "bf16x3" in PRECISIONS else [])
+                     + ["timit_3x250_blstm_H125:f32"])
     also = {}
     for spec in also_spec:
         name, _, pr = spec.partition(":")
