@@ -377,25 +377,34 @@ def main():
             tm, fr = res["timing"], res["timing_frames"]
             b_fwd, b_bwd, fl_rec = rec_algorithmic(wl["hidden"])
             nl_f, nl_b = max(1, tm["rec_fwd"][1]), max(1, tm["rec_bwd"][1])
-            bwd_dom = tm["rec_bwd"][0] >= tm["rec_fwd"][0]
-            dom = res["kernels"][1] if bwd_dom else res["kernels"][0]          # the kernel that actually ran (cluster or single-CU)
-            ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if bwd_dom else (tm["rec_fwd"][0], nl_f, b_fwd)
+            # The dominant kernel is the recurrent kernel with the larger share of device time.  Since round 2 the forward and the
+            # backward kernel are within a per cent of each other; inside that noise band (3 %) the backward kernel -- the one with
+            # more algorithmic bytes per frame, reported since round 1 -- stays the reference, and the other one is always reported
+            # beside it (`roofline_other`) so that neither number hides.
+            bwd_dom = tm["rec_bwd"][0] >= 0.97 * tm["rec_fwd"][0]
             nlayers = len(wl["hidden"])
-            frames_per_launch = fr / (nl / float(nlayers))      # one launch = one layer pass over one fraction
-            bytes_per_launch = bpf / nlayers * frames_per_launch
-            avg_s = ms / nl * 1e-3
-            ach = bytes_per_launch / avg_s / 1e9
             total_ms = sum(v[0] for v in tm.values())
-            traffic, src = (None, None)
-            if args.workload == "timit_3x250_blstm_H125" and args.parallel_sequences == 50 and args.precision == "bf16":
-                tb, src = pmc_bytes_per_launch(dom.split("<")[0])
-                traffic = tb / avg_s / 1e9 if tb else None
-            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
-                               "algorithmic_bytes_per_launch": bytes_per_launch,
-                               "avg_launch_ms": ms / nl, "launches": nl,
-                               "note": "latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
-                                       "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items())}
+
+            def roof(bwd):
+                dom = res["kernels"][1] if bwd else res["kernels"][0]          # the kernel that actually ran (cluster or single-CU)
+                ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if bwd else (tm["rec_fwd"][0], nl_f, b_fwd)
+                frames_per_launch = fr / (nl / float(nlayers))      # one launch = one layer pass over one fraction
+                bytes_per_launch = bpf / nlayers * frames_per_launch
+                avg_s = ms / nl * 1e-3
+                ach = bytes_per_launch / avg_s / 1e9
+                traffic, src = (None, None)
+                if args.workload == "timit_3x250_blstm_H125" and args.parallel_sequences == 50 and args.precision == "bf16":
+                    tb, src = pmc_bytes_per_launch(dom.split("<")[0])
+                    traffic = tb / avg_s / 1e9 if tb else None
+                return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
+                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms / nl, "launches": nl,
+                        "share_of_device_time": ms / total_ms}
+
+            out["roofline"] = roof(bwd_dom)
+            out["roofline"]["note"] = ("latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
+                                       "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items()))
+            out["roofline_other"] = roof(not bwd_dom)
             fpf = flops_per_frame(wl["P"], wl["hidden"], wl["C"])
             gemm_ms = tm["gemm_wide"][0] + tm["gemm_grad"][0]
             rec_ms = tm["rec_fwd"][0] + tm["rec_bwd"][0]
