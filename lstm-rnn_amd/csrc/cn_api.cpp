@@ -148,6 +148,7 @@ struct cn_layer {
 
     // lstm internals
     float *acts = nullptr, *cell = nullptr, *th = nullptr;
+    bool err_in_delta = false;            // ff/softmax, bf16 mode: outputErrors of the last backward pass exist only as the bf16 operand copy
     void *delta_op = nullptr;
 
     // parameters (flat reference layout, inside the ctx arena)
@@ -590,8 +591,11 @@ void ff_backward(cn_layer *l)
     {
         Timed tm(c, KC_OTHER);
         if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
-            launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, l->err, l->delta_op, l->dbias);
+            // bf16 mode: the fp32 outputErrors stay unwritten (read back from the bf16 operand copy if anyone asks)
+            launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias);
+            l->err_in_delta = !c->f32;
         } else {
+            l->err_in_delta = false;
             if (l->mcc_pending) launch_mcc_backward(c->stream, l->out_f32, c->d_tcls, N, l->size, l->Lp, l->err);
             if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, l->out_f32, l->err, c->d_pat, N, l->size, l->Lp);
             launch_ff_delta(c->stream, c->f32, ff_act(l->kind), l->out_f32, l->err, l->delta_op, N, l->size, l->Lp);
@@ -1356,6 +1360,7 @@ int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t coun
         HIP_CHECK(hipMalloc((void **)&tmp, count * sizeof(float)));
         HIP_CHECK(hipMemcpyAsync(tmp, host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
         layer->mcc_pending = false;
+        layer->err_in_delta = false;
         HIP_CHECK(hipMemsetAsync(layer->err, 0, (size_t)c->N * layer->Lp * sizeof(float), c->stream));
         launch_pad_f32(c->stream, tmp, c->Next, layer->size, layer->err, layer->Lp, layer->lstm ? layer->H : 0, layer->lstm ? layer->Hp : 0, c->PS, c->PSp);
         HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -1411,6 +1416,8 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
             }
             if (layer->lstm)
                 for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, false, layer->err, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
+            else if (layer->err_in_delta)      // fused softmax backward in bf16 mode: only the operand copy exists
+                launch_unpad(c->stream, true, layer->delta_op, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else launch_unpad(c->stream, false, layer->err, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             break;
         case CN_BUF_LSTM_CELL_STATES:

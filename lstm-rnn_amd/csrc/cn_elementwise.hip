@@ -602,6 +602,8 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 // SoftmaxLayer.cu:317-349, FeedForwardLayer.cu:69-102).  The injected error is -1/max(FLT_MIN, p_t) at the
 // target and 0 elsewhere, so sum_j y_j e_j has exactly one non-zero term: bit-identical to the three passes.
 // Requires Lp <= 256 (column sums live in 4 registers per lane).
+// `err` may be null in bf16 mode: the fp32 outputErrors of the layer are then not materialised (nothing on the training path reads
+// them: the products take the bf16 operand copy), which is 4 of the 10 bytes per element this HBM-bound pass moves.
 template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                                        float *err, void *delta_op, float *colsum)
@@ -644,7 +646,7 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
                 if (j >= Lp) break;
                 float dl = 0.f;
                 if (real[b] && j < L) dl = yv[b][k] * ((j == tc[b] ? et[b] : 0.f) - off[b]);
-                err[row * Lp + j] = dl;
+                if (err) err[row * Lp + j] = dl;         // (bf16 mode: only the operand copy is written; cn_layer_read converts it)
                 if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
                 cs[k] += dl;
             }
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
 #pragma unroll
                 for (int e = 0; e < 4; ++e) if (j + e < L) dl[e] = yv[e] * ((j + e == tc ? et : 0.f) - off);
             }
-            *(f32x4 *)(err + row * Lp + j) = dl;
+            if (err) *(f32x4 *)(err + row * Lp + j) = dl;
             if constexpr (!F32) *(bf16x4 *)((__bf16 *)delta_op + row * Lp + j) = bf16x4{(__bf16)dl[0], (__bf16)dl[1], (__bf16)dl[2], (__bf16)dl[3]};
             cs[k] += dl;
         }

@@ -402,6 +402,27 @@ def test_row_pair_sparse_products_bf16_shapes(pkg, orc, monkeypatch, size, rpl, 
             assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 5e-2, lay.name
 
 
+@pytest.mark.parametrize("C", [20, 700])
+def test_softmax_output_errors_read_back_in_bf16_mode(pkg, orc, C):
+    """bf16 mode: the fused softmax / multiclass backward kernel (narrow and wide rows) writes only the bf16 operand copy of the
+    layer's outputErrors; cn_layer_read hands that copy back.  It must be the oracle's outputErrors up to bf16 rounding and the
+    bf16 noise of the forward pass (SoftmaxLayer.cu:317-349 after MulticlassClassificationLayer.cu:220-240)."""
+    rng = np.random.RandomState(5 + C)
+    P, PS = 9, 6
+    layers = net_desc(P, [("blstm", 24)], C)
+    weights = random_weights(layers, rng, 0.3)
+    xs, ts = random_sequences(rng, [11, 10, 10, 7, 4, 2], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    ref, net, _, _ = run_both(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16)
+    with net:
+        real = real_mask(frac)
+        sm, rsm = net.layers[-2], ref.layers[-2]
+        oe = sm.output_errors().reshape(-1, C)[real]
+        roe = rsm.outputErrors[:net.N * C].reshape(-1, C)[real]
+        assert np.abs(oe - roe).max() < 2e-2 * np.abs(roe).max()
+        assert np.abs(oe).max() > 0.1                                   # (it is there at all)
+
+
 @pytest.mark.parametrize("T", [1, 2, 3, 6])
 @pytest.mark.parametrize("PS", [3, 520, 1100])
 def test_short_sequences_and_sequences_per_lane(pkg, orc, T, PS):
