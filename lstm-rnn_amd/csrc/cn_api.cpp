@@ -63,7 +63,7 @@ struct cn_ctx {
     // CU-masked twin of the side stream: gradient GEMMs that run beside a recurrent kernel have its whole duration
     // to finish, and at full speed their memory traffic stalls the latency-bound recurrent kernel (291 vs 229 us
     // per backward launch); on a subset of the CUs they run longer but draw less bandwidth
-    hipStream_t side_slow = nullptr;
+    hipStream_t side_slow = nullptr; int side_cus = 0;    // CU-masked side stream and its CU count
     hipEvent_t ev_sgd = nullptr, ev_ext = nullptr;
     hipEvent_t ev_pack_last = nullptr;         // = ev_pack of the last layer whose operand copies cn_sgd_update_all rebuilt (not owned)
     std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet ...
@@ -321,8 +321,20 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     if (tail_on_main && l->prev && !l->prev->trainable && !fork_attached) { f(c->stream, nullptr); return; }
     if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
     if (!fork_attached) HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
-    // a recurrent kernel follows on the main stream when the preceding layer is an LSTM layer: slow lane
-    hipStream_t st = (c->side_slow && l->prev && l->prev->lstm) ? c->side_slow : c->side;
+    // a recurrent kernel follows on the main stream when the preceding layer is an LSTM layer: slow lane (a CU-masked stream, so
+    // that the gradient products leave the latency-bound recurrent kernel's CUs and memory path alone) -- unless the products
+    // would outlast that kernel on the masked CUs and end up in front of the next N-wide product of the critical path
+    // (LVCSR config: the softmax layer's 8000 x 1024 gradient took 2.0 ms on 80 CUs beside a 1.3 ms recurrent kernel and the
+    // error product behind it 757 instead of 140 us; 13.3 -> 12.7 ms per fraction with the rule below)
+    bool slow = c->side_slow && l->prev && l->prev->lstm;
+    static const bool side_rule = getenv("CN_NO_SIDE_RULE") == nullptr;
+    if (slow && side_rule) {
+        const double flops = 2.0 * c->N * (l->lstm ? (double)l->dirs * 4 * l->Hp * (l->Pp + l->Hp) : (double)l->Lp * l->Pp);
+        const double t_side = flops / (c->side_cus * 1.5e12);                                        // ~1.5 TFLOP/s per CU
+        const double t_rec = c->T * (l->prev->Hp > 192 ? 1.4e-6 : 0.5e-6);                           // cluster / single-CU step
+        if (t_side > 0.8 * t_rec) slow = false;
+    }
+    hipStream_t st = slow ? c->side_slow : c->side;
     HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
     // the join event rides on the last kernel of the side work too (f returns true when it attached it)
     const bool join_attached = f(st, (c->attach_forks && !c->timing) ? l->ev_join : nullptr);
@@ -692,6 +704,7 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             int ncu = prop.multiProcessorCount * 5 / 16;
             if (const char *e = getenv("CN_SIDE_CUS")) ncu = atoi(e);
             c->side_slow = masked_stream(device_id, ncu, prop.multiProcessorCount);
+            c->side_cus = ncu;
         }
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_NO_ATTACHED_FORKS")) c->attach_forks = atoi(e) == 0;
