@@ -1526,7 +1526,11 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         if (ctx->overlap && !grouped && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
         bool own_rates = false;
         for (cn_layer *l : ctx->layers) own_rates = own_rates || (l->trainable && l->own_lr >= 0.f);
-        if (!own_rates) {
+        // grouped: the update itself rides on the pack launch (pack_fetch): one kernel instead of two behind the last gradient
+        static const bool fuse_off = getenv("CN_NO_SGD_FUSE") != nullptr;
+        const bool fused = grouped && !fuse_off;
+        if (fused) {
+        } else if (!own_rates) {
             launch_sgd(ctx->stream, ctx->arena, ctx->arena + ctx->total, ctx->arena + 2 * ctx->total, ctx->total, learning_rate, momentum,
                        attach ? ctx->ev_sgd : nullptr);
         } else {
@@ -1548,6 +1552,10 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
                 if (l->lstm) it.lg = lstm_geom(l); else it.fg = ff_geom(l);
                 it.bias = l->bias; it.w = l->w; it.Win = l->Win; it.WinT = l->WinT; it.Wrec = l->Wrec; it.WrecT = l->WrecT;
                 it.bias_p = l->bias_p; it.peep_p = l->peep_p;
+                if (fused) {
+                    it.update = 1; it.w_rw = l->w; it.wu = l->wu; it.wd = l->wd;
+                    it.lr = l->own_lr >= 0.f ? l->own_lr : learning_rate; it.mom = momentum;
+                }
                 l->dirty = false; l->pack_pending = false;
             }
             launch_pack_group(ctx->stream, ctx->f32, grp);

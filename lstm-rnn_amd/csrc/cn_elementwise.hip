@@ -42,10 +42,26 @@ __device__ __forceinline__ int pad_col(int i, int prevH, int prevHp)
 // ---------------------------------------------------------------------------------------------
 // LSTM weight packing (flat layout: LstmLayer.hpp:36-55, LstmLayer.cu:535-541,583-596)
 // ---------------------------------------------------------------------------------------------
+// The weight at flat index fi as the operand copies should see it: as stored, or (upd) after the momentum-SGD step, which this
+// thread then also writes back (same arithmetic as sgd_kernel: separate multiplies and adds, no contraction).
+struct PackUpd { float *w_rw; const float *wu; float *wd; float lr, mom; };
+template <bool UPD>
+__device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, long fi)
+{
+    if constexpr (UPD) {
+        const float dl = __fsub_rn(__fmul_rn(u.mom, u.wd[fi]), __fmul_rn(u.lr, u.wu[fi]));   // SteepestDescentOptimizer.cu:51
+        u.wd[fi] = dl;
+        const float v = __fadd_rn(u.w_rw[fi], dl);                                            // :55
+        u.w_rw[fi] = v;
+        return v;
+    } else return w[fi];
+}
+
 // (first / count: the workgroups [first, first + count) of the launch work on this layer: pack_group_kernel)
-template <bool F32>
+template <bool F32, bool UPD = false>
 __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, const float *w, void *Win, void *WinT,
-                                               void *Wrec, void *WrecT, float *bias_p, float *peep_p, int first, int count)
+                                               void *Wrec, void *WrecT, float *bias_p, float *peep_p, int first, int count,
+                                               const PackUpd &upd = PackUpd{})
 {
     const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp, dirs = g.dirs;
     const long R = (long)dirs * 4 * Hp;                 // packed gate rows
@@ -59,7 +75,7 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             const int d = r / (4 * Hp), j = (r / 4) % Hp, gg = r % 4;
             const int i = unpad_col(pc, P, g.prevH, g.prevHp, g.prevDirs);
             float v = 0.f;
-            if (j < H && i >= 0) v = w[(long)gg * L * P + (long)d * H * P + (long)j * P + i];
+            if (j < H && i >= 0) v = pack_fetch<UPD>(w, upd, (long)gg * L * P + (long)d * H * P + (long)j * P + i);
             st_op<F32>(Win, (long)r * Pp + pc, v);
             st_op<F32>(WinT, (long)pc * R + r, v);
         } else if (idx < nIn + nRec) {
@@ -68,17 +84,17 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             const int gg = rem / (Hp * Hp), j = (rem / Hp) % Hp, i = rem % Hp;
             float v = 0.f;
             if (j < H && i < H)
-                v = w[4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i];
+                v = pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i);
             st_op<F32>(Wrec, ((long)d * 4 * Hp + gg * Hp + j) * Hp + i, v);
             st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + 4 * j + gg, v);
         } else if (idx < nIn + nRec + nB) {
             const int k = idx - nIn - nRec;
             const int d = k / (4 * Hp), j = (k / 4) % Hp, gg = k % 4;
-            bias_p[k] = (j < H) ? bias * w[4L * L * P + gg * L + d * H + j] : 0.f;   // LstmLayer.cu:97-100
+            bias_p[k] = (j < H) ? bias * pack_fetch<UPD>(w, upd, 4L * L * P + gg * L + d * H + j) : 0.f;   // LstmLayer.cu:97-100
         } else {
             const int k = idx - nIn - nRec - nB;
             const int d = k / (3 * Hp), pp = (k / Hp) % 3, j = k % Hp;
-            peep_p[k] = (j < H) ? w[4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j] : 0.f;
+            peep_p[k] = (j < H) ? pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j) : 0.f;
         }
     }
 }
@@ -143,20 +159,21 @@ void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, flo
 // feed-forward weight packing (flat layout: [j][i] P x L column-major then L bias weights,
 // FeedForwardLayer.cu:148,160)
 // ---------------------------------------------------------------------------------------------
-template <bool F32>
-__device__ __forceinline__ void ff_pack_body(const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p, int first, int count)
+template <bool F32, bool UPD = false>
+__device__ __forceinline__ void ff_pack_body(const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p, int first, int count,
+                                             const PackUpd &upd = PackUpd{})
 {
     const long nW = (long)g.Lp * g.Pp, total = nW + g.Lp;
     for (long idx = (blockIdx.x - first) * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)count * blockDim.x) {
         if (idx < nW) {
             const int j = idx / g.Pp, pc = idx % g.Pp;
             const int i = unpad_col(pc, g.P, g.prevH, g.prevHp, g.prevDirs);
-            float v = (j < g.L && i >= 0) ? w[(long)j * g.P + i] : 0.f;
+            float v = (j < g.L && i >= 0) ? pack_fetch<UPD>(w, upd, (long)j * g.P + i) : 0.f;
             st_op<F32>(W, (long)j * g.Pp + pc, v);
             st_op<F32>(WT, (long)pc * g.Lp + j, v);
         } else {
             const int j = idx - nW;
-            bias_p[j] = (j < g.L) ? bias * w[(long)g.L * g.P + j] : 0.f;            // FeedForwardLayer.cu:59
+            bias_p[j] = (j < g.L) ? bias * pack_fetch<UPD>(w, upd, (long)g.L * g.P + j) : 0.f;            // FeedForwardLayer.cu:59
         }
     }
 }
@@ -176,6 +193,12 @@ __global__ void pack_group_kernel(PackGroup grp)
     for (int k = 1; k < PACK_GROUP_MAX; ++k) if (k < grp.n && (int)blockIdx.x >= grp.first[k]) i = k;
     const PackItem &it = grp.item[i];
     const int count = (i + 1 < grp.n ? grp.first[i + 1] : (int)gridDim.x) - grp.first[i];
+    if (it.update) {      // cn_sgd_update_all: the weight update rides on the pack (one launch instead of two on the critical tail)
+        const PackUpd upd{it.w_rw, it.wu, it.wd, it.lr, it.mom};
+        if (it.lstm) lstm_pack_body<F32, true>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd);
+        else         ff_pack_body<F32, true>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd);
+        return;
+    }
     if (it.lstm) lstm_pack_body<F32>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count);
     else         ff_pack_body<F32>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count);
 }

@@ -121,6 +121,9 @@ constexpr int PACK_GROUP_MAX = 8;
 struct PackItem {
     int lstm; LstmGeom lg; FfGeom fg; float bias; const float *w;
     void *Win, *WinT, *Wrec, *WrecT; float *bias_p, *peep_p;
+    // update == 1: the momentum-SGD step of SteepestDescentOptimizer.cu:39-59 is applied on the way (every flat weight is read by
+    // exactly one packed position, so the thread that packs it also updates it): wd = mom*wd - lr*wu; w += wd
+    int update; float *w_rw; const float *wu; float *wd; float lr, mom;
 };
 struct PackGroup { PackItem item[PACK_GROUP_MAX]; int first[PACK_GROUP_MAX]; int n; };
 void launch_pack_group(hipStream_t s, bool f32, PackGroup &grp, hipEvent_t done = nullptr);
