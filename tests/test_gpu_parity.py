@@ -403,6 +403,41 @@ def test_row_pair_sparse_products_bf16_shapes(pkg, orc, monkeypatch, size, rpl, 
 
 
 @pytest.mark.parametrize("C", [20, 700])
+@pytest.mark.parametrize("order", ["accumulate_then_backward", "accumulate_twice", "no_backward"])
+def test_loss_accumulate_matches_the_per_fraction_errors(pkg, orc, C, order):
+    """cn_loss_accumulate + cn_loss_read (the epoch sums of Optimizer.cu:46-55) against the per-fraction values of cn_loss_eval
+    and the oracle, over two fractions (narrow and wide softmax rows), with and without backward passes in between and with a
+    fraction accumulated twice."""
+    rng = np.random.RandomState(9 + C)
+    P, PS = 7, 5
+    layers = net_desc(P, [("blstm", 16)], C)
+    weights = random_weights(layers, rng, 0.3)
+    fracs = []
+    for lens in ([9, 9, 8, 5, 2], [7, 6, 6, 6, 1]):
+        xs, ts = random_sequences(rng, lens, P, C=C)
+        fracs.append(pkg.make_fraction(xs, ts, PS))
+    ref = orc.OracleNetwork(layers, weights, PS, max(f["T"] for f in fracs))
+    want_e, want_c = 0.0, 0
+    with pkg.NeuralNetwork(layers, weights, PS, max(f["T"] for f in fracs)) as net:
+        per_fraction = []
+        for f in fracs:
+            ref.load_sequences(f); ref.compute_forward_pass()
+            want_e += ref.calculate_error(); want_c += ref.count_correct_classifications()
+            net.load_sequences(f); net.compute_forward_pass()
+            per_fraction.append(net.error_and_correct())
+            net.loss_accumulate()
+            if order == "accumulate_twice":
+                net.loss_accumulate()
+            if order != "no_backward":
+                net.compute_backward_pass()
+        e, c = net.loss_read()
+        k = 2 if order == "accumulate_twice" else 1
+        assert abs(e - k * want_e) <= 1e-5 * k * want_e and c == k * want_c
+        assert abs(e - k * sum(x[0] for x in per_fraction)) <= 1e-6 * e
+        assert net.loss_read() == (0.0, 0)                              # (the read reset the sums)
+
+
+@pytest.mark.parametrize("C", [20, 700])
 def test_softmax_output_errors_read_back_in_bf16_mode(pkg, orc, C):
     """bf16 mode: the fused softmax / multiclass backward kernel (narrow and wide rows) writes only the bf16 operand copy of the
     layer's outputErrors; cn_layer_read hands that copy back.  It must be the oracle's outputErrors up to bf16 rounding and the
