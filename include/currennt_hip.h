@@ -26,6 +26,7 @@
 #define CURRENNT_HIP_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -187,7 +188,7 @@ int  cn_loss_eval(cn_layer *post_output, float *error, int *correct);
  * accumulators (Optimizer.cu:46-55 sums them per epoch on the host, two blocking D2H copies per
  * fraction) and read the sums once with cn_loss_read ([sync]; `reset` != 0 clears them). */
 int  cn_loss_accumulate(cn_layer *post_output);
-int  cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset);
+int  cn_loss_read(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset);
 
 /* ---- weights (TrainableLayer.cu:65-101,211-248) --------------------------------------------- */
 
@@ -249,7 +250,7 @@ int  cn_comm_info(const cn_ctx *ctx, int *rank, int *world);
  * order.                                                                                              [async] */
 int  cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n);
 /* cn_loss_read over all ranks: all-reduce(SUM) of the device-side error / #correct sums, then read.   [sync] */
-int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset);
+int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 
@@ -257,7 +258,7 @@ int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, long *correct_sum, int r
  * time; used by bench.py for the live roofline figure.  kernel_class: 0 = recurrent forward,
  * 1 = recurrent backward, 2 = N-wide gate GEMMs, 3 = weight-gradient GEMMs, 4 = everything else. */
 int  cn_ctx_timing_enable(cn_ctx *ctx, int enable);
-int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, long *launches); /* [sync] */
+int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches); /* [sync] */
 int  cn_ctx_timing_reset(cn_ctx *ctx);
 /* name of the recurrent kernel a layer's forward (backward != 0: backward) pass launches for the loaded fraction
  * shape, e.g. "lstm_bwd_kernel<bf16,Hp=128,rpl=1>" or "lstm_bwd_cluster_kernel<Hp=256,2 CUs>"; "" for other layers */

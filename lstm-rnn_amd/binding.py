@@ -108,7 +108,7 @@ def load_library():
     L.cn_fraction_load.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_fraction_load_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_loss_accumulate.argtypes = [vp]
-    L.cn_loss_read.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_long), ci]
+    L.cn_loss_read.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_layer_forward.argtypes = [vp]
     L.cn_layer_backward.argtypes = [vp]
     L.cn_loss_eval.argtypes = [vp, C.POINTER(cf), C.POINTER(ci)]
@@ -123,7 +123,7 @@ def load_library():
     L.cn_sgd_update.argtypes = [vp, cf, cf]
     L.cn_sgd_update_all.argtypes = [vp, cf, cf]
     L.cn_ctx_timing_enable.argtypes = [vp, ci]
-    L.cn_ctx_timing_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+    L.cn_ctx_timing_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.cn_ctx_timing_reset.argtypes = [vp]
     L.cn_layer_set_learning_rate.argtypes = [vp, cf]
     L.cn_layer_recurrent_kernel.argtypes = [vp, ci]
@@ -133,7 +133,7 @@ def load_library():
     L.cn_comm_destroy.argtypes = [vp]
     L.cn_comm_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.cn_allreduce_grads.argtypes = [vp, C.POINTER(vp), ci]
-    L.cn_loss_read_global.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_long), ci]
+    L.cn_loss_read_global.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_dbg_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci]
     L.cn_dbg_gemm_tn.argtypes = [vp, vp, vp, vp, ci, ci, ci]
     _LIB = L

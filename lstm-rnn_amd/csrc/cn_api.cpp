@@ -1289,7 +1289,7 @@ int cn_loss_accumulate(cn_layer *post)
     });
 }
 
-int cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
+int cn_loss_read(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset)
 {
     if (!ctx) { g_last_error = "cn_loss_read: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
@@ -1304,7 +1304,7 @@ int cn_loss_read(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
     });
 }
 
-int cn_loss_read_global(cn_ctx *ctx, float *error_sum, long *correct_sum, int reset)
+int cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset)
 {
     if (!ctx) { g_last_error = "cn_loss_read_global: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
@@ -1590,7 +1590,7 @@ int cn_ctx_timing_enable(cn_ctx *ctx, int enable)
     if (!ctx) { g_last_error = "cn_ctx_timing_enable: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); timing_collect(ctx); ctx->timing = enable != 0; });
 }
-int cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, long *launches)
+int cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches)
 {
     if (!ctx || kernel_class < 0 || kernel_class >= KC_COUNT) { g_last_error = "cn_ctx_timing_read: bad argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {

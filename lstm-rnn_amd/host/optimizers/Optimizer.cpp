@@ -101,7 +101,7 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     }
     if (calcWeightUpdates && !m_hybridOnlineBatch) _updateWeights();
     {
-        float e = 0; long correct = 0;
+        float e = 0; int64_t correct = 0;
         // data-parallel: the sums of all ranks (every rank then computes the same epoch errors and takes the same
         // early-stopping decisions)
         if (m_neuralNetwork.dataParallel())

@@ -230,7 +230,7 @@ class NeuralNetwork:
         B.check(self.lib.cn_loss_accumulate(self.layers[-1].handle), self.ctx)
 
     def loss_read(self, reset=True):
-        err, cor = C.c_float(), C.c_long()
+        err, cor = C.c_float(), C.c_int64()
         B.check(self.lib.cn_loss_read(self.ctx, C.byref(err), C.byref(cor), 1 if reset else 0), self.ctx)
         return float(err.value), int(cor.value)
 
@@ -300,7 +300,7 @@ class NeuralNetwork:
                 self.allreduce_grads([lay])
 
     def loss_read_global(self, reset=True):
-        err, cor = C.c_float(), C.c_long()
+        err, cor = C.c_float(), C.c_int64()
         B.check(self.lib.cn_loss_read_global(self.ctx, C.byref(err), C.byref(cor), 1 if reset else 0), self.ctx)
         return float(err.value), int(cor.value)
 
@@ -383,7 +383,7 @@ class NeuralNetwork:
         names = ["rec_fwd", "rec_bwd", "gemm_wide", "gemm_grad", "other"]
         out = {}
         for k, nm in enumerate(names):
-            ms, n = C.c_double(), C.c_long()
+            ms, n = C.c_double(), C.c_int64()
             B.check(self.lib.cn_ctx_timing_read(self.ctx, k, C.byref(ms), C.byref(n)), self.ctx)
             out[nm] = (ms.value, n.value)
         return out

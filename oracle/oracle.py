@@ -90,12 +90,13 @@ _REF_PATH = os.path.join(_HERE, "_ref", "libcurrennt_ref.so")
 _ref = None
 # the functions oracle/_ref implements with the reference's own functors (oracle/ref/*.cpp): same signatures as orc_*
 _REF_FUNCS = ["matmul", "lstm_forward", "lstm_backward", "ff_forward", "ff_backward", "softmax_forward", "softmax_backward",
-              "mcc_error", "mcc_correct", "mcc_backward"]
+              "mcc_error", "mcc_correct", "mcc_backward",
+              "sse_error", "sse_backward", "post_error", "post_backward", "binary_correct"]
 
 
 class _RefLib:
     """oracle/_ref/libcurrennt_ref.so behind the oracle's function names: orc_X -> ref_X for the functions the reference's
-    own object code covers, the oracle's C restatement for the rest (weight counts, SGD update, other post output layers)."""
+    own object code covers, the oracle's C restatement for the rest (weight counts, SGD update)."""
 
     def __init__(self, ref, orc):
         self._ref, self._orc = ref, orc

@@ -85,10 +85,11 @@ def load_ref_golden(name):
         parts = k[len(pre):].split("/")
         if parts[0] == "w":
             weights.setdefault(parts[1], {})[parts[2]] = z[k]
-        elif parts[0] not in ("layers_json", "PS", "seqLengths", "inputs", "targetClasses"):
+        elif parts[0] not in ("layers_json", "PS", "seqLengths", "inputs", "targetClasses", "targets"):
             exp["/".join(parts)] = z[k]
     lens = z[pre + "seqLengths"]
     off = np.concatenate([[0], np.cumsum(lens)])
     xs = [z[pre + "inputs"][off[i]:off[i + 1]] for i in range(len(lens))]
-    ts = [z[pre + "targetClasses"][off[i]:off[i + 1]] for i in range(len(lens))]
+    tkey = pre + ("targetClasses" if pre + "targetClasses" in z.files else "targets")      # real-valued targets: sse case
+    ts = [z[tkey][off[i]:off[i + 1]] for i in range(len(lens))]
     return layers, weights, xs, ts, int(z[pre + "PS"]), exp

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 POSTERIOR_TOL = 1e-4      # BASELINE.json north_star
 
 
-def run_both(pkg, orc, layers, weights, frac, PS, precision=0, lr=None):
-    ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+def run_both(pkg, orc, layers, weights, frac, PS, precision=0, lr=None, backend="oracle"):
+    ref = orc.OracleNetwork(layers, weights, PS, frac["T"], backend=backend)
     ref.load_sequences(frac)
     ref.compute_forward_pass()
     e_ref = ref.calculate_error()
@@ -30,8 +30,8 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
 
 
-def check_network(pkg, orc, layers, weights, frac, PS, grad_tol=2e-4, precision=0):
-    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision)
+def check_network(pkg, orc, layers, weights, frac, PS, grad_tol=2e-4, precision=0, backend="oracle"):
+    ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision, backend=backend)
     try:
         real = real_mask(frac)
         C = layers[-1]["size"]

@@ -139,3 +139,47 @@ def test_feedforward_layers_bit_equal(orc, ref, pkg, act):
     b, rb = run(orc, "ref", layers, weights, frac, PS)
     assert ra == rb
     assert_networks_bit_equal(a, b, a.N)
+
+
+def post_case(pkg, post, out_type, seed=31):
+    """A small net ending in the given post output layer, with ragged sequences and an unused parallel slot."""
+    rng = np.random.RandomState(seed)
+    P, PS = 5, 4
+    L = 1 if post == "binary_classification" else 6
+    W = 2 * L if post in ("weightedsse", "wf") else L
+    layers = [{"name": "input", "type": "input", "size": P},
+              {"name": "lstm_0", "type": "blstm", "size": 12, "bias": 1.0},
+              {"name": "output", "type": out_type, "size": L, "bias": 1.0},
+              {"name": "postoutput", "type": post, "size": W}]
+    weights = random_weights(layers, rng, 0.5)
+    lengths = [11, 7, 9]
+    xs = [rng.randn(n, P).astype(np.float32) for n in lengths]
+    if post == "binary_classification":
+        ts = [rng.randint(0, 2, n).astype(np.int32) for n in lengths]
+        return layers, weights, pkg.make_fraction(xs, ts, PS, classification=True), PS
+    if post == "ce":            # a target distribution with exact zeros (max(FLT_MIN, t)) ...
+        ts = []
+        for n in lengths:
+            t = rng.rand(n, L).astype(np.float32); t[:, 0] = 0; ts.append(t / t.sum(1, keepdims=True))
+        weights["output"]["bias"] = np.array([0, -100, 0, 0, 0, 5], np.float32)    # ... and posteriors that underflow to 0 (the +-100 clip)
+    else:
+        ts = [rng.randn(n, W).astype(np.float32) for n in lengths]
+    return layers, weights, pkg.make_fraction(xs, ts, PS, classification=False), PS
+
+
+@pytest.mark.parametrize("post,out_type", [("sse", "feedforward_identity"), ("weightedsse", "feedforward_identity"),
+                                           ("wf", "feedforward_tanh"), ("ce", "softmax"), ("rmse", "feedforward_identity"),
+                                           ("binary_classification", "feedforward_logistic")])
+def test_post_output_layers_bit_equal(orc, ref, pkg, post, out_type):
+    """calculateError / countCorrectClassifications / computeBackwardPass of SsePostOutputLayer.cu:39-155, WeightedSse...:40-167,
+    SseMask...:40-167, CePostOutputLayer.cu:43-170, RmsePostOutputLayer.cu:40-174, BinaryClassificationLayer.cu:44-207:
+    the oracle's restatement against the reference's own functors and thrust calls (oracle/ref/ref_post.cpp), and everything
+    the injected errors flow into below (output layer and LSTM gradients)."""
+    layers, weights, frac, PS = post_case(pkg, post, out_type)
+    a, ra = run(orc, "oracle", layers, weights, frac, PS, steps=2, lr=1e-5)
+    b, rb = run(orc, "ref", layers, weights, frac, PS, steps=2, lr=1e-5)
+    assert ra == rb and np.all(np.isfinite([e for e, _ in ra]))
+    if post == "binary_classification":
+        assert a.count_correct_classifications() == b.count_correct_classifications() > 0
+    assert_networks_bit_equal(a, b, a.N)
+    assert np.any(a.layers[-2].outputErrors != 0)
