@@ -260,8 +260,9 @@ int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, in
 int  cn_ctx_timing_enable(cn_ctx *ctx, int enable);
 int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches); /* [sync] */
 int  cn_ctx_timing_reset(cn_ctx *ctx);
-/* name of the recurrent kernel a layer's forward (backward != 0: backward) pass launches for the loaded fraction
- * shape, e.g. "lstm_bwd_kernel<bf16,Hp=128,rpl=1>" or "lstm_bwd_cluster_kernel<Hp=256,2 CUs>"; "" for other layers */
+/* name of the recurrent kernel the layer's last forward (backward != 0: backward) pass launched, recorded by the launcher
+ * that instantiated it, e.g. "lstm_bwd_s2_kernel<0,128>", "lstm_fwd_kernel<2,128,1,1>" or
+ * "lstm_bwd_cluster_kernel<0,256,128,1>"; "" for other layers and before the first pass */
 const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward);
 
 #ifdef __cplusplus

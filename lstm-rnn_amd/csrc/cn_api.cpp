@@ -170,6 +170,8 @@ struct cn_layer {
     hipEvent_t ev_pack = nullptr;         // operand copies rebuilt on the side stream after cn_sgd_update_all
     bool pack_pending = false;
 
+    char kname[2][CN_KNAME_LEN] = {{0}, {0}};   // recurrent kernels the last forward / backward pass launched (written by the launchers)
+
     std::vector<void *> owned;            // device allocations to free
 
     size_t maxN() const { return (size_t)PSp * maxT; }
@@ -469,6 +471,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.bias = l->bias;
     r.rpl = c->rpl;
     r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = c->num_cus;
+    r.kname = nullptr;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
     if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }
     r.xch_epoch = c->xch_epoch;
@@ -501,7 +504,7 @@ void lstm_forward(cn_layer *l)
     }
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
-        LstmRec r; lstm_rec_args(l, r);
+        LstmRec r; lstm_rec_args(l, r); r.kname = l->kname[0];
         if (!launch_lstm_cluster(c->stream, c->prec, false, r, &c->xch_epoch)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->prec, r); }
         HIP_CHECK(hipGetLastError());
     }
@@ -517,7 +520,7 @@ void lstm_backward(cn_layer *l)
     // (the packed gradient accumulators are zero here: allocation clears them, the unpack kernel re-clears them)
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
-        LstmRec r; lstm_rec_args(l, r);
+        LstmRec r; lstm_rec_args(l, r); r.kname = l->kname[1];
         if (!launch_lstm_cluster(c->stream, c->prec, true, r, &c->xch_epoch)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
@@ -1612,21 +1615,9 @@ int cn_ctx_timing_reset(cn_ctx *ctx)
 
 const char *cn_layer_recurrent_kernel(cn_layer *layer, int backward)
 {
-    static thread_local std::string name;
-    name.clear();
-    if (!layer || !layer->lstm) return name.c_str();
-    cn_ctx *c = layer->ctx;
-    const char *dirn = backward ? "bwd" : "fwd";
-    const int cs = lstm_cluster_size(c->prec, layer->Hp, layer->dirs, c->PSp, c->rpl, c->num_cus);
-    char buf[160];
-    if (c->d_xch && cs > 0)
-        snprintf(buf, sizeof(buf), "lstm_%s_cluster_kernel<%d,%d,%d,%d>", dirn, c->prec, layer->Hp, layer->Hp / cs, c->rpl);
-    else {
-        const bool resident = lstm_rec_resident(c->prec, layer->Hp);
-        snprintf(buf, sizeof(buf), "lstm_%s_kernel<%d,%d,1,%d>", dirn, c->prec, resident ? layer->Hp : 0, c->rpl);
-    }
-    name = buf;
-    return name.c_str();
+    // what the launchers instantiated on the layer's last forward / backward pass (empty before the first one)
+    if (!layer || !layer->lstm) return "";
+    return layer->kname[backward ? 1 : 0];
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -91,10 +91,16 @@ struct LstmRec {
     unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T (launch_lstm_cluster sets it and advances the counter)
     int *fault;                   // set to 1 by a bounded spin that gave up
     int num_cus;                  // CUs of the device: a cluster grid must be resident as a whole
+    char *kname;                  // nullable, CN_KNAME_LEN bytes: the launcher writes the name of the kernel it instantiated
 };
+constexpr int CN_KNAME_LEN = 64;
 size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T);        // dynamic LDS per workgroup of the single-CU kernels
 bool lstm_rec_resident(int prec, int Hp);                                      // W_rec fragments register resident (single-CU kernels)
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p);
+// "s2" shape (cn_lstm_s2.hip): two sequences per workgroup, one wave per SIMD, 32 units per wave; launch_lstm_forward /
+// launch_lstm_backward dispatch to it when it applies
+bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd);
+void launch_lstm_s2(hipStream_t s, int prec, bool bwd, const LstmRec &p, hipEvent_t done = nullptr);
 void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
 // `num_cus`: the CU count of the device; the spin-wait hand-off needs every member workgroup resident, so a grid larger

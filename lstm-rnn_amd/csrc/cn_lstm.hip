@@ -36,6 +36,7 @@
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 #ifndef CN_KQ_STACK
@@ -908,6 +909,7 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t d
     size_t lds_claim = lds;
     if (p.dirs * nsg <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UG, RPL);
 }
 
 template <int PREC, bool BWD, int HP, int UG>
@@ -974,12 +976,14 @@ size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T)
 
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p)
 {
+    if (lstm_s2_applies(prec, p, false)) { launch_lstm_s2(s, prec, false, p); return; }
     if (prec == P_F32) launch_rec<P_F32, false>(s, p);
     else if (prec == P_X3) launch_rec<P_X3, false>(s, p);
     else launch_rec<P_BF16, false>(s, p);
 }
 void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t done)
 {
+    if (lstm_s2_applies(prec, p, true)) { launch_lstm_s2(s, prec, true, p, done); return; }
     if (prec == P_F32) launch_rec<P_F32, true>(s, p, done);
     else if (prec == P_X3) launch_rec<P_X3, true>(s, p, done);
     else launch_rec<P_BF16, true>(s, p, done);

@@ -25,6 +25,8 @@
 #include "cn_internal.h"
 #include "cn_lstm_device.h"
 
+#include <cstdio>
+
 #ifndef CN_KQ_STACK
 #define CN_KQ_STACK 1
 #endif
@@ -649,6 +651,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_cluster_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UPC, RPL);
 }
 
 // cluster shapes: Hp = 256 -> 2 CUs x 128 units (8 waves each), Hp = 512 -> 8 CUs x 64 units (4 waves each; the slice of

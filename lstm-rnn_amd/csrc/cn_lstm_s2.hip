@@ -1,0 +1,444 @@
+// Persistent recurrent LSTM kernels, "s2" shape: TWO sequences per workgroup, one wave per SIMD.
+//
+// Same reference functions as cn_lstm.hip (LstmLayer.cu:812-829 / :847-864 forward with ComputeBlockOutputFn :47-138,
+// :936-951 / :970-985 backward with ComputeBlockErrorsFn :190-287, the Resort functors :140-188 and the bias / peephole
+// parts of ComputeWeightUpdateFn :289-512), same buffers, same arithmetic (row-pair sparse MFMAs of cn_lstm_device.h,
+// P_BF16 and P_X3) -- a different cut of the work over the chip.
+//
+// Why.  The step of the 4-sequences-per-workgroup kernels (cn_lstm.hip) is bound by vector-instruction issue, not by the
+// MFMA pipe and not by memory: 8 waves x (43 VALU + 10 transcendental + 8 MFMA issues) = 2 waves per SIMD x ~316 issue
+// cycles = ~630 of the ~1080 cycles of a forward step, the rest is the LDS hand-off, and at PS = 50 the grid is 26
+// workgroups on a 256-CU chip.  Halving the sequences per workgroup halves the cell updates per CU and doubles the CUs
+// in use -- but only if every lane of every wave still owns a (unit, sequence) pair, because instruction issue is per
+// wave, not per lane.  So a wave owns 32 units (two 16-column MFMA tiles, "unit groups" 0 and 1) x 2 sequences:
+//   lane (c = lane & 15, q = lane >> 4)  ->  unit 32*wave + 16*(q >> 1) + c,  sequence s0 + (q & 1).
+// The 16x16 MFMA hands row 4*q' + r of the output tile to lane quarter q', so group 0's sums must come out in tile rows
+// 0..7 and group 1's in rows 8..15.  Both groups accumulate into the SAME accumulators: group 0's product reads the
+// operand tile through a view whose rows 8..15 are a row of zeros, group 1's through the mirrored view (rows 0..7 zero),
+// so each adds exactly nothing to the other's lanes.  The views are per-lane LDS addresses (a lane of the A operand IS a
+// tile row): the tile itself holds only the 4 (forward) / 8 (backward) data rows of the two sequences plus one zero row.
+// Cost: 16 instead of 8 sparse MFMAs per wave and step on half as many waves -- the MFMA pipe of a SIMD is busy for the
+// same 256 cycles per step as before, while its VALU issue drops from two waves' cell updates to one.
+//
+// Everything else follows cn_lstm.hip: W_rec fragments register resident for the whole pass (128 VGPRs per lane at
+// Hp = 128; 256 with the hi/lo fragments of P_X3), y[t] / deltas handed over through a double-buffered LDS tile, operands
+// prefetched two steps ahead through staged registers, LDS-only barrier, fw/bw halves written in place.
+#include "cn_internal.h"
+#include "cn_lstm_device.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace cn {
+
+#define KEEP_TUPLE(tuple, after) asm volatile("" :: "v"(tuple), "v"(after))
+
+template <typename T> __device__ __forceinline__ T &at32(const void *base, unsigned elem)
+{
+    return *(T *)((char *)base + elem * (unsigned)sizeof(T));
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int PREC, int HP>
+__global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(PREC != P_F32 && HP % 64 == 0, "row-pair products: bf16 operands, whole 64-value K chunks");
+    constexpr bool X3 = PREC == P_X3;
+    constexpr int MELT = X3 ? 4 : 2;                 // operand element in memory (y, W_rec)
+    constexpr int PLANES = X3 ? 2 : 1;               // LDS planes of the y tile (hi, lo)
+    constexpr int KCS = HP / 64;                     // 64-value K chunks
+    constexpr int pitch = lds_pitch(HP);             // a tile row holds half of the K values of a sequence (bf16)
+    constexpr int DROWS = 5;                         // rows (2*seq + parity) of the two sequences + one row of zeros
+    constexpr int plane = DROWS * pitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;               // this lane's unit group and sequence
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    // W_rec fragments of both unit groups: B lane (col = c, k slice = q) of gate g, chunk kc
+    u32x8 wsp[2][4][KCS];
+    [[maybe_unused]] u32x8 wsl[X3 ? 2 : 1][4][KCS];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * MELT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc) {
+                const long w0 = (long)(g * HP + 32 * wave + 16 * j + c) * HP + kc * 64 + q * 16;
+                if constexpr (X3) sp_load_split((const float *)Wd + w0, wsp[j][g][kc], wsl[j][g][kc]);
+                else wsp[j][g][kc] = sp_load_bf16(Wd + w0 * 2);
+            }
+    const int spidx = sp_index(c);
+    // the two views of the tile: as A-operand lane, c is the tile row and q the k slice
+    const int vrow0 = (c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4;          // rows 0,1,4,5 = (seq 0, seq 1) x (even, odd)
+    const int vrow1 = (c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4;    // rows 8,9,12,13
+    const int av0 = vrow0 * pitch + q * 16, av1 = vrow1 * pitch + q * 16;
+
+    const int unit = 32 * wave + 16 * ug + c;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const unsigned oA = sv * (int)arow + (d * HP + unit) * 4;
+    const unsigned oC = sv * (int)crow + d * HP + unit;
+    const unsigned oP = sv;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const int k = unit & 63;
+    const int oT = (2 * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;
+
+    float cst = 0.f;
+    f32x4 preA, preB;
+    int ptA, ptB;
+    auto prefetch = [&](int t, f32x4 &pre, int &pt) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        pt = (int)at32<unsigned char>(p.pat + (long)t * PS, oP);
+        pre = *(const f32x4 *)&at32<float>(p.acts + t * stepA, oA);
+    };
+
+    // accumulators live across steps (the sparse MFMA accumulates in place): register 0 = even tile row, seeded with the
+    // staged pre-activation; register 1 = odd row, cleared; registers 2, 3 belong to zero rows in both views and stay 0
+    f32x4 accp[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) accp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto step = [&](int it, f32x4 &pre, int &pt) {
+        const int t = d ? T - 1 - it : it;
+        const char *ycur = smem + (it & 1) * PLANES * plane;
+        char *ynxt = smem + ((it + 1) & 1) * PLANES * plane;
+        const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
+        float *actsT = p.acts + t * stepA;
+        float *cellT = p.cell + t * stepC;
+        float *thT = p.th + t * stepC;
+        char *yT = (char *)p.y_op + t * stepC * MELT;
+
+        int ptc;
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(ptc) : "v"(pt));
+        const bool dummy = check && ptc == 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v_;
+            asm volatile("v_mov_b32 %0, %1" : "=&v"(v_) : "v"(pre[g]));
+            accp[g][0] = v_; accp[g][1] = 0.f;
+        }
+        prefetch(d ? t - 2 : t + 2, pre, pt);
+
+        // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates of both unit groups
+        u32x4 a0[KCS], a1[KCS];
+        [[maybe_unused]] u32x4 l0[X3 ? KCS : 1], l1[X3 ? KCS : 1];
+#pragma unroll
+        for (int kc = 0; kc < KCS; ++kc) {
+            a0[kc] = *(const u32x4 *)(ycur + av0 + kc * 64);
+            a1[kc] = *(const u32x4 *)(ycur + av1 + kc * 64);
+            if constexpr (X3) {
+                l0[kc] = *(const u32x4 *)(ycur + plane + av0 + kc * 64);
+                l1[kc] = *(const u32x4 *)(ycur + plane + av1 + kc * 64);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc) {
+                if constexpr (X3) {
+                    smma16_x3(accp[g], a0[kc], l0[kc], wsp[0][g][kc], wsl[0][g][kc], spidx);
+                    smma16_x3(accp[g], a1[kc], l1[kc], wsp[1][g][kc], wsl[1][g][kc], spidx);
+                } else {
+                    smma16(accp[g], a0[kc], wsp[0][g][kc], spidx);
+                    smma16(accp[g], a1[kc], wsp[1][g][kc], spidx);
+                }
+            }
+
+        // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
+        float s_[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { s_[g] = accp[g][0] + accp[g][1]; KEEP_TUPLE(accp[g], s_[g]); }
+        const float cp = cst;
+        const float ni = tanh_ref<false>(s_[0]);
+        const float ig = logistic<false>(s_[1] + cp * pi);
+        const float fg = logistic<false>(s_[2] + cp * pf);
+        const float cs = ni * ig + cp * fg;
+        const float og = logistic<false>(s_[3] + cs * po);
+        const float th = tanh_ref<false>(cs);
+        const float y = th * og;
+        const float yo = dummy ? 0.f : y;
+        const float co = dummy ? 0.f : cs;            // :78-85 (zeroed in both directions here)
+        cst = co;
+        if constexpr (X3) {
+            __bf16 yh, yl;
+            split_bf16(yo, yh, yl);
+            *(__bf16 *)(ynxt + oT) = yh;
+            *(__bf16 *)(ynxt + plane + oT) = yl;
+        } else *(__bf16 *)(ynxt + oT) = (__bf16)yo;
+        const f32x4 av = {ni, ig, fg, og};           // (dummy slots: never read back)
+        *(f32x4 *)&at32<float>(actsT, oA) = av;
+        at32<float>(cellT, oC) = co;
+        at32<float>(thT, oC) = th;
+        if constexpr (MELT == 4) at32<float>(yT, oC) = yo;
+        else at32<__bf16>(yT, oC) = (__bf16)yo;
+        lds_barrier();
+    };
+
+    prefetch(d ? T - 1 : 0, preA, ptA);
+    prefetch(d ? T - 2 : 1, preB, ptB);
+    lds_barrier();
+    // branch-free pairs of steps, first pair peeled (see cn_lstm.hip)
+    if (T >= 2) {
+        step(0, preA, ptA);
+        step(1, preB, ptB);
+        int it = 2;
+        for (; it + 1 < T; it += 2) {
+            step(it, preA, ptA);
+            step(it + 1, preB, ptB);
+        }
+        if (it < T) step(it, preA, ptA);
+    } else {
+        step(0, preA, ptA);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+struct BwdStage {
+    f32x4 a;        // n, i, f, o of step t
+    float e;        // outputErrors of step t
+    float cp;       // cell state of prev(t)
+    float th;       // tanh(cell state) of step t
+};
+
+template <int PREC, int HP>
+__global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(PREC != P_F32 && HP % 32 == 0, "row-pair products: bf16 operands");
+    constexpr bool X3 = PREC == P_X3;
+    constexpr int MELT = X3 ? 4 : 2;                 // operand element in memory (delta, W_rec^T)
+    constexpr int PLANES = X3 ? 2 : 1;
+    // K = 4*HP with k = 4*unit + gate.  A sequence takes four tile rows: (K half, parity); the product of K half h uses
+    // accumulator h and is read from the rows of that half (cn_lstm.hip "KHS"): e = accA[0] + accA[1] + accB[2] + accB[3]
+    constexpr int KCS = 4 * HP / 64, KCH = KCS / 2;
+    constexpr int pitch = lds_pitch(KCH * 64);
+    constexpr int DROWS = 9;                         // rows 4*seq + 2*half + parity, + one row of zeros
+    constexpr int plane = DROWS * pitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    // dummy-slot table: dtab[t][s] = (t >= Tmin && patTypes[t][s0 + s] == NONE) (LstmLayer.cu:224-234 with :949,983)
+    unsigned char *dtab = (unsigned char *)smem + 2 * PLANES * plane;
+    for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {
+        const int tt = i >> 1;
+        dtab[i] = tt >= p.Tmin && p.pat[(long)tt * PS + s0 + (i & 1)] == 0;
+    }
+
+    u32x8 wsp[2][KCS];
+    [[maybe_unused]] u32x8 wsl[X3 ? 2 : 1][KCS];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * MELT;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kc = 0; kc < KCS; ++kc) {
+            const long w0 = (long)(32 * wave + 16 * j + c) * 4 * HP + kc * 64 + q * 16;
+            if constexpr (X3) sp_load_split((const float *)Wd + w0, wsp[j][kc], wsl[j][kc]);
+            else wsp[j][kc] = sp_load_bf16(Wd + w0 * 2);
+        }
+    const int spidx = sp_index(c);
+    const int av0 = (c < 8 ? c : 8) * pitch + q * 16, av1 = (c >= 8 ? c - 8 : 8) * pitch + q * 16;
+
+    const int unit = 32 * wave + 16 * ug + c;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const unsigned oA = (unsigned)(sv * (int)arow + (d * HP + unit) * 4);
+    const unsigned oC = (unsigned)(sv * (int)crow + d * HP + unit);
+    const unsigned stepA = (unsigned)PS * (unsigned)arow, stepC = (unsigned)PS * (unsigned)crow;
+    const int uh = unit % (HP / 2), half = unit / (HP / 2);
+    const int oT = (4 * sq + 2 * half) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2;
+
+    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, ccur;
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
+
+    const int tfirst = d ? 0 : T - 1;
+    BwdStage preA, preB;
+    auto prefetch = [&](int t, BwdStage &pre) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const int tprev = d ? t + 1 : t - 1;
+        const bool hasprev = tprev >= 0 && tprev < T;
+        const unsigned bA = (unsigned)t * stepA, bC = (unsigned)t * stepC;
+        const unsigned bCp = (unsigned)(hasprev ? tprev : t) * stepC;
+        pre.e = at32<float>(p.err, bC + oC);
+        pre.a = *(const f32x4 *)&at32<float>(p.acts, bA + oA);
+        pre.cp = at32<float>(p.cell, bCp + oC);
+        pre.th = at32<float>(p.th, bC + oC);
+    };
+
+    auto step = [&](int it, BwdStage &pre) {
+        const int t = d ? it : T - 1 - it;
+        const char *dcur = smem + (it & 1) * PLANES * plane;
+        char *dnxt = smem + ((it + 1) & 1) * PLANES * plane;
+        const int tprev_ = d ? t + 1 : t - 1;
+        const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
+        const unsigned bD = (unsigned)t * stepA;
+
+        const unsigned char dmy = dtab[2 * t + sq];
+        float e_, c_, th_;
+        f32x4 a_;
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(e_) : "v"(pre.e));
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(c_) : "v"(pre.cp));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(a_[g]) : "v"(pre.a[g]));
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(th_) : "v"(pre.th));
+        const float cp = hasprev_ ? c_ : 0.f;
+        prefetch(d ? t + 2 : t - 2, pre);
+
+        // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*HP
+        u32x4 a0[KCH], a1[KCH];
+        [[maybe_unused]] u32x4 l0[X3 ? KCH : 1], l1[X3 ? KCH : 1];
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            a0[kc] = *(const u32x4 *)(dcur + av0 + kc * 64);
+            a1[kc] = *(const u32x4 *)(dcur + av1 + kc * 64);
+            if constexpr (X3) {
+                l0[kc] = *(const u32x4 *)(dcur + plane + av0 + kc * 64);
+                l1[kc] = *(const u32x4 *)(dcur + plane + av1 + kc * 64);
+            }
+        }
+        f32x4 accA = {e_, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};      // err enters as the C operand
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            if constexpr (X3) {
+                smma16_x3(accA, a0[kc], l0[kc], wsp[0][kc], wsl[0][kc], spidx);
+                smma16_x3(accB, a0[kc], l0[kc], wsp[0][KCH + kc], wsl[0][KCH + kc], spidx);
+                smma16_x3(accA, a1[kc], l1[kc], wsp[1][kc], wsl[1][kc], spidx);
+                smma16_x3(accB, a1[kc], l1[kc], wsp[1][KCH + kc], wsl[1][KCH + kc], spidx);
+            } else {
+                smma16(accA, a0[kc], wsp[0][kc], spidx);
+                smma16(accB, a0[kc], wsp[0][KCH + kc], spidx);
+                smma16(accA, a1[kc], wsp[1][kc], spidx);
+                smma16(accB, a1[kc], wsp[1][KCH + kc], spidx);
+            }
+        }
+        const float e = (accA[0] + accA[1]) + (accB[2] + accB[3]);
+        KEEP_TUPLE(accA, e); KEEP_TUPLE(accB, e);
+
+        // ComputeBlockErrorsFn, LstmLayer.cu:236-285
+        const bool dummy = dmy != 0;
+        const float ni = a_[0], ig = a_[1], fg = a_[2], og = a_[3];
+        const float cs = ccur, th = th_;
+        float dog = og * (1.0f - og) * th * e;
+        float ec = og * (1.0f - th * th) * e + po * dog;
+        ec += fgn * ecn + pi * dign + pf * dfgn;     // zero carry at firstCall
+        float dni = ig * (1.0f - ni * ni) * ec;
+        float dfg = fg * (1.0f - fg) * cp * ec;      // cp = 0 at lastCall
+        float dig = ig * (1.0f - ig) * ni * ec;
+        dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
+        dni = dummy ? 0.f : dni; dig = dummy ? 0.f : dig; dfg = dummy ? 0.f : dfg; dog = dummy ? 0.f : dog;   // :224-234
+        ec = dummy ? 0.f : ec;
+        fgn = dummy ? 0.f : fg;
+        ecn = ec; dign = dig; dfgn = dfg;
+        ccur = cp;
+        // gradient sums (ComputeWeightUpdateFn bias / peephole cases, :392-408, :440-475)
+        sb[0] += dni; sb[1] += dig; sb[2] += dfg; sb[3] += dog;
+        spi += cp * dig; spf += cp * dfg; spo += cs * dog;
+        if constexpr (X3) {
+            const f32x4 dv = {dni, dig, dfg, dog};
+            bf16x4 dh, dl;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(dv[g], h_, l_); dh[g] = h_; dl[g] = l_; }
+            *(bf16x2 *)(dnxt + oT) = bf16x2{dh[0], dh[1]};
+            *(bf16x2 *)(dnxt + oT + pitch) = bf16x2{dh[2], dh[3]};
+            *(bf16x2 *)(dnxt + plane + oT) = bf16x2{dl[0], dl[1]};
+            *(bf16x2 *)(dnxt + plane + oT + pitch) = bf16x2{dl[2], dl[3]};
+            *(f32x4 *)&at32<float>(p.delta_op, bD + oA) = dv;
+        } else {
+            const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+            *(bf16x2 *)(dnxt + oT) = bf16x2{dv[0], dv[1]};
+            *(bf16x2 *)(dnxt + oT + pitch) = bf16x2{dv[2], dv[3]};
+            *(bf16x4 *)&at32<__bf16>(p.delta_op, bD + oA) = dv;
+        }
+        lds_barrier();
+    };
+
+    ccur = at32<float>(p.cell, (unsigned)tfirst * stepC + oC);
+    prefetch(tfirst, preA);
+    prefetch(d ? 1 : T - 2, preB);
+    lds_barrier();
+    if (T >= 2) {
+        step(0, preA);
+        step(1, preB);
+        int it = 2;
+        for (; it + 1 < T; it += 2) {
+            step(it, preA);
+            step(it + 1, preB);
+        }
+        if (it < T) step(it, preA);
+    } else {
+        step(0, preA);
+    }
+
+    // fold the two sequences of each unit column, then one atomic per (gate, unit) and workgroup
+    float v[7] = {sb[0], sb[1], sb[2], sb[3], spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
+    if (sq == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------
+static size_t s2_lds_bytes(int prec, bool bwd, int Hp, int T)
+{
+    const int PLANES = prec == P_X3 ? 2 : 1;
+    const size_t pitch = (size_t)lds_pitch(bwd ? 2 * Hp : Hp);      // bwd: KCH * 64 = (4*Hp/64/2) * 64
+    return 2 * (size_t)PLANES * (bwd ? 9 : 5) * pitch + (bwd ? (((size_t)T * 2 + 15) & ~(size_t)15) : 0);
+}
+
+// The shape applies when the layer is one the row-pair products cover (bf16 / split-bf16, Hp = 64 or 128), the caller
+// chose one sequence per lane (PS * dirs / 4 workgroups fit the chip: rpl == 1), and twice that grid still leaves every
+// workgroup a CU of its own.
+bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
+{
+    if (getenv("CN_NO_S2") || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
+    if (p.dirs * (p.PS / 2) > p.num_cus) return false;
+    return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;
+}
+
+template <int PREC, bool BWD, int HP>
+static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
+{
+    auto kern = BWD ? lstm_bwd_s2_kernel<PREC, HP> : lstm_fwd_s2_kernel<PREC, HP>;
+    static DeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
+    // claim the CU's whole LDS so that no workgroup of a concurrently running kernel is placed beside it (cn_lstm.hip)
+    size_t lds_claim = lds;
+    if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    hipExtLaunchKernelGGL(kern, dim3(p.dirs * (p.PS / 2)), dim3(HP * 2), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2_kernel<%d,%d>", BWD ? "bwd" : "fwd", PREC, HP);
+}
+
+void launch_lstm_s2(hipStream_t s, int prec, bool bwd, const LstmRec &p, hipEvent_t done)
+{
+    if (prec == P_X3) {
+        if (p.Hp == 128) { if (bwd) launch_s2<P_X3, true, 128>(s, p, done); else launch_s2<P_X3, false, 128>(s, p, done); }
+        else             { if (bwd) launch_s2<P_X3, true, 64>(s, p, done);  else launch_s2<P_X3, false, 64>(s, p, done); }
+    } else {
+        if (p.Hp == 128) { if (bwd) launch_s2<P_BF16, true, 128>(s, p, done); else launch_s2<P_BF16, false, 128>(s, p, done); }
+        else             { if (bwd) launch_s2<P_BF16, true, 64>(s, p, done);  else launch_s2<P_BF16, false, 64>(s, p, done); }
+    }
+}
+
+}  // namespace cn

@@ -42,8 +42,8 @@ def test_config0_literal_lstm128_softmax183(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
-def test_config1_headline_net_against_the_live_reference_library(pkg, orc, mode):
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_s4"])
+def test_config1_headline_net_against_the_live_reference_library(pkg, orc, monkeypatch, mode):
     """BASELINE configs[1] as benchmarked -- 39 -> 3 x blstm250 -> softmax183, PS = 50 (one sequence per lane, 26 workgroups
     of the Hp = 128 register-resident kernels) -- against oracle/_ref, the REFERENCE's own compiled functors and Cpu GEMM
     (oracle/ref/ref_common.h), run live on this box: no restatement between the HIP path and the reference's arithmetic.
@@ -57,11 +57,14 @@ def test_config1_headline_net_against_the_live_reference_library(pkg, orc, mode)
     weights = random_weights(layers, rng, 0.1)
     xs, ts = random_sequences(rng, sorted(rng.randint(14, 25, PS - 2).tolist(), reverse=True), P, C=C)     # two unused slots
     frac = pkg.make_fraction(xs, ts, PS)
+    if mode == "bf16x3_s4":
+        monkeypatch.setenv("CN_NO_S2", "1")
     ref, net = check_network(pkg, orc, layers, weights, frac, PS, backend="ref",
                              precision=pkg.PREC_F32 if mode == "f32" else pkg.PREC_BF16X3)
     with net:
-        assert net.recurrent_kernel(False).startswith("lstm_fwd_kernel<") and net.recurrent_kernel(False).endswith(",128,1,1>")
-        assert net.recurrent_kernel(True).startswith("lstm_bwd_kernel<") and net.recurrent_kernel(True).endswith(",128,1,1>")
+        # f32: 4 sequences per workgroup, exact-fp32 MFMAs; bf16x3: the two-sequences-per-workgroup cut (cn_lstm_s2.hip)
+        want = {"f32": "lstm_%s_kernel<1,128,1,1>", "bf16x3": "lstm_%s_s2_kernel<2,128>", "bf16x3_s4": "lstm_%s_kernel<2,128,1,1>"}[mode]
+        assert net.recurrent_kernel(False) == want % "fwd" and net.recurrent_kernel(True) == want % "bwd"
 
 
 CHIME_LAYERS = [("blstm", 156), ("blstm", 300), ("blstm", 102)]

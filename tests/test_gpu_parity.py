@@ -358,15 +358,19 @@ def test_cluster_kernel_matches_streaming_kernel(pkg, orc, size, scale):
 
 
 @pytest.mark.parametrize("T", [1, 3, 8])
-@pytest.mark.parametrize("rpl", [1, 2])
+@pytest.mark.parametrize("shape", ["s2", "rpl1", "rpl2"])
 @pytest.mark.parametrize("kind,size", [("blstm", 128), ("lstm", 125), ("blstm", 250)])
-def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, rpl, T):
-    """The 2:4 row-pair MFMA path of the register-resident kernels (bf16 and split-bf16 modes, at most two sequences per
-    lane, Hp = 64 / 128): one and two sequences per lane (CN_RPL), loop shapes T = 1, 3, 8, ragged lengths, a partly filled
-    last sequence group, one- and two-directional.  Checked in the split-bf16 mode at the fp32 tolerances, which a misplaced
-    operand element cannot meet."""
+def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, shape, T):
+    """The 2:4 row-pair MFMA path of the register-resident kernels (bf16 and split-bf16 modes, Hp = 64 / 128) in its three
+    cuts: "s2" = two sequences per workgroup, 32 units per wave (cn_lstm_s2.hip; what a grid that fits the chip gets), and
+    the 4- and 8-sequence workgroups of cn_lstm.hip with one and two sequences per lane (CN_RPL; CN_NO_S2 keeps the s2 cut
+    away).  Loop shapes T = 1, 3, 8, ragged lengths, a partly filled last sequence group, one- and two-directional.
+    Checked in the split-bf16 mode at the fp32 tolerances, which a misplaced operand element cannot meet."""
+    rpl = 2 if shape == "rpl2" else 1
     monkeypatch.setenv("CN_RPL", str(rpl))
-    rng = np.random.RandomState(300 + T + rpl + size)
+    if shape == "rpl1":
+        monkeypatch.setenv("CN_NO_S2", "1")
+    rng = np.random.RandomState(300 + T + rpl + size)          # (same data for "s2" and "rpl1")
     P, C, PS = 6, 4, 13
     layers = net_desc(P, [(kind, size)], C)
     weights = random_weights(layers, rng, 0.15)
@@ -376,8 +380,12 @@ def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, rpl, T):
     ref, net = check_network(pkg, orc, layers, weights, frac, PS, precision=pkg.PREC_BF16X3)
     with net:
         Hp = 64 if size == 128 else 128
-        assert net.recurrent_kernel(False) == "lstm_fwd_kernel<2,%d,1,%d>" % (Hp, rpl)
-        assert net.recurrent_kernel(True) == "lstm_bwd_kernel<2,%d,1,%d>" % (Hp, rpl)
+        if shape == "s2":
+            assert net.recurrent_kernel(False) == "lstm_fwd_s2_kernel<2,%d>" % Hp
+            assert net.recurrent_kernel(True) == "lstm_bwd_s2_kernel<2,%d>" % Hp
+        else:
+            assert net.recurrent_kernel(False) == "lstm_fwd_kernel<2,%d,1,%d>" % (Hp, rpl)
+            assert net.recurrent_kernel(True) == "lstm_bwd_kernel<2,%d,1,%d>" % (Hp, rpl)
 
 
 @pytest.mark.parametrize("size,rpl,kernel", [(384, 1, "lstm_fwd_kernel<0,192,1,1>"), (384, 2, "lstm_fwd_kernel<0,192,1,2>"),
