@@ -161,7 +161,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
         const float ni = tanh_ref<false>(s_[0]);
         const float ig = logistic<false>(s_[1] + cp * pi);
         const float fg = logistic<false>(s_[2] + cp * pf);
-        const float cs = ni * ig + cp * fg;
+        const float cs = __builtin_fmaf(ni, ig, cp * fg);     // (written out: the hand-written loop below rounds the same way)
         const float og = logistic<false>(s_[3] + cs * po);
         const float th = tanh_ref<false>(cs);
         const float y = th * og;
@@ -199,6 +199,222 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     } else {
         step(0, preA, ptA);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, bf16, Hp = 128: the time loop written by hand
+// ---------------------------------------------------------------------------------------------
+// Same layout, same operand order and the same arithmetic as lstm_fwd_s2_kernel<P_BF16, 128> above (tests hold the two
+// bit-equal on every real slot); only the instruction stream of the loop is ours.  With one wave per SIMD nothing overlaps
+// a wave's own issue slots, so a step costs what its instructions cost: hipcc's loop issues ~180 instructions per step
+// (50 scalar: the time index is turned into 64-bit addresses again every step; 8 64-bit VALU address adds; register
+// shuffles around the v_pk_* pairs it forms); this one issues 86:
+//   * addresses are a constant SGPR base + a 32-bit VGPR byte offset that moves by one time step per step (4 v_add_u32);
+//     the prefetch two steps ahead uses the same offsets on bases shifted by two steps, so it needs no address of its own;
+//     the last two steps have no prefetch (their copies of the body simply lack the loads: no clamping);
+//   * the stage of step t+2 lands in the registers step t has just copied into the accumulators: two stages, loop body of
+//     two steps, no copies besides the accumulator seeding the sparse MFMA needs anyway;
+//   * MFMAs gate-major (n, i, f, o; per accumulator in the order of the C++ kernel), the activations of a finished gate
+//     in the issue gaps of the following gates' MFMAs -- 8 of each MFMA's 16 cycles, one transcendental or two plain
+//     VALU instructions -- and never sooner than four MFMAs after the gate's last one (the matrix pipe's result is not
+//     interlocked against VALU reads: 11 wait states after an 8-pass MFMA);
+//   * a transcendental's consumer never issues right behind it (trans forwarding hazard of gfx940+).
+// Dummy slots: a slot is treated as a dummy whenever its pattern type is NONE; the reference (LstmLayer.cu:825,860) and the
+// C++ kernels only look at the pattern type from t >= minSeqLength on, so for t < minSeqLength the UNUSED slots of a
+// partial fraction (never real slots) hold zeros here and functor output there.  Nothing reads them: their errors are
+// zero in the backward pass either way.
+//
+// Fixed registers (clobbered): v[224:239] the four accumulators, v[240:243] / v[244:247] the two stages, v[248:251]
+// n, i, f, o of the step (one 16-byte store), v252 = cell state before the dummy select, v253 = tanh(cell state).
+#define S2A_K1 "0xbfb8aa3b"     /* -log2(e)   */
+#define S2A_K2 "0xc038aa3b"     /* -2 log2(e) */
+#define S2A_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#define S2A_PF(PX, PT) \
+    "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
+    "global_load_dwordx4 " PX ", %[oA], %[actspf]\n\t"
+#define S2A_NOPF "s_nop 1\n\t"
+// PX0..PX3: the stage's registers; PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of the tile
+// read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
+#define S2A_STEP(PX0, PX1, PX2, PX3, PT, R0, R1, WO, VM, PFCODE) \
+    "s_waitcnt vmcnt(" VM ")\n\t" \
+    "ds_read_b128 %[a0], %[av0] offset:" R0 "\n\t" \
+    "ds_read_b128 %[a1], %[av1] offset:" R0 "\n\t" \
+    "ds_read_b128 %[a2], %[av0] offset:" R1 "\n\t" \
+    "ds_read_b128 %[a3], %[av1] offset:" R1 "\n\t" \
+    "v_mov_b32 v224, " PX0 "\n\t" \
+    "v_mov_b32 v225, 0\n\t" \
+    "v_mov_b32 v228, " PX1 "\n\t" \
+    "v_mov_b32 v229, 0\n\t" \
+    "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    S2A_MF("v[224:227]", "a0", "w0n0") \
+    "v_mov_b32 v232, " PX2 "\n\t" \
+    "v_mov_b32 v233, 0\n\t" \
+    "s_waitcnt lgkmcnt(2)\n\t" \
+    S2A_MF("v[224:227]", "a1", "w1n0") \
+    "v_mov_b32 v236, " PX3 "\n\t" \
+    "v_mov_b32 v237, 0\n\t" \
+    "s_waitcnt lgkmcnt(1)\n\t" \
+    S2A_MF("v[224:227]", "a2", "w0n1") \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    S2A_MF("v[224:227]", "a3", "w1n1") \
+    PFCODE \
+    S2A_MF("v[228:231]", "a0", "w0i0") \
+    S2A_MF("v[228:231]", "a1", "w1i0") \
+    S2A_MF("v[228:231]", "a2", "w0i1") \
+    S2A_MF("v[228:231]", "a3", "w1i1") \
+    "v_add_f32 %[x0], v224, v225\n\t" \
+    S2A_MF("v[232:235]", "a0", "w0f0") \
+    "v_mul_f32 %[x0], " S2A_K2 ", %[x0]\n\t" \
+    S2A_MF("v[232:235]", "a1", "w1f0") \
+    "v_exp_f32 %[x0], %[x0]\n\t" \
+    S2A_MF("v[232:235]", "a2", "w0f1") \
+    "v_add_f32 %[x1], v228, v229\n\t" \
+    "v_add_f32 %[x0], 1.0, %[x0]\n\t" \
+    S2A_MF("v[232:235]", "a3", "w1f1") \
+    "v_fmac_f32 %[x1], %[pi], %[cst]\n\t" \
+    "v_rcp_f32 %[x0], %[x0]\n\t" \
+    S2A_MF("v[236:239]", "a0", "w0o0") \
+    "v_mul_f32 %[x1], " S2A_K1 ", %[x1]\n\t" \
+    S2A_MF("v[236:239]", "a1", "w1o0") \
+    "v_exp_f32 %[x1], %[x1]\n\t" \
+    S2A_MF("v[236:239]", "a2", "w0o1") \
+    "v_fma_f32 v248, %[x0], 2.0, -1.0\n\t" \
+    "v_add_f32 %[x1], 1.0, %[x1]\n\t" \
+    S2A_MF("v[236:239]", "a3", "w1o1") \
+    "v_add_f32 %[x2], v232, v233\n\t" \
+    "v_rcp_f32 v249, %[x1]\n\t" \
+    "v_fmac_f32 %[x2], %[pf], %[cst]\n\t" \
+    "v_mul_f32 %[x2], " S2A_K1 ", %[x2]\n\t" \
+    "v_exp_f32 %[x2], %[x2]\n\t" \
+    "s_nop 0\n\t" \
+    "v_add_f32 %[x2], 1.0, %[x2]\n\t" \
+    "v_rcp_f32 v250, %[x2]\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32 %[x3], %[cst], v250\n\t" \
+    "v_fma_f32 v252, v248, v249, %[x3]\n\t" \
+    "v_add_f32 %[x4], v236, v237\n\t" \
+    "v_fmac_f32 %[x4], %[po], v252\n\t" \
+    "v_mul_f32 %[x5], " S2A_K2 ", v252\n\t" \
+    "v_mul_f32 %[x4], " S2A_K1 ", %[x4]\n\t" \
+    "v_exp_f32 %[x5], %[x5]\n\t" \
+    "v_exp_f32 %[x4], %[x4]\n\t" \
+    "v_add_f32 %[x5], 1.0, %[x5]\n\t" \
+    "v_add_f32 %[x4], 1.0, %[x4]\n\t" \
+    "v_rcp_f32 %[x5], %[x5]\n\t" \
+    "v_rcp_f32 v251, %[x4]\n\t" \
+    "v_fma_f32 v253, %[x5], 2.0, -1.0\n\t" \
+    "v_cndmask_b32_e64 %[cst], v252, 0, vcc\n\t" \
+    "v_mul_f32 %[x6], v253, v251\n\t" \
+    "v_cvt_pk_bf16_f32 %[x6], %[x6], %[x6]\n\t" \
+    "v_cndmask_b32_e64 %[x6], %[x6], 0, vcc\n\t" \
+    "ds_write_b16 %[oT], %[x6] offset:" WO "\n\t" \
+    "global_store_dwordx4 %[oA], v[248:251], %[acts]\n\t" \
+    "global_store_dword %[oC], %[cst], %[cell]\n\t" \
+    "global_store_dword %[oC], v253, %[th]\n\t" \
+    "global_store_short %[oY], %[x6], %[yop]\n\t" \
+    "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
+    "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
+    "v_add_u32 %[oY], %[oY], %[sY]\n\t" \
+    "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "s_barrier\n\t"
+#define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "v242", "v243", "ptA", R0, R1, WO, VM, PFCODE)
+#define S2A_STEP_B(R0, R1, WO, VM, PFCODE) S2A_STEP("v244", "v245", "v246", "v247", "ptB", R0, R1, WO, VM, PFCODE)
+
+__global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 128, KCS = 2;
+    constexpr int pitch = lds_pitch(HP);             // 160
+    constexpr int plane = 5 * pitch;                 // 800: the asm below carries it as literal offsets
+    static_assert(plane == 800, "LDS offsets of the hand-written loop");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x8 w[2][4][KCS];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc)
+                w[j][g][kc] = sp_load_bf16(Wd + ((long)(g * HP + 32 * wave + 16 * j + c) * HP + kc * 64 + q * 16) * 2);
+    const int spidx = sp_index(c);
+    const int vrow0 = (c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4;
+    const int vrow1 = (c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4;
+    const unsigned av0 = vrow0 * pitch + q * 16, av1 = vrow1 * pitch + q * 16;
+
+    const int unit = 32 * wave + 16 * ug + c;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const int k = unit & 63;
+    const unsigned oT = (2 * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;
+    // byte offsets of this lane at the first processed step, and what one step adds (mod 2^32: backwards for d = 1)
+    const long t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);          // elements into a cell row block (x 16 / 4 / 2 bytes)
+    unsigned oA = (unsigned)(t0 * stepA * 4) + lC * 16, oC = (unsigned)(t0 * stepC * 4) + lC * 4, oY = (unsigned)(t0 * stepC * 2) + lC * 2;
+    unsigned oP = (unsigned)(t0 * PS) + (unsigned)sv;
+    const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sY = (unsigned)(dt * stepC * 2), sP = (unsigned)(dt * PS);
+    const char *acts = (const char *)p.acts, *actspf = acts + 2 * dt * stepA * 4;
+    const char *pat = p.pat, *patpf = pat + 2 * dt * PS;
+    unsigned np = (unsigned)(T - 2) / 2;             // pairs of steps with a prefetch (T >= 4: at least one)
+    const unsigned rem = (unsigned)T - 2 * np;       // 2 or 3 steps behind them
+
+    float cst = 0.f;
+    int ptA, ptB;
+    u32x4 a0, a1, a2, a3;
+    float x0, x1, x2, x3, x4, x5, x6;
+    lds_barrier();
+    asm volatile(
+        // accumulator rows 2, 3 belong to rows of zeros in both views and stay 0 for the whole pass
+        "v_mov_b32 v226, 0\n\tv_mov_b32 v227, 0\n\tv_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\t"
+        "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t"
+        // stages of the first two steps
+        "global_load_ubyte %[ptA], %[oP], %[pat]\n\t"
+        "global_load_dwordx4 v[240:243], %[oA], %[acts]\n\t"
+        "v_add_u32 %[x0], %[oP], %[sP]\n\t"
+        "v_add_u32 %[x1], %[oA], %[sA]\n\t"
+        "global_load_ubyte %[ptB], %[x0], %[pat]\n\t"
+        "global_load_dwordx4 v[244:247], %[x1], %[acts]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "1:\n\t"
+        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:243]", "ptA"))
+        S2A_STEP_B("800", "864", "0", "10", S2A_PF("v[244:247]", "ptB"))
+        "s_sub_u32 %[np], %[np], 1\n\t"
+        "s_cmp_lg_u32 %[np], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_cmp_eq_u32 %[rem], 3\n\t"
+        "s_cbranch_scc0 2f\n\t"
+        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:243]", "ptA"))
+        S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
+        S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
+        "s_branch 3f\n\t"
+        "2:\n\t"
+        S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
+        S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
+        "3:\n\t"
+        : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [np] "+s"(np),
+          [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6)
+        : [w0n0] "v"(w[0][0][0]), [w0n1] "v"(w[0][0][1]), [w1n0] "v"(w[1][0][0]), [w1n1] "v"(w[1][0][1]),
+          [w0i0] "v"(w[0][1][0]), [w0i1] "v"(w[0][1][1]), [w1i0] "v"(w[1][1][0]), [w1i1] "v"(w[1][1][1]),
+          [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]),
+          [w0o0] "v"(w[0][3][0]), [w0o1] "v"(w[0][3][1]), [w1o0] "v"(w[1][3][0]), [w1o1] "v"(w[1][3][1]),
+          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
+          [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(p.cell), [th] "s"(p.th), [yop] "s"(p.y_op),
+          [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem)
+        : "memory", "vcc", "scc",
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+          "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -416,9 +632,28 @@ bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
     return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;
 }
 
+// the hand-written loops cover bf16, Hp = 128, at least four time steps, and activations addressable with 32-bit byte offsets
+static bool s2_asm_applies(int prec, bool bwd, const LstmRec &p)
+{
+    if (getenv("CN_NO_S2_ASM") || prec != P_BF16 || p.Hp != 128 || p.T < 4 || bwd) return false;
+    return (unsigned long long)p.T * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;
+}
+
 template <int PREC, bool BWD, int HP>
 static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
 {
+    if constexpr (PREC == P_BF16 && HP == 128 && !BWD) {
+        if (s2_asm_applies(PREC, BWD, p)) {
+            static DeviceOnce once;
+            if (once.first()) (void)hipFuncSetAttribute((const void *)lstm_fwd_s2_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
+            size_t lds_claim = lds;
+            if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+            hipExtLaunchKernelGGL(lstm_fwd_s2_asm_kernel, dim3(p.dirs * (p.PS / 2)), dim3(256), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
+            if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_fwd_s2_asm_kernel");
+            return;
+        }
+    }
     auto kern = BWD ? lstm_bwd_s2_kernel<PREC, HP> : lstm_fwd_s2_kernel<PREC, HP>;
     static DeviceOnce attr_once;
     if (attr_once.first()) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

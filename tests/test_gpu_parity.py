@@ -625,3 +625,42 @@ def test_destroy_deep_cluster_network(depth):
         "print('destroyed ok')\n" % (root, os.path.join(root, "tests"), depth))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert out.returncode == 0 and "destroyed ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
+@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 4), ("blstm", 250, 5), ("lstm", 128, 9), ("blstm", 256, 37), ("blstm", 250, 64)])
+def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
+    """The hand-written (asm) time loops of cn_lstm_s2.hip against the C++ kernels of the same cut (CN_NO_S2_ASM): same
+    operand order, same arithmetic, so EVERY value on a real slot must be bit-identical -- outputs, the four gate
+    activations, cell states, all deltas, every weight gradient except the split-K atomics' last bits (compared at 1e-6).
+    Loop shapes: T = 4 (one pair + tail of two), 5 (tail of three), odd / even longer passes, ragged lengths, unused slots,
+    one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
+    rng = np.random.RandomState(500 + T)
+    P, C, PS = 9, 7, 11                       # 11 slots -> padded to 12, the last group half filled
+    layers = net_desc(P, [(kind, size), (kind, size)], C)
+    weights = random_weights(layers, rng, 0.08)
+    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]      # one unused slot
+    lengths[0] = T
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    real = real_mask(frac)
+    got = {}
+    for mode in ("asm", "cpp"):
+        if mode == "cpp":
+            monkeypatch.setenv("CN_NO_S2_ASM", "1")
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+            net.load_sequences(frac); net.compute_forward_pass()
+            e, c = net.error_and_correct()
+            net.compute_backward_pass()
+            names = (net.recurrent_kernel(False), net.recurrent_kernel(True))
+            vals = {"error": np.float32(e), "out": net.outputs().reshape(-1, C)[real]}
+            for lay in net.layers[1:3]:
+                for dd in range(lay.dirs):
+                    for name in ("cellStates", "niActs", "igActs", "fgActs", "ogActs", "tmpOutputs", "niDeltas", "igDeltas", "fgDeltas", "ogDeltas"):
+                        vals["%s/%d/%s" % (lay.name, dd, name)] = lay.internal(name, dd).reshape(-1, lay.H)[real]
+            grads = {lay.name: lay.weight_updates() for lay in net.trainable_layers()}
+            got[mode] = (names, vals, grads)
+    assert got["asm"][0][0] == "lstm_fwd_s2_asm_kernel" and got["cpp"][0][0] == "lstm_fwd_s2_kernel<0,128>"
+    for key, v in got["asm"][1].items():
+        assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
+    for name, g in got["asm"][2].items():
+        assert rel_err(g, got["cpp"][2][name]) < 1e-6, name
