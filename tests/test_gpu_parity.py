@@ -627,13 +627,14 @@ def test_destroy_deep_cluster_network(depth):
     assert out.returncode == 0 and "destroyed ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
-@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 4), ("blstm", 250, 5), ("lstm", 128, 9), ("blstm", 256, 37), ("blstm", 250, 64)])
+@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 3), ("blstm", 250, 4), ("blstm", 250, 5), ("blstm", 250, 6), ("lstm", 128, 9), ("blstm", 256, 37),
+                                         ("blstm", 250, 64)])
 def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
     """The hand-written (asm) time loops of cn_lstm_s2.hip against the C++ kernels of the same cut (CN_NO_S2_ASM): same
     operand order, same arithmetic, so EVERY value on a real slot must be bit-identical -- outputs, the four gate
     activations, cell states, all deltas, every weight gradient except the split-K atomics' last bits (compared at 1e-6).
-    Loop shapes: T = 4 (one pair + tail of two), 5 (tail of three), odd / even longer passes, ragged lengths, unused slots,
-    one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
+    Loop shapes: T = 3 (backward: tail only; forward: compiled kernel), 4, 5, 6 (every combination of pair count and tail
+    length of both loops), odd / even longer passes, ragged lengths, unused slots, one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
     rng = np.random.RandomState(500 + T)
     P, C, PS = 9, 7, 11                       # 11 slots -> padded to 12, the last group half filled
     layers = net_desc(P, [(kind, size), (kind, size)], C)
@@ -659,7 +660,8 @@ def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, mon
                         vals["%s/%d/%s" % (lay.name, dd, name)] = lay.internal(name, dd).reshape(-1, lay.H)[real]
             grads = {lay.name: lay.weight_updates() for lay in net.trainable_layers()}
             got[mode] = (names, vals, grads)
-    assert got["asm"][0][0] == "lstm_fwd_s2_asm_kernel" and got["cpp"][0][0] == "lstm_fwd_s2_kernel<0,128>"
+    assert got["asm"][0] == ("lstm_fwd_s2_asm_kernel" if T >= 4 else "lstm_fwd_s2_kernel<0,128>", "lstm_bwd_s2_asm_kernel")
+    assert got["cpp"][0] == ("lstm_fwd_s2_kernel<0,128>", "lstm_bwd_s2_kernel<0,128>")
     for key, v in got["asm"][1].items():
         assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
     for name, g in got["asm"][2].items():
