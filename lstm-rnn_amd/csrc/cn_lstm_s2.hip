@@ -229,9 +229,15 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
 #define S2A_K1 "0xbfb8aa3b"     /* -log2(e)   */
 #define S2A_K2 "0xc038aa3b"     /* -2 log2(e) */
 #define S2A_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#ifdef CN_S2_DIAG_HOT
+#define S2A_PF(PX, PT) \
+    "global_load_ubyte %[" PT "], %[oT], %[pat]\n\t" \
+    "global_load_dwordx4 " PX ", %[oT], %[acts]\n\t"
+#else
 #define S2A_PF(PX, PT) \
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
     "global_load_dwordx4 " PX ", %[oA], %[actspf]\n\t"
+#endif
 #define S2A_NOPF "s_nop 1\n\t"
 // PX0..PX3: the stage's registers; PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of the tile
 // read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
@@ -547,34 +553,34 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 
         // ComputeBlockErrorsFn, LstmLayer.cu:236-285, as an explicit operation sequence (no contraction left to the compiler:
         // the hand-written loop below issues exactly these operations and is held bit-equal).  Everything that does not
-        // depend on e is formed first -- in the hand-written loop under the MFMAs --, so that behind the product only
-        //   dog = og (1 - og) th e,  ec = og (1 - th^2) e + po dog + (fg' ec' + pi dig' + pf dfg')   (' = carried from t+1)
-        //   dni = ig (1 - ni^2) ec,  dfg = fg (1 - fg) cp ec,  dig = ig (1 - ig) ni ec
-        // remain as one multiply each.
+        // depend on e is formed first -- in the hand-written loop one step early, in the shadow of the LDS hand-off --, and
+        // the dummy-slot rule (:224-234: all deltas and the cell state error are 0) enters as a factor m = 0 / 1, so that
+        // behind the product only
+        //   dog = [m og (1 - og) th] e,   ec = e [m (og (1 - th^2) + po og (1 - og) th)] + m (fg' ec' + pi dig' + pf dfg')
+        //   dni = [m ig (1 - ni^2)] ec,   dfg = [m fg (1 - fg) cp] ec,   dig = [m ig (1 - ig) ni] ec      (' = carried from t+1)
+        // remain: one multiply or fma each, then the clips.  (ec uses the unclipped dog, :262-263, as the reference does.)
         const bool dummy = dmy != 0;
         const float ni = a_[0], ig = a_[1], fg = a_[2], og = a_[3];
         const float cs = ccur, th = th_;
         float dog, ec, dni, dfg, dig;
         {
 #pragma clang fp contract(off)
+            const float m = dummy ? 0.f : 1.f;
             const float t2p = __builtin_fmaf(-og, og, og) * th;
             const float vp = og * __builtin_fmaf(-th, th, 1.0f);
+            const float w = __builtin_fmaf(po, t2p, vp);
             const float d2p = ig * __builtin_fmaf(-ni, ni, 1.0f);
             const float d3p = __builtin_fmaf(-fg, fg, fg) * cp;              // cp = 0 at lastCall
             const float d4p = __builtin_fmaf(-ig, ig, ig) * ni;
             float car = fgn * ecn;                                          // zero carry at firstCall
             car = __builtin_fmaf(pi, dign, car);
             car = __builtin_fmaf(pf, dfgn, car);
-            dog = t2p * e;
-            ec = vp * e;
-            ec = __builtin_fmaf(po, dog, ec);
-            ec = ec + car;
-            dni = d2p * ec; dfg = d3p * ec; dig = d4p * ec;
+            dog = (t2p * m) * e;
+            ec = __builtin_fmaf(e, w * m, car * m);
+            dni = (d2p * m) * ec; dfg = (d3p * m) * ec; dig = (d4p * m) * ec;
+            fgn = fg * m;
         }
         dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
-        dni = dummy ? 0.f : dni; dig = dummy ? 0.f : dig; dfg = dummy ? 0.f : dfg; dog = dummy ? 0.f : dog;   // :224-234
-        ec = dummy ? 0.f : ec;
-        fgn = dummy ? 0.f : fg;
         ecn = ec; dign = dig; dfgn = dfg;
         ccur = cp;
         // gradient sums (ComputeWeightUpdateFn bias / peephole cases, :392-408, :440-475)
@@ -632,42 +638,101 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 // backward, bf16, Hp = 128: the time loop written by hand
 // ---------------------------------------------------------------------------------------------
 // As lstm_fwd_s2_asm_kernel: layout, operand order and arithmetic of lstm_bwd_s2_kernel<P_BF16, 128> (bit-equal on real
-// slots), our own instruction stream: 95 issued instructions per step against hipcc's ~190.
-//   * everything of ComputeBlockErrorsFn that does not depend on the product (the activation derivatives, the carried
-//     terms, the forget-gate carry) is formed in the issue gaps of the first eight MFMAs; behind the product the chain is
-//     three adds, nine multiplies / fmas, the four clips and the selects;
-//   * by then the stage registers are dead, so the prefetch of step t+2 is issued in the middle of step t, straight into
-//     them (outputErrors straight into register 0 of the stage's own accumulator, which is the MFMA's C operand): no
-//     copies at all; two stages, two accumulator sets, loop body of two steps;
+// slots), our own instruction stream, ~95 issued instructions per step against hipcc's ~190 -- and software-pipelined:
+// in-kernel stamps (tools/stamps_s2.py) showed a step of one wave per SIMD to be the SUM of its stalls (LDS operands landed
+// 170 cycles after the barrier, 16 MFMAs with two fillers per gap 410, the e-dependent chain of dependent VALU instructions
+// at 6.6 cycles each 125, LDS write + tail 125), so the work is placed where the wave waits anyway:
+//   * "block": everything of ComputeBlockErrorsFn that does not depend on the product -- the activation derivatives, the
+//     carried terms, the dummy-slot factor m -- is formed for step t+1 at the END of step t, between the LDS write and the
+//     barrier; the MFMA phase carries only one cheap filler per gap (a gap hides one VALU instruction, not two);
+//   * the stage registers are therefore dead when their step begins: the prefetch of step t+2 is issued at the TOP of step
+//     t, straight into them (outputErrors into register 0 of the stage's accumulator, the MFMA's C operand, once the sums
+//     are read): two full steps of distance, no copies; two stages, two accumulator sets, loop body of two steps;
+//   * the 11 wait states between the last MFMA and the first read of its result are the previous step's gradient sums;
+//   * behind the product: three adds, five multiplies / fmas, four clips, two conversions; no selects (the factor m);
 //   * the step whose prefetch targets the last processed step (lastCall, LstmLayer.cu:947,981: no cell state behind it)
-//     and the last two steps (no prefetch) are separate copies of the body;
+//     and the last two steps (no prefetch; the last one no block) are separate copies of the body;
 //   * both LDS writes of a lane are one ds_write2_b32, its delta_op store one 8-byte store.
 // Dummy slots as in the forward loop: the pattern type alone decides (for t < minSeqLength the unused slots of a partial
 // fraction carry zero errors, so their deltas are zero either way).
 //
 // Fixed registers (clobbered): stage A: v[224:227] n,i,f,o; v[228:231] / v[232:235] the accumulators of K half 0 / 1;
 // stage B: v[236:239], v[240:243] / v[244:247]; v[248:249] the four bf16 deltas of the step.
+#ifdef CN_S2_DIAG_NOMFMA
+#define S2B_MF(acc, a, w) ""
+#else
 #define S2B_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#endif
+// CN_S2_STAMP (tools/stamps_s2.py; never in the shipped build): every wave of workgroup 0 sums s_memtime deltas per step segment
+#ifdef CN_S2_STAMP
+__device__ unsigned cn_s2_stamp_buf[4][8];
+#define S2B_ST(i) "s_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 %[tq], s98, %[tl]\n\ts_add_u32 %[st" #i "], %[st" #i "], %[tq]\n\ts_mov_b32 %[tl], s98\n\t"
+#else
+#define S2B_ST(i) ""
+#endif
 // prefetch of step t+2 into stage X: activations, tanh(c), c[prev], pattern type (outputErrors follow behind the e sum)
+#ifdef CN_S2_DIAG_HOT
+#define S2B_PF(AXT, TH, CP, PT) \
+    "global_load_dwordx4 " AXT ", %[oT], %[acts]\n\t" \
+    "global_load_dword %[" TH "], %[oT], %[th]\n\t" \
+    "global_load_dword %[" CP "], %[oT], %[cell]\n\t" \
+    "global_load_ubyte %[" PT "], %[oT], %[pat]\n\t"
+#define S2B_PFE(ACCA0) "global_load_dword " ACCA0 ", %[oT], %[err]\n\t"
+#else
 #define S2B_PF(AXT, TH, CP, PT) \
     "global_load_dwordx4 " AXT ", %[oA], %[actspf]\n\t" \
     "global_load_dword %[" TH "], %[oC], %[thpf]\n\t" \
     "global_load_dword %[" CP "], %[oC], %[cellpf]\n\t" \
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t"
+#define S2B_PFE(ACCA0) "global_load_dword " ACCA0 ", %[oC], %[errpf]\n\t"
+#endif
+#ifdef CN_S2_DIAG_NOSTORE
+#define S2B_STORE ""
+#else
+#define S2B_STORE "global_store_dwordx2 %[oD], v[248:249], %[delta1]\n\t"
+#endif
 #define S2B_PF_LAST(AXT, TH, CP, PT) \
     "global_load_dwordx4 " AXT ", %[oA], %[actspf]\n\t" \
     "global_load_dword %[" TH "], %[oC], %[thpf]\n\t" \
     "v_mov_b32 %[" CP "], 0\n\t" \
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t"
-#define S2B_NOPF "s_nop 3\n\t"
-#define S2B_PFE(ACCA0) "global_load_dword " ACCA0 ", %[oC], %[errpf]\n\t"
+#define S2B_NOPF ""
 #define S2B_NOPFE ""
-// NI..OG: the stage's activation registers; ACCA / ACCB: its accumulators (A0, A1 / B2, B3: the registers that are read);
-// TH, CP, PT: operands of the stage; CS: register holding the cell state of this step; CN: register that receives c[prev]
-// (the next step's CS); R: LDS byte offset of the tile read; WT: operand holding the lane's address in the tile written (the
-// two dword offsets of ds_write2_b32 are 8-bit fields: its second row, one pitch = 72 dwords on, fits; the tile base does not)
-#define S2B_STEP(NI, IG, FG, OG, ACCA, A0, A1, ACCB, B2, B3, TH, CP, PT, CS, CN, R, WT, VM, PFCODE, PFECODE) \
-    "s_waitcnt vmcnt(" VM ")\n\t" \
+// the e-independent terms of the step that stage X holds; CN: register that receives c[prev] of that step (the CS of the
+// step after it).  Reads the carries of the step processed before it.
+#define S2B_BLOCK(NI, IG, FG, OG, TH, CP, PT, CN) \
+    "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
+    "v_fma_f32 %[x0], -" OG ", " OG ", " OG "\n\t" \
+    "v_fma_f32 %[x1], -%[" TH "], %[" TH "], 1.0\n\t" \
+    "v_cndmask_b32_e64 %[m], 1.0, 0, vcc\n\t" \
+    "v_mul_f32 %[t2m], %[x0], %[" TH "]\n\t" \
+    "v_mul_f32 %[x1], " OG ", %[x1]\n\t" \
+    "v_fma_f32 %[x0], -" NI ", " NI ", 1.0\n\t" \
+    "v_mul_f32 %[car], %[fgn], %[ecn]\n\t" \
+    "v_fma_f32 %[wm], %[po], %[t2m], %[x1]\n\t" \
+    "v_mul_f32 %[d2m], " IG ", %[x0]\n\t" \
+    "v_fma_f32 %[x0], -" FG ", " FG ", " FG "\n\t" \
+    "v_fmac_f32 %[car], %[pi], %[dign]\n\t" \
+    "v_fma_f32 %[x1], -" IG ", " IG ", " IG "\n\t" \
+    "v_mul_f32 %[d3m], %[x0], %[" CP "]\n\t" \
+    "v_fmac_f32 %[car], %[pf], %[dfgn]\n\t" \
+    "v_mul_f32 %[d4m], %[x1], " NI "\n\t" \
+    "v_mul_f32 %[t2m], %[t2m], %[m]\n\t" \
+    "v_mul_f32 %[wm], %[wm], %[m]\n\t" \
+    "v_mul_f32 %[carm], %[car], %[m]\n\t" \
+    "v_mul_f32 %[d2m], %[d2m], %[m]\n\t" \
+    "v_mul_f32 %[d3m], %[d3m], %[m]\n\t" \
+    "v_mul_f32 %[d4m], %[d4m], %[m]\n\t" \
+    "v_mul_f32 %[fgn], " FG ", %[m]\n\t" \
+    "v_mov_b32 %[" CN "], %[" CP "]\n\t"
+#define S2B_TAIL(VM, BLOCKCODE) "s_waitcnt vmcnt(" VM ")\n\t" BLOCKCODE
+#define S2B_NOTAIL ""
+// ACCA / ACCB: the stage's accumulators (A0, A1 / B2, B3: the registers that are read); CS: register holding the cell state
+// of this step; R: LDS byte offset of the tile read; WT: operand holding the lane's address in the tile written (the two
+// dword offsets of ds_write2_b32 are 8-bit fields: its second row, one pitch = 72 dwords on, fits; the tile base does not);
+// PFCODE / PFECODE: the prefetch into this stage; TAILCODE: the block of the OTHER stage behind a wait for its loads
+#define S2B_STEP(ACCA, A0, A1, ACCB, B2, B3, CS, R, WT, PFCODE, PFECODE, TAILCODE) \
+    S2B_ST(0) \
     "ds_read_b128 %[r00], %[av0] offset:" R "\n\t" \
     "ds_read_b128 %[r10], %[av1] offset:" R "\n\t" \
     "ds_read_b128 %[r01], %[av0] offset:" R "+64\n\t" \
@@ -679,34 +744,24 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
     "v_mov_b32 " A1 ", 0\n\t" \
     "v_mov_b32 " B2 ", 0\n\t" \
     "v_mov_b32 " B3 ", 0\n\t" \
-    "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
+    PFCODE \
     "s_waitcnt lgkmcnt(7)\n\t" \
+    S2B_ST(1) \
     S2B_MF(ACCA, "r00", "w0k0") \
-    "v_fma_f32 %[x0], -" OG ", " OG ", " OG "\n\t" \
-    "v_fma_f32 %[x1], -%[" TH "], %[" TH "], 1.0\n\t" \
+    "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
     S2B_MF(ACCB, "r00", "w0k4") \
-    "v_mul_f32 %[t2p], %[x0], %[" TH "]\n\t" \
-    "v_mul_f32 %[vp], " OG ", %[x1]\n\t" \
+    "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
     "s_waitcnt lgkmcnt(6)\n\t" \
     S2B_MF(ACCA, "r10", "w1k0") \
-    "v_fma_f32 %[x0], -" NI ", " NI ", 1.0\n\t" \
-    "v_fma_f32 %[x1], -" FG ", " FG ", " FG "\n\t" \
+    "v_add_u32 %[oD], %[oD], %[sD]\n\t" \
     S2B_MF(ACCB, "r10", "w1k4") \
-    "v_mul_f32 %[d2p], " IG ", %[x0]\n\t" \
-    "v_mul_f32 %[d3p], %[x1], %[" CP "]\n\t" \
+    "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
     "s_waitcnt lgkmcnt(5)\n\t" \
     S2B_MF(ACCA, "r01", "w0k1") \
-    "v_fma_f32 %[x0], -" IG ", " IG ", " IG "\n\t" \
-    "v_mul_f32 %[car], %[fgn], %[ecn]\n\t" \
     S2B_MF(ACCB, "r01", "w0k5") \
-    "v_mul_f32 %[d4p], %[x0], " NI "\n\t" \
-    "v_fmac_f32 %[car], %[pi], %[dign]\n\t" \
     "s_waitcnt lgkmcnt(4)\n\t" \
     S2B_MF(ACCA, "r11", "w1k1") \
-    "v_fmac_f32 %[car], %[pf], %[dfgn]\n\t" \
-    "v_cndmask_b32_e64 %[fgn], " FG ", 0, vcc\n\t" \
     S2B_MF(ACCB, "r11", "w1k5") \
-    "v_mov_b32 %[" CN "], %[" CP "]\n\t" \
     "s_waitcnt lgkmcnt(3)\n\t" \
     S2B_MF(ACCA, "r02", "w0k2") \
     S2B_MF(ACCB, "r02", "w0k6") \
@@ -719,65 +774,57 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
     "s_waitcnt lgkmcnt(0)\n\t" \
     S2B_MF(ACCA, "r13", "w1k3") \
     S2B_MF(ACCB, "r13", "w1k7") \
-    PFCODE \
-    "s_nop 7\n\t" \
+    S2B_ST(2) \
+    "v_add_f32 %[sb0], %[sb0], %[dni]\n\t" \
+    "v_add_f32 %[sb1], %[sb1], %[dign]\n\t" \
+    "v_add_f32 %[sb2], %[sb2], %[dfgn]\n\t" \
+    "v_add_f32 %[sb3], %[sb3], %[dog]\n\t" \
+    "v_fmac_f32 %[spi], %[" CS "], %[dign]\n\t" \
+    "v_fmac_f32 %[spf], %[" CS "], %[dfgn]\n\t" \
+    "s_nop 4\n\t" \
     "v_add_f32 %[x0], " A0 ", " A1 "\n\t" \
     "v_add_f32 %[x1], " B2 ", " B3 "\n\t" \
     "v_add_f32 %[x0], %[x0], %[x1]\n\t" \
     PFECODE \
-    "v_mul_f32 %[dog], %[t2p], %[x0]\n\t" \
-    "v_mul_f32 %[x1], %[vp], %[x0]\n\t" \
-    "v_fmac_f32 %[x1], %[po], %[dog]\n\t" \
-    "v_add_f32 %[x1], %[x1], %[car]\n\t" \
-    "v_mul_f32 %[x2], %[d2p], %[x1]\n\t" \
-    "v_mul_f32 %[x3], %[d3p], %[x1]\n\t" \
-    "v_mul_f32 %[x4], %[d4p], %[x1]\n\t" \
-    "v_med3_f32 %[x2], %[x2], -1.0, 1.0\n\t" \
-    "v_med3_f32 %[x4], %[x4], -1.0, 1.0\n\t" \
-    "v_med3_f32 %[x3], %[x3], -1.0, 1.0\n\t" \
+    S2B_ST(3) \
+    "v_mul_f32 %[dog], %[t2m], %[x0]\n\t" \
+    "v_fma_f32 %[ecn], %[x0], %[wm], %[carm]\n\t" \
     "v_med3_f32 %[dog], %[dog], -1.0, 1.0\n\t" \
-    "v_cndmask_b32_e64 %[x2], %[x2], 0, vcc\n\t" \
-    "v_cndmask_b32_e64 %[dign], %[x4], 0, vcc\n\t" \
-    "v_cndmask_b32_e64 %[dfgn], %[x3], 0, vcc\n\t" \
-    "v_cndmask_b32_e64 %[dog], %[dog], 0, vcc\n\t" \
-    "v_cndmask_b32_e64 %[ecn], %[x1], 0, vcc\n\t" \
-    "v_cvt_pk_bf16_f32 v248, %[x2], %[dign]\n\t" \
+    "v_mul_f32 %[dni], %[d2m], %[ecn]\n\t" \
+    "v_mul_f32 %[dfgn], %[d3m], %[ecn]\n\t" \
+    "v_mul_f32 %[dign], %[d4m], %[ecn]\n\t" \
+    "v_med3_f32 %[dni], %[dni], -1.0, 1.0\n\t" \
+    "v_med3_f32 %[dfgn], %[dfgn], -1.0, 1.0\n\t" \
+    "v_med3_f32 %[dign], %[dign], -1.0, 1.0\n\t" \
     "v_cvt_pk_bf16_f32 v249, %[dfgn], %[dog]\n\t" \
+    "v_cvt_pk_bf16_f32 v248, %[dni], %[dign]\n\t" \
+    S2B_ST(4) \
     "ds_write2_b32 %[" WT "], v248, v249 offset0:0 offset1:72\n\t" \
-    "global_store_dwordx2 %[oD], v[248:249], %[delta]\n\t" \
-    "v_add_f32 %[sb0], %[sb0], %[x2]\n\t" \
-    "v_add_f32 %[sb1], %[sb1], %[dign]\n\t" \
-    "v_add_f32 %[sb2], %[sb2], %[dfgn]\n\t" \
-    "v_add_f32 %[sb3], %[sb3], %[dog]\n\t" \
-    "v_fmac_f32 %[spi], %[" CN "], %[dign]\n\t" \
-    "v_fmac_f32 %[spf], %[" CN "], %[dfgn]\n\t" \
+    S2B_STORE \
     "v_fmac_f32 %[spo], %[" CS "], %[dog]\n\t" \
-    "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
-    "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
-    "v_add_u32 %[oD], %[oD], %[sD]\n\t" \
-    "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
+    TAILCODE \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    "s_barrier\n\t"
-// tiles: plane = 9 * 288 = 2592 bytes; tile 0 at 0, tile 1 at 2592; a lane's second row (f, o) sits one pitch = 288 bytes on
-#define S2B_STEP_A(VM, PFCODE, PFECODE) \
-    S2B_STEP("v224", "v225", "v226", "v227", "v[228:231]", "v228", "v229", "v[232:235]", "v234", "v235", "thA", "cpA", "ptA", "ccA", "ccB", \
-             "0", "oT1", VM, PFCODE, PFECODE)
-#define S2B_STEP_B(VM, PFCODE, PFECODE) \
-    S2B_STEP("v236", "v237", "v238", "v239", "v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "thB", "cpB", "ptB", "ccB", "ccA", \
-             "2592", "oT", VM, PFCODE, PFECODE)
-#define S2B_A_FULL S2B_PF("v[224:227]", "thA", "cpA", "ptA"), S2B_PFE("v228")
-#define S2B_A_LAST S2B_PF_LAST("v[224:227]", "thA", "cpA", "ptA"), S2B_PFE("v228")
-#define S2B_B_FULL S2B_PF("v[236:239]", "thB", "cpB", "ptB"), S2B_PFE("v240")
-#define S2B_B_LAST S2B_PF_LAST("v[236:239]", "thB", "cpB", "ptB"), S2B_PFE("v240")
-#define S2B_NONE S2B_NOPF, S2B_NOPFE
-#define S2B_APPLY(M, VM, ...) M(VM, __VA_ARGS__)
+    S2B_ST(5) \
+    "s_barrier\n\t" \
+    S2B_ST(6)
+// tiles: plane = 9 * 288 = 2592 bytes; tile 0 at 0, tile 1 at 2592
+#define S2B_STEP_A(PFCODE, PFECODE, TAILCODE) \
+    S2B_STEP("v[228:231]", "v228", "v229", "v[232:235]", "v234", "v235", "ccA", "0", "oT1", PFCODE, PFECODE, TAILCODE)
+#define S2B_STEP_B(PFCODE, PFECODE, TAILCODE) \
+    S2B_STEP("v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "ccB", "2592", "oT", PFCODE, PFECODE, TAILCODE)
+#define S2B_BLOCK_A S2B_BLOCK("v224", "v225", "v226", "v227", "thA", "cpA", "ptA", "ccB")
+#define S2B_BLOCK_B S2B_BLOCK("v236", "v237", "v238", "v239", "thB", "cpB", "ptB", "ccA")
+#define S2B_PFA_FULL S2B_PF("v[224:227]", "thA", "cpA", "ptA")
+#define S2B_PFA_LAST S2B_PF_LAST("v[224:227]", "thA", "cpA", "ptA")
+#define S2B_PFB_FULL S2B_PF("v[236:239]", "thB", "cpB", "ptB")
+#define S2B_PFB_LAST S2B_PF_LAST("v[236:239]", "thB", "cpB", "ptB")
 
 __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HP = 128, KCS = 8, KCH = 4;
     constexpr int pitch = lds_pitch(KCH * 64);       // 288
-    constexpr int plane = 9 * pitch;                 // 2592: the asm carries it (and plane / 4 = 648, pitch / 4 = 72) as literals
+    constexpr int plane = 9 * pitch;                 // 2592: the asm carries it (and pitch / 4 = 72) as literals
     static_assert(pitch == 288 && plane == 2592, "LDS offsets of the hand-written loop");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -804,30 +851,40 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
     const int uh = unit % (HP / 2), half = unit / (HP / 2);
     const unsigned oT = (4 * sq + 2 * half) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2, oT1 = oT + plane;
     // byte offsets of this lane at the first processed step (the last one of the forward pass of this direction) and what
-    // one step adds (mod 2^32)
+    // one step adds (mod 2^32).  The offsets move on under the first MFMAs of a step, behind its prefetch: outputErrors of
+    // step t+2, issued later in the step, use a base one step back.  The delta_op offset starts one step BEFORE the first one
+    // instead, so that it never passes the last step (mod 2^32 a negative offset would be 4 GB up).
     const long t0 = d ? 0 : T - 1, dt = d ? 1 : -1;
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
     const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
     unsigned oA = (unsigned)(t0 * stepA * 4) + lC * 16, oC = (unsigned)(t0 * stepC * 4) + lC * 4, oD = (unsigned)(t0 * stepA * 2) + lC * 8;
     unsigned oP = (unsigned)(t0 * PS) + (unsigned)sv;
     const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sD = (unsigned)(dt * stepA * 2), sP = (unsigned)(dt * PS);
+    oD -= sD;
     const char *acts = (const char *)p.acts, *cell = (const char *)p.cell, *th = (const char *)p.th, *err = (const char *)p.err, *pat = p.pat;
     // bases of the prefetch two steps ahead; c[prev(t)] is the cell state of the step processed after t: three steps ahead
-    const char *actspf = acts + 2 * dt * stepA * 4, *thpf = th + 2 * dt * stepC * 4, *errpf = err + 2 * dt * stepC * 4;
+    const char *actspf = acts + 2 * dt * stepA * 4, *thpf = th + 2 * dt * stepC * 4, *errpf = err + (2 - 1) * dt * stepC * 4;
     const char *cell1 = cell + dt * stepC * 4, *cellpf = cell + 3 * dt * stepC * 4, *patpf = pat + 2 * dt * PS;
+    const char *delta1 = (const char *)p.delta_op;
     unsigned np = (unsigned)(T - 3) / 2;             // pairs of steps with a full prefetch
     const unsigned rem = (unsigned)T - 2 * np;       // 3 or 4 steps behind them (T >= 3)
 
-    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f;
+    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, dni = 0.f, dog = 0.f;
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f, spi = 0.f, spf = 0.f, spo = 0.f;
     float ccA, ccB, thA, thB, cpA, cpB;
     int ptA, ptB;
     u32x4 r00, r01, r02, r03, r10, r11, r12, r13;
-    float x0, x1, x2, x3, x4, t2p, vp, d2p, d3p, d4p, car, dog;
+    float x0, x1, m, t2m, wm, carm, d2m, d3m, d4m, car;
+#ifdef CN_S2_STAMP
+    unsigned st[7] = {0, 0, 0, 0, 0, 0, 0}, tq;
+    unsigned long long tm;
+    unsigned tl = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     lds_barrier();
     asm volatile(
         // (registers 2, 3 of the K-half-0 accumulators and 0, 1 of the K-half-1 accumulators collect products of rows that belong
-        // to the other half; they are never read, but must not start as NaN patterns that could raise nothing -- cleared once)
+        // to the other half; they are never read -- cleared once so that they hold numbers)
         "v_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\tv_mov_b32 v232, 0\n\tv_mov_b32 v233, 0\n\t"
         "v_mov_b32 v242, 0\n\tv_mov_b32 v243, 0\n\tv_mov_b32 v244, 0\n\tv_mov_b32 v245, 0\n\t"
         // cell state of the first processed step; stages of the first two steps (T >= 3: both have a step behind them)
@@ -839,52 +896,66 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
         "global_load_dword v228, %[oC], %[err]\n\t"
         "v_add_u32 %[x0], %[oA], %[sA]\n\t"
         "v_add_u32 %[x1], %[oC], %[sC]\n\t"
-        "v_add_u32 %[x2], %[oP], %[sP]\n\t"
+        "v_add_u32 %[m], %[oP], %[sP]\n\t"
         "global_load_dwordx4 v[236:239], %[x0], %[acts]\n\t"
         "global_load_dword %[thB], %[x1], %[th]\n\t"
         "global_load_dword %[cpB], %[x1], %[cell1]\n\t"
-        "global_load_ubyte %[ptB], %[x2], %[pat]\n\t"
+        "global_load_ubyte %[ptB], %[m], %[pat]\n\t"
         "global_load_dword v240, %[x1], %[err]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
+        S2B_BLOCK_A
         "s_cmp_eq_u32 %[np], 0\n\t"
         "s_cbranch_scc1 2f\n\t"
         "1:\n\t"
-        S2B_APPLY(S2B_STEP_A, "7", S2B_A_FULL)
-        S2B_APPLY(S2B_STEP_B, "7", S2B_B_FULL)
+        S2B_STEP_A(S2B_PFA_FULL, S2B_PFE("v228"), S2B_TAIL("7", S2B_BLOCK_B))
+        S2B_STEP_B(S2B_PFB_FULL, S2B_PFE("v240"), S2B_TAIL("7", S2B_BLOCK_A))
         "s_sub_u32 %[np], %[np], 1\n\t"
         "s_cmp_lg_u32 %[np], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
         "2:\n\t"
         "s_cmp_eq_u32 %[rem], 3\n\t"
         "s_cbranch_scc0 3f\n\t"
-        S2B_APPLY(S2B_STEP_A, "7", S2B_A_LAST)
-        S2B_APPLY(S2B_STEP_B, "6", S2B_NONE)
-        S2B_APPLY(S2B_STEP_A, "2", S2B_NONE)
+        S2B_STEP_A(S2B_PFA_LAST, S2B_PFE("v228"), S2B_TAIL("6", S2B_BLOCK_B))
+        S2B_STEP_B(S2B_NOPF, S2B_NOPFE, S2B_TAIL("2", S2B_BLOCK_A))
+        S2B_STEP_A(S2B_NOPF, S2B_NOPFE, S2B_NOTAIL)
+        // gradient sums of the last step (its c[prev] is 0: lastCall)
+        "v_add_f32 %[sb0], %[sb0], %[dni]\n\tv_add_f32 %[sb1], %[sb1], %[dign]\n\tv_add_f32 %[sb2], %[sb2], %[dfgn]\n\tv_add_f32 %[sb3], %[sb3], %[dog]\n\t"
         "s_branch 4f\n\t"
         "3:\n\t"
-        S2B_APPLY(S2B_STEP_A, "7", S2B_A_FULL)
-        S2B_APPLY(S2B_STEP_B, "7", S2B_B_LAST)
-        S2B_APPLY(S2B_STEP_A, "6", S2B_NONE)
-        S2B_APPLY(S2B_STEP_B, "2", S2B_NONE)
+        S2B_STEP_A(S2B_PFA_FULL, S2B_PFE("v228"), S2B_TAIL("7", S2B_BLOCK_B))
+        S2B_STEP_B(S2B_PFB_LAST, S2B_PFE("v240"), S2B_TAIL("6", S2B_BLOCK_A))
+        S2B_STEP_A(S2B_NOPF, S2B_NOPFE, S2B_TAIL("2", S2B_BLOCK_B))
+        S2B_STEP_B(S2B_NOPF, S2B_NOPFE, S2B_NOTAIL)
+        "v_add_f32 %[sb0], %[sb0], %[dni]\n\tv_add_f32 %[sb1], %[sb1], %[dign]\n\tv_add_f32 %[sb2], %[sb2], %[dfgn]\n\tv_add_f32 %[sb3], %[sb3], %[dog]\n\t"
         "4:\n\t"
-        : [fgn] "+v"(fgn), [ecn] "+v"(ecn), [dign] "+v"(dign), [dfgn] "+v"(dfgn),
+        : [fgn] "+v"(fgn), [ecn] "+v"(ecn), [dign] "+v"(dign), [dfgn] "+v"(dfgn), [dni] "+v"(dni), [dog] "+v"(dog),
           [sb0] "+v"(sb0), [sb1] "+v"(sb1), [sb2] "+v"(sb2), [sb3] "+v"(sb3), [spi] "+v"(spi), [spf] "+v"(spf), [spo] "+v"(spo),
           [oA] "+v"(oA), [oC] "+v"(oC), [oD] "+v"(oD), [oP] "+v"(oP), [np] "+s"(np),
           [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [thA] "=&v"(thA), [thB] "=&v"(thB), [cpA] "=&v"(cpA), [cpB] "=&v"(cpB),
           [ptA] "=&v"(ptA), [ptB] "=&v"(ptB),
           [r00] "=&v"(r00), [r01] "=&v"(r01), [r02] "=&v"(r02), [r03] "=&v"(r03), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13),
-          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [t2p] "=&v"(t2p), [vp] "=&v"(vp),
-          [d2p] "=&v"(d2p), [d3p] "=&v"(d3p), [d4p] "=&v"(d4p), [car] "=&v"(car), [dog] "=&v"(dog)
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [m] "=&v"(m), [t2m] "=&v"(t2m), [wm] "=&v"(wm), [carm] "=&v"(carm),
+          [d2m] "=&v"(d2m), [d3m] "=&v"(d3m), [d4m] "=&v"(d4m), [car] "=&v"(car)
+#ifdef CN_S2_STAMP
+          , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]), [st6] "+s"(st[6]),
+          [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#endif
         : [w0k0] "v"(w[0][0]), [w0k1] "v"(w[0][1]), [w0k2] "v"(w[0][2]), [w0k3] "v"(w[0][3]), [w0k4] "v"(w[0][4]), [w0k5] "v"(w[0][5]), [w0k6] "v"(w[0][6]), [w0k7] "v"(w[0][7]),
           [w1k0] "v"(w[1][0]), [w1k1] "v"(w[1][1]), [w1k2] "v"(w[1][2]), [w1k3] "v"(w[1][3]), [w1k4] "v"(w[1][4]), [w1k5] "v"(w[1][5]), [w1k6] "v"(w[1][6]), [w1k7] "v"(w[1][7]),
           [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [oT1] "v"(oT1), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
           [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(cell), [cell1] "s"(cell1), [cellpf] "s"(cellpf), [th] "s"(th), [thpf] "s"(thpf),
-          [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta] "s"(p.delta_op),
+          [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta1] "s"(delta1),
           [sA] "s"(sA), [sC] "s"(sC), [sD] "s"(sD), [sP] "s"(sP), [rem] "s"(rem)
         : "memory", "vcc", "scc",
           "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
           "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
 
+#ifdef CN_S2_STAMP
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; ++i) cn_s2_stamp_buf[wave][i] = st[i];
+        cn_s2_stamp_buf[wave][7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);      // 100 MHz ticks over the loop
+    }
+#endif
     // fold the two sequences of each unit column, then one atomic per (gate, unit) and workgroup
     float v[7] = {sb0, sb1, sb2, sb3, spi, spf, spo};
 #pragma unroll
@@ -896,6 +967,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
         for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
     }
 }
+
+#ifdef CN_S2_STAMP
+extern "C" int cn_dbg_read_stamps_s2(unsigned *host)      // [4][8]
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_s2_stamp_buf), sizeof(cn_s2_stamp_buf));
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // launcher
