@@ -125,7 +125,72 @@ def spawn_ranks(n, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
-    return subprocess.run(cmd, env=env).returncode
+    # This process has touched no GPU and may therefore wait, time out and kill: the ranks run in a process group of their
+    # own; if the job is not done within CN_BENCH_TIMEOUT seconds (a rank that never reaches the rendezvous leaves the others
+    # waiting in ncclCommInitRank / a barrier for ever) the whole group is terminated and the exit code says so.
+    import signal
+    limit = float(os.environ.get("CN_BENCH_TIMEOUT", "1200"))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the %d-rank job did not finish within %.0f s; terminating its process group %d\n" % (n, limit, proc.pid))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
+
+
+def roofline_records(res, wl, workload, PS, precision, value):
+    """`roofline` (the recurrent kernel with the larger share of device time), `roofline_other` (the other one), `roofline_pair`
+    (both together) and `roofline_mfma` from the event-timed pass of run_workload."""
+    tm, fr = res["timing"], res["timing_frames"]
+    b_fwd, b_bwd, fl_rec = rec_algorithmic(wl["hidden"])
+    nl_f, nl_b = max(1, tm["rec_fwd"][1]), max(1, tm["rec_bwd"][1])
+    nlayers = len(wl["hidden"])
+    total_ms = sum(v[0] for k, v in tm.items() if k != "exchange")          # (the exchange runs on a stream of its own, beside the rest)
+
+    def roof(bwd):
+        dom = res["kernels"][1] if bwd else res["kernels"][0]          # the kernel the launcher instantiated (cn_layer_recurrent_kernel)
+        ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if bwd else (tm["rec_fwd"][0], nl_f, b_fwd)
+        frames_per_launch = fr / (nl / float(nlayers))      # one launch = one layer pass over one fraction
+        bytes_per_launch = bpf / nlayers * frames_per_launch
+        avg_s = ms / nl * 1e-3
+        ach = bytes_per_launch / avg_s / 1e9
+        traffic, src = (None, None)
+        if workload == "timit_3x250_blstm_H125" and PS == 50 and precision == "bf16":
+            tb, src = pmc_bytes_per_launch(dom.split("<")[0])
+            traffic = tb / avg_s / 1e9 if tb else None
+        return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms / nl, "launches": nl,
+                "share_of_device_time": ms / total_ms}
+
+    out = {}
+    bwd_dom = tm["rec_bwd"][0] >= tm["rec_fwd"][0]        # the larger share, whichever it is
+    out["roofline"] = roof(bwd_dom)
+    out["roofline"]["note"] = ("latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
+                               "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items()))
+    out["roofline_other"] = roof(not bwd_dom)
+    pair_ms = tm["rec_fwd"][0] + tm["rec_bwd"][0]
+    pair_bytes = (b_fwd + b_bwd) * fr
+    out["roofline_pair"] = {"kernels": list(res["kernels"]), "bound": "hbm", "achieved": pair_bytes / (pair_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                            "unit": "GB/s", "frac": pair_bytes / (pair_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "share_of_device_time": pair_ms / total_ms}
+    fpf = flops_per_frame(wl["P"], wl["hidden"], wl["C"])
+    gemm_ms = tm["gemm_wide"][0] + tm["gemm_grad"][0]
+    gemm_fl = (fpf - fl_rec * 2) * fr
+    out["roofline_mfma"] = {"gate_gemms_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None,
+                            "recurrent_tflops": fl_rec * 2 * fr / (pair_ms * 1e-3) / 1e12 if pair_ms else None,
+                            "whole_step_tflops": fpf * value / 1e12, "peak": PEAK_MFMA_TFLOPS.get(precision, 2500.0 / 3),
+                            "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
+    return out
 
 
 def main():
@@ -155,6 +220,8 @@ def main():
         # imported or any GPU call is made here (a process that has initialised the GPU must not exec), relay
         # rank 0's JSON line (the children inherit stdout) and hand the launcher's exit code on.
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if launched and os.environ.get("CN_BENCH_TEST_HANG") in (os.environ.get("RANK"), "all"):
+        time.sleep(3600)        # test hook (tests/test_parallel_gloo.py): a rank that never reaches the rendezvous
     if launched and int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     wl0 = WORKLOADS[args.workload]
@@ -179,11 +246,30 @@ def main():
                          % (world, world, torch.cuda.device_count()))
     device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
+    rendezvous_s = float(os.environ.get("CN_BENCH_RENDEZVOUS_TIMEOUT", "180"))
     if world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1":
+        import datetime
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=rendezvous_s))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=rendezvous_s))
+
+    def bounded(what, seconds, fn, *a):
+        """Run a blocking collective set-up call under a watchdog: a rank whose call does not return in time says which rank and
+        which call on stderr and ends the process with code 3 (exiting is always allowed; the launcher then ends the others)."""
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(seconds):
+                sys.stderr.write("bench.py: rank %d of %d: %s did not complete within %.0f s (a rank missing from the rendezvous?)\n" % (rank, world, what, seconds))
+                sys.stderr.flush()
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            return fn(*a)
+        finally:
+            done.set()
 
     pkg = ge.load_package()
     dev = torch.device("cuda", device_index)
@@ -217,6 +303,7 @@ def main():
         return [float(x) for x in t]
 
     def run_workload(name, steps, warmup, precision, roofline_pass=False, host_pass=False, min_seconds=0.5):
+        """-> (result dict, workload): `steps` timed steps per repetition (median of enough repetitions for min_seconds)"""
         wl = WORKLOADS[name]
         PS = args.parallel_sequences if name == args.workload else wl.get("PS", 50)
         tmin = args.tmin if name == args.workload else wl.get("tmin", 250)
@@ -233,7 +320,8 @@ def main():
             uid = [net.comm_unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            net.comm_init(uid[0], rank, world)
+            bounded("cn_comm_init (ncclCommInitRank)", rendezvous_s, net.comm_init, uid[0], rank, world)
+            comm_world = net.comm_info()[1]                       # what RCCL itself reports (ncclCommCount), not WORLD_SIZE
         # fractions resident in HBM (torch owns the device memory)
         dfr, keep = [], []
         for f in fracs:
@@ -296,8 +384,13 @@ def main():
                "seconds_min": float(min(dts)), "seconds_max": float(max(dts)), "timed_total_s": float(sum(dts)),
                "weights": int(count), "PS": PS, "tmin": tmin, "tmax": tmax,
                "kernels": (net.recurrent_kernel(False), net.recurrent_kernel(True))}
-        err_sum, correct = net.loss_read()
+        # epoch sums: over all ranks through the library's communicator when it is bound (cn_loss_read_global), so that the
+        # record compares with a single-process run over the union of the ranks' fractions
+        err_sum, correct = net.loss_read_global() if native_comm else net.loss_read()
         res["error_sum"] = err_sum
+        if native_comm:
+            lo_hi = allmax([float(comm_world), -float(comm_world)])
+            res["rccl_ranks"] = (int(-lo_hi[1]), int(lo_hi[0]))      # (min, max) over ranks
         # what warm-up + the FIRST repetition's steps did to the weights is not separable from later repetitions; the
         # data-parallel equivalence test runs with min_seconds = 0 (CN_BENCH_MIN_SECONDS=0), i.e. one repetition
         upd = (wts.double() - w0.double())
@@ -324,7 +417,7 @@ def main():
             for i in range(steps):
                 fr2 += step(warmup + i)
             net.synchronize()
-            res["timing"] = net.timing_read(); res["timing_frames"] = fr2
+            res["timing"] = net.timing_read(); res["timing_frames"] = fr2; res["timing_steps"] = steps
             net.timing_enable(False)
         net.close()
         del keep
@@ -341,13 +434,22 @@ def main():
     if not args.also and world == 1 and args.workload == "timit_3x250_blstm_H125" and not args.no_also:
         also_spec = (["timit_3x500_blstm_H250"] + (["timit_3x250_blstm_H125:bf16x3", "timit_3x500_blstm_H250:bf16x3"] if "bf16x3" in PRECISIONS else [])
                      + ["timit_3x250_blstm_H125:f32"])
+        # BASELINE.json configs[3] and configs[4] as written (one GPU's share of the 8-GPU configs: PS per GPU as in WORKLOADS)
+        also_spec += ["lvcsr_4x512_blstm_8000", "longutt_5x1024_blstm"]
     also = {}
     for spec in also_spec:
         name, _, pr = spec.partition(":")
         pr = pr or args.precision
-        r2, _ = run_workload(name, args.steps, args.warmup, pr, min_seconds=min(min_seconds, 0.25))
-        also[spec] = {"value": r2["frames"] / r2["seconds"], "unit": "frames/s", "dtype": pr, "ms_per_step": 1e3 * r2["seconds"] / args.steps,
-                      "repeats": r2["repeats"]}
+        big = name in ("lvcsr_4x512_blstm_8000", "longutt_5x1024_blstm")
+        st2, wu2 = (min(args.steps, 5), min(args.warmup, 2)) if big else (args.steps, args.warmup)
+        r2, wl2 = run_workload(name, st2, wu2, pr, roofline_pass=big, min_seconds=0 if big else min(min_seconds, 0.25))
+        v2 = r2["frames"] / r2["seconds"]
+        also[spec] = {"value": v2, "unit": "frames/s", "dtype": pr, "ms_per_step": 1e3 * r2["seconds"] / st2, "steps": st2, "repeats": r2["repeats"],
+                      "parallel_sequences": r2["PS"], "seq_len": "U[%d,%d]" % (r2["tmin"], r2["tmax"])}
+        if big and "timing" in r2:
+            rr = roofline_records(r2, wl2, name, r2["PS"], pr, v2)
+            also[spec].update({"roofline": rr["roofline"], "roofline_other": rr["roofline_other"], "roofline_pair": rr["roofline_pair"],
+                               "roofline_mfma": rr["roofline_mfma"]})
 
     if rank == 0:
         exch = "none"
@@ -374,45 +476,13 @@ def main():
                                 "note": "same steps with every fraction handed over as HOST buffers through cn_fraction_load (pinned staging, upload of "
                                         "fraction k+1 under the compute of fraction k, re-layout kernel); PCIe-inclusive, informational, never `value`"}
         if "timing" in res:
-            tm, fr = res["timing"], res["timing_frames"]
-            b_fwd, b_bwd, fl_rec = rec_algorithmic(wl["hidden"])
-            nl_f, nl_b = max(1, tm["rec_fwd"][1]), max(1, tm["rec_bwd"][1])
-            # The dominant kernel is the recurrent kernel with the larger share of device time.  Since round 2 the forward and the
-            # backward kernel are within a per cent of each other; inside that noise band (3 %) the backward kernel -- the one with
-            # more algorithmic bytes per frame, reported since round 1 -- stays the reference, and the other one is always reported
-            # beside it (`roofline_other`) so that neither number hides.
-            bwd_dom = tm["rec_bwd"][0] >= 0.97 * tm["rec_fwd"][0]
-            nlayers = len(wl["hidden"])
-            total_ms = sum(v[0] for v in tm.values())
-
-            def roof(bwd):
-                dom = res["kernels"][1] if bwd else res["kernels"][0]          # the kernel that actually ran (cluster or single-CU)
-                ms, nl, bpf = (tm["rec_bwd"][0], nl_b, b_bwd) if bwd else (tm["rec_fwd"][0], nl_f, b_fwd)
-                frames_per_launch = fr / (nl / float(nlayers))      # one launch = one layer pass over one fraction
-                bytes_per_launch = bpf / nlayers * frames_per_launch
-                avg_s = ms / nl * 1e-3
-                ach = bytes_per_launch / avg_s / 1e9
-                traffic, src = (None, None)
-                if args.workload == "timit_3x250_blstm_H125" and args.parallel_sequences == 50 and args.precision == "bf16":
-                    tb, src = pmc_bytes_per_launch(dom.split("<")[0])
-                    traffic = tb / avg_s / 1e9 if tb else None
-                return {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": ach / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": src,
-                        "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_ms": ms / nl, "launches": nl,
-                        "share_of_device_time": ms / total_ms}
-
-            out["roofline"] = roof(bwd_dom)
-            out["roofline"]["note"] = ("latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
-                                       "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items()))
-            out["roofline_other"] = roof(not bwd_dom)
-            fpf = flops_per_frame(wl["P"], wl["hidden"], wl["C"])
-            gemm_ms = tm["gemm_wide"][0] + tm["gemm_grad"][0]
-            rec_ms = tm["rec_fwd"][0] + tm["rec_bwd"][0]
-            gemm_fl = (fpf - fl_rec * 2) * fr
-            out["roofline_mfma"] = {"gate_gemms_tflops": gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None,
-                                    "recurrent_tflops": fl_rec * 2 * fr / (rec_ms * 1e-3) / 1e12 if rec_ms else None,
-                                    "whole_step_tflops": fpf * value / 1e12, "peak": PEAK_MFMA_TFLOPS.get(args.precision, 2500.0 / 3),
-                                    "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
+            out.update(roofline_records(res, wl, args.workload, args.parallel_sequences, args.precision, value))
+            if native_comm:
+                ex = res["timing"].get("exchange", (0.0, 0))
+                out["exchange"] = {"rccl_ranks_min": res["rccl_ranks"][0], "rccl_ranks_max": res["rccl_ranks"][1],
+                                   "allreduce_ms_per_step": ex[0] / max(1, res["timing_steps"]), "allreduces_per_step": ex[1] / max(1, res["timing_steps"]),
+                                   "note": "ranks as RCCL's own communicator reports them (cn_comm_info); device time of the per-layer all-reduces from "
+                                           "hipEvents on the library's communication stream during the event-timed pass"}
         if also:
             out["also"] = also
         if world == 1 and not args.no_driver_leg:
@@ -424,13 +494,14 @@ def main():
         dist.destroy_process_group()
 
 
-def time_oracle_step(pkg, orc, wl, args, PS, tlo, thi):
-    """One training step (load, forward, error, backward, update) of the oracle on one synthetic fraction; 1 thread."""
+def time_oracle_step(pkg, orc, wl, args, PS, tlo, thi, backend="oracle"):
+    """One training step (load, forward, error, backward, update) of the oracle on one synthetic fraction; 1 thread.
+    backend "ref": the same call sequence through oracle/_ref, the reference's own compiled functors and Cpu GEMM."""
     layers = net_desc(wl["P"], wl["hidden"], wl["C"])
     weights = make_weights(layers, 1234)
     rng = np.random.RandomState(99)
     frac = synth_fraction(pkg, rng, PS, wl["P"], wl["C"], tlo, thi)
-    net = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    net = orc.OracleNetwork(layers, weights, PS, frac["T"], backend=backend)
     t0 = time.perf_counter()
     net.load_sequences(frac); net.compute_forward_pass(); net.calculate_error(); net.count_correct_classifications()
     net.compute_backward_pass(); net.update_weights(args.lr, args.momentum)
@@ -499,6 +570,12 @@ def cpu_baseline(pkg, wl, args, precisions):
         thi = max(4, int(budget / PS * 1.15)); tlo = max(2, int(thi * 0.75))
     v, sample = time_oracle_step(pkg, orc, wl, args, PS, tlo, thi)
     out = {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample}
+    if orc.ref_available():
+        # oracle/_ref travelled to this box: the reference's OWN object code (its functors and helpers::Matrix<Cpu>, compiled from
+        # /root/reference in the build container) on the same sample is the baseline; the restatement's figure stays beside it
+        vr, sample_r = time_oracle_step(pkg, orc, wl, args, PS, tlo, thi, backend="ref")
+        out = {"value": vr, "unit": "frames/s", "cores": 1, "kind": "reference", "sample": sample_r + " (oracle/_ref: reference functors + Cpu GEMM)",
+               "port": {"value": v, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample}}
     w0 = WORKLOADS["timit_1x128_lstm"]
     v0, sample0 = time_oracle_step(pkg, orc, w0, args, 16, 250, 350)
     out["configs0_timit_1x128_lstm"] = {"value": v0, "unit": "frames/s", "cores": 1, "kind": "port", "sample": sample0}

@@ -256,7 +256,8 @@ int  cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, in
 
 /* Wrap hipEvents around the kernels of one class on the ctx stream and accumulate their device
  * time; used by bench.py for the live roofline figure.  kernel_class: 0 = recurrent forward,
- * 1 = recurrent backward, 2 = N-wide gate GEMMs, 3 = weight-gradient GEMMs, 4 = everything else. */
+ * 1 = recurrent backward, 2 = N-wide gate GEMMs, 3 = weight-gradient GEMMs, 4 = everything else,
+ * 5 = the gradient all-reduces of cn_allreduce_grads (events on the communication stream). */
 int  cn_ctx_timing_enable(cn_ctx *ctx, int enable);
 int  cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches); /* [sync] */
 int  cn_ctx_timing_reset(cn_ctx *ctx);

@@ -119,8 +119,8 @@ struct cn_ctx {
     struct Span { hipEvent_t a, b; };
     std::vector<Span> spans[KC_COUNT];
     std::vector<hipEvent_t> free_events;
-    double acc_ms[KC_COUNT] = {0, 0, 0, 0, 0};
-    long acc_n[KC_COUNT] = {0, 0, 0, 0, 0};
+    double acc_ms[KC_COUNT] = {};
+    long acc_n[KC_COUNT] = {};
 
     size_t esz() const { return f32 ? 4 : 2; }
 };
@@ -359,6 +359,7 @@ void timing_collect(cn_ctx *c)
     HIP_CHECK(hipStreamSynchronize(c->stream));
     if (c->side) HIP_CHECK(hipStreamSynchronize(c->side));
     if (c->side_slow) HIP_CHECK(hipStreamSynchronize(c->side_slow));
+    if (c->comm_stream) HIP_CHECK(hipStreamSynchronize(c->comm_stream));
     for (int k = 0; k < KC_COUNT; ++k) {
         for (auto &sp : c->spans[k]) {
             float ms = 0.f;
@@ -471,6 +472,15 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.bias = l->bias;
     r.rpl = c->rpl;
     r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = c->num_cus;
+    // With a communicator bound, RCCL's persistent workgroups hold CUs on the communication stream while they wait for peer
+    // ranks, beside the recurrent kernel of the layer below.  A cluster grid needs ALL its members resident (spin-wait
+    // hand-off), so it must fit what RCCL leaves: the grid is sized against num_cus minus a margin for RCCL's channels
+    // (CN_COMM_CU_MARGIN, default 32 -- RCCL's MI300-class defaults stay at or below that many workgroups per collective);
+    // a grid that no longer fits takes the streaming kernels, which make no residency assumption.
+    if (c->comm) {
+        static const int margin = getenv("CN_COMM_CU_MARGIN") ? atoi(getenv("CN_COMM_CU_MARGIN")) : 32;
+        r.num_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
+    }
     r.kname = nullptr;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
     if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }
@@ -869,12 +879,14 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
             HIP_CHECK(hipEventRecord(ctx->ev_comm_fork, ctx->stream));
             HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_fork, 0));
             float *g = ctx->arena + ctx->total;
+            Timed tm(ctx, KC_COMM, ctx->comm_stream);
             if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
         } else {
             for (int i = 0; i < n; ++i) {
                 cn_layer *l = layers[i];
                 if (!l || l->ctx != ctx || !l->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_allreduce_grads: not a trainable layer of this context");
                 stream_wait_layer(l, ctx->comm_stream);
+                Timed tm(ctx, KC_COMM, ctx->comm_stream);          // (events on the communication stream: the exchange itself, not its wait)
                 RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
             }
         }

@@ -16,7 +16,7 @@ namespace cn {
 enum Act { ACT_TANH = 0, ACT_LOGISTIC = 1, ACT_IDENTITY = 2 };
 
 // kernel classes for cn_ctx_timing_*
-enum KClass { KC_REC_FWD = 0, KC_REC_BWD = 1, KC_GEMM_WIDE = 2, KC_GEMM_GRAD = 3, KC_OTHER = 4, KC_COUNT = 5 };
+enum KClass { KC_REC_FWD = 0, KC_REC_BWD = 1, KC_GEMM_WIDE = 2, KC_GEMM_GRAD = 3, KC_OTHER = 4, KC_COMM = 5, KC_COUNT = 6 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 

@@ -985,11 +985,15 @@ static size_t s2_lds_bytes(int prec, bool bwd, int Hp, int T)
     return 2 * (size_t)PLANES * (bwd ? 9 : 5) * pitch + (bwd ? (((size_t)T * 2 + 15) & ~(size_t)15) : 0);
 }
 
-// The shape applies when the layer is one the row-pair products cover (bf16 / split-bf16, Hp = 64 or 128), the caller
+// The shape applies when the layer is one the row-pair products cover (bf16, Hp = 64 or 128), the caller
 // chose one sequence per lane (PS * dirs / 4 workgroups fit the chip: rpl == 1), and twice that grid still leaves every
 // workgroup a CU of its own.
 bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
 {
+    // bf16 only: the split-bf16 mode issues three MFMAs per product and is bound by the MFMA pipe, which this cut does not
+    // relieve (48 MFMAs per SIMD and step either way) while it takes away the second wave that hides the first one's VALU
+    // work: measured 6.7 M against 7.7 M frames/s on the headline net (CN_S2_X3=1 keeps it selectable for the tests)
+    if (prec == P_X3 && !getenv("CN_S2_X3")) return false;
     if (getenv("CN_NO_S2") || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
     if (p.dirs * (p.PS / 2) > p.num_cus) return false;
     return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;

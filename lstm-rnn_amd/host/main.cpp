@@ -3,6 +3,7 @@
 // single_csv / csv / htk).  Exit code 2 and "FAILED: msg" on any error like main.cpp:492-495.
 #include <signal.h>
 #include <sys/stat.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -340,7 +341,10 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
             feedForward(config, neuralNetwork, *feedForwardSet);
         }
     } catch (const std::exception &e) {
+        // the console protocol of the reference (main.cpp:488-491) on stdout; a data-parallel rank also says so on stderr, which
+        // every rank shares: ranks > 0 have no stdout, and the parent only sees exit codes
         printf("FAILED: %s\n", e.what());
+        if (dp.active) { fprintf(stderr, "rank %d: FAILED: %s\n", dp.rank, e.what()); fflush(stderr); }
         return 2;
     }
     return 0;
@@ -364,8 +368,14 @@ int runDataParallel(const Configuration &config, int world)
     std::vector<pid_t> pids(world, -1);
     for (int r = 0; r < world; ++r) {
         pid_t pid = fork();
-        if (pid < 0) throw std::runtime_error("fork() failed");
+        if (pid < 0) {
+            // the ranks already started would wait for the missing ones in the rendezvous for ever
+            for (int k = 0; k < r; ++k) { kill(pids[k], SIGTERM); waitpid(pids[k], nullptr, 0); }
+            throw std::runtime_error("fork() failed for rank " + std::to_string(r));
+        }
         if (pid == 0) {
+            prctl(PR_SET_PDEATHSIG, SIGTERM);            // a rank does not outlive the launcher (SIGKILL / SIGTERM of the parent)
+            if (getppid() == 1) _exit(2);                // (the parent died between fork and prctl)
             DataParallel dp;
             dp.rank = r; dp.world = world; dp.active = true;
             if (r == 0) { for (int k = 1; k < world; ++k) { dp.idWriteFds.push_back(writeFd[k]); close(readFd[k]); } }
@@ -388,9 +398,12 @@ int runDataParallel(const Configuration &config, int world)
         if (done < 0) break;
         --left;
         const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
+        int which = -1;
+        for (int r = 0; r < world; ++r) if (pids[r] == done) { which = r; pids[r] = -1; }     // reaped: never signalled again
+        if (code != 0) { fprintf(stderr, "rank %d exited with code %d\n", which, code); fflush(stderr); }
         if (code != 0 && rc == 0) {
             rc = code;
-            for (int r = 0; r < world; ++r) if (pids[r] != done) kill(pids[r], SIGTERM);
+            for (int r = 0; r < world; ++r) if (pids[r] > 0) kill(pids[r], SIGTERM);
         }
     }
     return rc;

@@ -380,7 +380,7 @@ class NeuralNetwork:
         B.check(self.lib.cn_ctx_timing_reset(self.ctx), self.ctx)
 
     def timing_read(self):
-        names = ["rec_fwd", "rec_bwd", "gemm_wide", "gemm_grad", "other"]
+        names = ["rec_fwd", "rec_bwd", "gemm_wide", "gemm_grad", "other", "exchange"]
         out = {}
         for k, nm in enumerate(names):
             ms, n = C.c_double(), C.c_int64()

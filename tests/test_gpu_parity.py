@@ -363,13 +363,12 @@ def test_cluster_kernel_matches_streaming_kernel(pkg, orc, size, scale):
 def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, shape, T):
     """The 2:4 row-pair MFMA path of the register-resident kernels (bf16 and split-bf16 modes, Hp = 64 / 128) in its three
     cuts: "s2" = two sequences per workgroup, 32 units per wave (cn_lstm_s2.hip; what a grid that fits the chip gets), and
-    the 4- and 8-sequence workgroups of cn_lstm.hip with one and two sequences per lane (CN_RPL; CN_NO_S2 keeps the s2 cut
-    away).  Loop shapes T = 1, 3, 8, ragged lengths, a partly filled last sequence group, one- and two-directional.
+    the 4- and 8-sequence workgroups of cn_lstm.hip with one and two sequences per lane (CN_RPL).  Loop shapes T = 1, 3, 8, ragged lengths, a partly filled last sequence group, one- and two-directional.
     Checked in the split-bf16 mode at the fp32 tolerances, which a misplaced operand element cannot meet."""
     rpl = 2 if shape == "rpl2" else 1
     monkeypatch.setenv("CN_RPL", str(rpl))
-    if shape == "rpl1":
-        monkeypatch.setenv("CN_NO_S2", "1")
+    if shape == "s2":
+        monkeypatch.setenv("CN_S2_X3", "1")          # (the split-bf16 mode does not take this cut by default: it is MFMA bound)
     rng = np.random.RandomState(300 + T + rpl + size)          # (same data for "s2" and "rpl1")
     P, C, PS = 6, 4, 13
     layers = net_desc(P, [(kind, size)], C)

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -87,3 +88,21 @@ def test_two_rank_allreduce_equals_single_fraction(pkg, orc):
     for a, b, l in zip(w0, w1, net.trainable_layers()):
         assert np.array_equal(a, b)                                   # replicas stay bit-identical
         assert np.abs(a - l.weights).max() < 1e-6                     # = the big fraction up to fp32 summation order
+
+
+def test_launcher_ends_a_job_whose_ranks_never_arrive():
+    """`python bench.py --gpus 2` starts its own ranks from a process that has touched no GPU; when the ranks never reach the
+    rendezvous (here: they sleep, CN_BENCH_TEST_HANG) the launcher terminates the ranks' process group after
+    CN_BENCH_TIMEOUT seconds and returns 124 instead of hanging the driver; nothing of the job is left behind."""
+    import re, subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CN_BENCH_TIMEOUT="10", CN_BENCH_TEST_HANG="all")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124 and time.time() - t0 < 60, (p.returncode, p.stderr[-500:])
+    m = re.search(r"terminating its process group (\d+)", p.stderr)
+    assert m, p.stderr[-500:]
+    time.sleep(0.5)
+    with pytest.raises(ProcessLookupError):
+        os.killpg(int(m.group(1)), 0)
