@@ -873,6 +873,11 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
         require_comm(ctx, "cn_allreduce_grads");
         HIP_CHECK(hipSetDevice(ctx->device));
         finalize(ctx);
+        // CN_COMM_TEST_DOUBLE (tests/test_gpu_parallel.py): the collective is replaced by a kernel on the communication stream
+        // that doubles the gradient -- what a two-rank all-reduce of equal shards does --, so that the ORDER of gradient work,
+        // exchange and update can be checked on a one-GPU box: a reduction that starts early or an update that does not wait
+        // shows in the trained weights
+        const bool test_double = getenv("CN_COMM_TEST_DOUBLE") != nullptr;
         if (n == 0) {
             // the whole arena in one exchange: every gradient GEMM first, then fork the communication stream
             join_side(ctx);
@@ -880,14 +885,16 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
             HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_fork, 0));
             float *g = ctx->arena + ctx->total;
             Timed tm(ctx, KC_COMM, ctx->comm_stream);
-            if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
+            if (test_double) launch_scale(ctx->comm_stream, g, ctx->total, 2.0f);
+            else if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
         } else {
             for (int i = 0; i < n; ++i) {
                 cn_layer *l = layers[i];
                 if (!l || l->ctx != ctx || !l->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_allreduce_grads: not a trainable layer of this context");
                 stream_wait_layer(l, ctx->comm_stream);
                 Timed tm(ctx, KC_COMM, ctx->comm_stream);          // (events on the communication stream: the exchange itself, not its wait)
-                RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
+                if (test_double) launch_scale(ctx->comm_stream, l->wu, (size_t)l->nw, 2.0f);
+                else RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
             }
         }
         HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));

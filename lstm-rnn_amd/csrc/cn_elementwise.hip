@@ -904,6 +904,17 @@ void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N
 // ---------------------------------------------------------------------------------------------
 // optimizer step
 // ---------------------------------------------------------------------------------------------
+// x *= a (test double of the gradient exchange, cn_allreduce_grads with CN_COMM_TEST_DOUBLE: what a two-rank all-reduce of
+// equal shards does to a gradient)
+__global__ void scale_kernel(float *x, size_t n, float a)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= a;
+}
+void launch_scale(hipStream_t s, float *x, size_t n, float a)
+{
+    if (n) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024)), dim3(256), 0, s, x, n, a);
+}
+
 __global__ void sgd_kernel(float *w, const float *wu, float *wd, size_t n, float lr, float mom)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -165,6 +165,7 @@ void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int 
 void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
 // sse
 // UpdateWeightFn over a flat range
+void launch_scale(hipStream_t s, float *x, size_t n, float a);     // x *= a
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
 // (host row n = t*PS + s maps to device row t*PSp + s)

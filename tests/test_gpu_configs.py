@@ -272,3 +272,43 @@ def test_all_dummy_fraction_contributes_nothing(pkg):
             assert e == 0.0 and c == 0
             for lay in net.trainable_layers():
                 assert np.all(lay.weight_updates() == 0.0), lay.name
+
+
+@pytest.mark.parametrize("mode,post_bound,w_bound", [("f32", 2.5e-4, 2.5e-4), ("bf16x3", 8e-3, 8e-3)])
+def test_config1_drift_through_training_stays_inside_the_measured_bound(pkg, orc, mode, post_bound, w_bound):
+    """The real 39 -> 3 x blstm250 -> softmax183 net trained for 20 momentum-SGD updates (lr 1e-2, momentum 0.9) on a learnable
+    task, HIP path against the oracle doing the same.  Single-pass parity is < 1e-4 in both modes (test_gpu_parity.py); what
+    a training run ADDS is measured by bench.py's `parity_vs_cpu` after 40 updates: f32 0.7-1.1e-4 on the posteriors (fp32
+    summation order + split-K atomics, amplified by the updates), bf16x3 3.3-4.3e-3 (2^-16 per product term).  This test pins
+    those measured levels with a margin of ~2x so that a regression of either mode is caught; it is NOT the north-star
+    bound, which is a single-pass statement."""
+    rng = np.random.RandomState(77)
+    P, C, nseq, tlen = 39, 183, 6, 40
+    layers = net_desc(P, [("blstm", 250)] * 3, C)
+    weights = random_weights(layers, rng, 0.1)
+    proj = rng.randn(2 * P, C).astype(np.float32)
+    fracs = []
+    for _ in range(2):
+        xs = [rng.randn(tlen - (i % 3), P).astype(np.float32) for i in range(nseq)]
+        ts = [np.argmax(np.hstack([x, np.vstack([np.zeros((1, P), np.float32), x[:-1]])]) @ proj, axis=1).astype(np.int32) for x in xs]
+        fracs.append(pkg.make_fraction(xs, ts, nseq))
+
+    def train(net):
+        errs = []
+        for k in range(20):
+            net.load_sequences(fracs[k % 2]); net.compute_forward_pass(); errs.append(net.calculate_error())
+            net.compute_backward_pass(); net.update_weights(1e-2, 0.9)
+        net.load_sequences(fracs[0]); net.compute_forward_pass()
+        return errs
+    ref = orc.OracleNetwork(layers, weights, nseq, tlen)
+    eref = train(ref)
+    assert eref[-1] < 0.95 * eref[0]                      # the task is learnable: the posteriors have moved
+    real = real_mask(fracs[0])
+    yr = ref.outputs().reshape(-1, C)[real]
+    with pkg.NeuralNetwork(layers, weights, nseq, tlen, precision=pkg.PREC_F32 if mode == "f32" else pkg.PREC_BF16X3) as net:
+        e = train(net)
+        y = net.outputs().reshape(-1, C)[real]
+        post = float(np.abs(y - yr).max())
+        wmax = max(float(np.abs(l.weights() - ref.layer(l.name).weights).max()) for l in net.trainable_layers())
+        assert abs(e[-1] - eref[-1]) < 2e-3 * eref[-1], (e[-1], eref[-1])
+        assert post < post_bound and wmax < w_bound, (mode, post, wmax)

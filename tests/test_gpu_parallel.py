@@ -246,6 +246,48 @@ def test_per_layer_exchange_is_ordered_between_gradient_and_update(pkg):
     assert np.linalg.norm(trained["exchange"] - trained["plain"]) < 1e-3 * moved
 
 
+@pytest.mark.parametrize("net_kind", ["blstm250x2_s2", "blstm1024x2_cluster"])
+def test_library_exchange_is_ordered_between_gradient_and_update(pkg, monkeypatch, net_kind):
+    """The same ordering check for the LIBRARY's own exchange (compute_backward_pass_dp = cn_layer_backward + cn_allreduce_grads
+    per layer on the library's communication stream, then the fused update): a one-rank communicator is bound and
+    CN_COMM_TEST_DOUBLE replaces ncclAllReduce by a kernel that doubles the layer's weightUpdates on that stream.  Three
+    momentum-SGD steps must equal the plain path at twice the learning rate -- on the headline kernels (hand-written s2
+    loops) and on a network of 8-CU cluster kernels (blstm1024: spin-wait hand-off between CUs running beside the
+    communication stream's work and the gradient GEMMs of the side stream)."""
+    rng = np.random.RandomState(23)
+    if net_kind == "blstm250x2_s2":
+        P, C, PS, T, sizes, scale = 39, 40, 24, 120, [250, 250], 0.08
+    else:
+        P, C, PS, T, sizes, scale = 39, 40, 8, 60, [1024, 1024], 0.03
+    layers = net_desc(P, [("blstm", n) for n in sizes], C)
+    weights = random_weights(layers, rng, scale)
+    xs, ts = random_sequences(rng, [T - (i % 7) for i in range(PS)], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    trained, kernels = {}, {}
+    for mode, lr in (("plain", 2e-4), ("exchange", 1e-4)):
+        with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_BF16) as net:
+            if mode == "exchange":
+                monkeypatch.setenv("CN_COMM_TEST_DOUBLE", "1")
+                net.comm_init(net.comm_unique_id(), 0, 1)
+            for _ in range(3):
+                net.load_sequences(frac); net.compute_forward_pass()
+                if mode == "plain":
+                    net.compute_backward_pass()
+                else:
+                    net.compute_backward_pass_dp()
+                net.update_weights_fused(lr, 0.9)
+            net.synchronize()
+            kernels[mode] = net.recurrent_kernel(True)
+            trained[mode] = np.concatenate([l.weights() for l in net.trainable_layers()])
+    want = "lstm_bwd_s2_asm_kernel" if net_kind == "blstm250x2_s2" else "lstm_bwd_cluster_kernel<0,512,64,1>"
+    assert kernels["plain"] == want and kernels["exchange"] == want
+    start = np.concatenate([np.concatenate([np.asarray(weights[l["name"]][k], np.float32) for k in ("input", "bias", "internal")])
+                            for l in layers if l["name"] in weights])
+    moved = np.linalg.norm(trained["plain"] - start)
+    assert moved > 0
+    assert np.linalg.norm(trained["exchange"] - trained["plain"]) < 1e-3 * moved
+
+
 def test_rccl_allreduce_on_aliased_arena():
     """RCCL (torch.distributed backend nccl, one rank) all-reduces the aliased weightUpdates arena in place."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90))
