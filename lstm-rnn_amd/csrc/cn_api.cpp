@@ -82,7 +82,7 @@ struct cn_ctx {
     // N = T*PSp frames on the device, Next = T*PS frames in host layouts.
     int PS = 0, PSp = 0, rpl = 1, maxT = 0, T = 0, Tmin = 0, N = 0, Next = 0, numSeqs = 0;
     bool loaded = false;
-    char *d_pat = nullptr;
+    char *d_pat = nullptr, *d_pat_raw = nullptr;      // [maxN] pattern types inside an allocation with guard steps
     int *d_tcls = nullptr;
     float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
     float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
@@ -187,6 +187,16 @@ void *dalloc(cn_layer *l, size_t bytes)
     HIP_CHECK(hipMemsetAsync(p, 0, bytes, l->ctx->stream));
     l->owned.push_back(p);
     return p;
+}
+
+// A per-frame buffer of an LSTM layer with CN_GUARD_STEPS time steps of zeros in front of frame 0 and behind frame maxN: the
+// hand-written recurrent loops (cn_lstm_s2.hip) prefetch several steps ahead in EVERY step, also in the last ones, where the
+// target lies outside [0, T) -- those loads must hit mapped memory, their values are never used.  (Nobody writes the guards:
+// every kernel addresses frames 0 .. N-1 from the returned pointer.)
+void *dalloc_guarded(cn_layer *l, size_t bytes, size_t bytes_per_step)
+{
+    const size_t guard = (size_t)CN_GUARD_STEPS * bytes_per_step;
+    return (char *)dalloc(l, bytes + 2 * guard) + guard;
 }
 
 // ---- CU-masked stream ------------------------------------------------------------------------
@@ -762,7 +772,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
-        hipFree(ctx->d_pat); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
+        hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
     });
@@ -947,9 +957,13 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->stage_in = (float *)dalloc(l, maxN * size * sizeof(float));
             l->out_op = dalloc(l, maxN * l->Lp * e);
             ctx->PS = l->PS; ctx->maxT = l->maxT;
-            HIP_CHECK(hipMalloc((void **)&ctx->d_pat, maxN));
+            {   // pattern types, with guard steps of PATTYPE_NONE on both sides (dalloc_guarded)
+                const size_t guard = (size_t)CN_GUARD_STEPS * ctx->PSp;
+                HIP_CHECK(hipMalloc((void **)&ctx->d_pat_raw, maxN + 2 * guard));
+                HIP_CHECK(hipMemsetAsync(ctx->d_pat_raw, 0, maxN + 2 * guard, ctx->stream));   // pad slots: PATTYPE_NONE forever
+                ctx->d_pat = ctx->d_pat_raw + guard;
+            }
             HIP_CHECK(hipMalloc((void **)&ctx->d_tcls, maxN * sizeof(int)));
-            HIP_CHECK(hipMemsetAsync(ctx->d_pat, 0, maxN, ctx->stream));                       // pad slots: PATTYPE_NONE forever
             HIP_CHECK(hipMemsetAsync(ctx->d_tcls, 0xFF, maxN * sizeof(int), ctx->stream));     // pad slots: target class -1
             break; }
         case CN_LAYER_LSTM:
@@ -978,10 +992,10 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
                                              "per LSTM layer; use fewer parallel sequences");
             l->nw = size * (4 * (l->P + 1) + 4 * l->H + 3);                                            // LstmLayer.cu:525
             l->out_op = dalloc(l, maxN * l->Lp * e);
-            l->err = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
-            l->acts = (float *)dalloc(l, maxN * R * sizeof(float));
-            l->cell = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
-            l->th = (float *)dalloc(l, maxN * l->Lp * sizeof(float));
+            l->err = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
+            l->acts = (float *)dalloc_guarded(l, maxN * R * sizeof(float), (size_t)ctx->PSp * R * sizeof(float));
+            l->cell = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
+            l->th = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
             l->delta_op = dalloc(l, maxN * R * e);
             l->Win = dalloc(l, R * l->Pp * e); l->WinT = dalloc(l, R * l->Pp * e);
             l->Wrec = dalloc(l, R * l->Hp * e); l->WrecT = dalloc(l, R * l->Hp * e);

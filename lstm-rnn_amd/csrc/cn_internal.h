@@ -94,6 +94,9 @@ struct LstmRec {
     char *kname;                  // nullable, CN_KNAME_LEN bytes: the launcher writes the name of the kernel it instantiated
 };
 constexpr int CN_KNAME_LEN = 64;
+// time steps of zeros the library keeps in front of and behind acts / cell / th / err / pat of an LSTM layer (cn_api.cpp:
+// dalloc_guarded): a recurrent loop may load up to this many steps outside [0, T)
+constexpr int CN_GUARD_STEPS = 6;
 size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T);        // dynamic LDS per workgroup of the single-CU kernels
 bool lstm_rec_resident(int prec, int Hp);                                      // W_rec fragments register resident (single-CU kernels)
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p);

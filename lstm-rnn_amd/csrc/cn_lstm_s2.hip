@@ -638,30 +638,40 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 // backward, bf16, Hp = 128: the time loop written by hand
 // ---------------------------------------------------------------------------------------------
 // As lstm_fwd_s2_asm_kernel: layout, operand order and arithmetic of lstm_bwd_s2_kernel<P_BF16, 128> (bit-equal on real
-// slots), our own instruction stream, ~95 issued instructions per step against hipcc's ~190 -- and software-pipelined:
+// slots), our own instruction stream, ~100 issued instructions per step against hipcc's ~190 -- and software-pipelined:
 // in-kernel stamps (tools/stamps_s2.py) showed a step of one wave per SIMD to be the SUM of its stalls (LDS operands landed
 // 170 cycles after the barrier, 16 MFMAs with two fillers per gap 410, the e-dependent chain of dependent VALU instructions
 // at 6.6 cycles each 125, LDS write + tail 125), so the work is placed where the wave waits anyway:
 //   * "block": everything of ComputeBlockErrorsFn that does not depend on the product -- the activation derivatives, the
 //     carried terms, the dummy-slot factor m -- is formed for step t+1 at the END of step t, between the LDS write and the
 //     barrier; the MFMA phase carries only one cheap filler per gap (a gap hides one VALU instruction, not two);
-//   * the stage registers are therefore dead when their step begins: the prefetch of step t+2 is issued at the TOP of step
-//     t, straight into them (outputErrors into register 0 of the stage's accumulator, the MFMA's C operand, once the sums
-//     are read): two full steps of distance, no copies; two stages, two accumulator sets, loop body of two steps;
+//   * the stage registers are therefore dead when their step begins, and the prefetch is issued at the TOP of a step,
+//     straight into them (outputErrors into register 0 of the stage's accumulator, the MFMA's C operand, once the sums are
+//     read): no copies.  FOUR stages, four steps of distance: what the backward pass reads of a lower layer (gate
+//     activations, cell states, tanh(c): 90 MB written a whole forward pass ago) has left the Infinity Cache, and with two
+//     steps (0.8 us) in flight every workgroup of such a launch waited for HBM every step -- 121 us against 103 us per
+//     300 steps with the same loads served from cache (tools/wgtime_s2.py, diag build CN_S2_DIAG_HOT).  The 128 registers
+//     of W_rec^T fragments live in AGPRs (an MFMA reads its B operand from either file), which is what makes room;
+//   * every step is the same code: the activation buffers carry CN_GUARD_STEPS steps of mapped zeros on both sides
+//     (cn_api.cpp: dalloc_guarded), so the prefetch of the last steps needs no special case; lastCall (LstmLayer.cu:947,981:
+//     no cell state behind the last processed step) is a scalar select on the one register that carries c[prev]; the loop
+//     body is four steps and may be left after any of them;
 //   * the 11 wait states between the last MFMA and the first read of its result are the previous step's gradient sums;
 //   * behind the product: three adds, five multiplies / fmas, four clips, two conversions; no selects (the factor m);
-//   * the step whose prefetch targets the last processed step (lastCall, LstmLayer.cu:947,981: no cell state behind it)
-//     and the last two steps (no prefetch; the last one no block) are separate copies of the body;
 //   * both LDS writes of a lane are one ds_write2_b32, its delta_op store one 8-byte store.
 // Dummy slots as in the forward loop: the pattern type alone decides (for t < minSeqLength the unused slots of a partial
 // fraction carry zero errors, so their deltas are zero either way).
 //
-// Fixed registers (clobbered): stage A: v[224:227] n,i,f,o; v[228:231] / v[232:235] the accumulators of K half 0 / 1;
-// stage B: v[236:239], v[240:243] / v[244:247]; v[248:249] the four bf16 deltas of the step.
+// Fixed registers (clobbered): stage k = 0..3: v[200+12k : 203+12k] n,i,f,o; v[204+12k : 207+12k] / v[208+12k : 211+12k] the
+// accumulators of K half 0 / 1; v[248:249] the four bf16 deltas of the step.
 #ifdef CN_S2_DIAG_NOMFMA
 #define S2B_MF(acc, a, w) ""
 #else
 #define S2B_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#endif
+#ifdef CN_S2_WGTIME
+__device__ unsigned cn_s2_wg_time[256][2];        // diag: loop time of every workgroup of the last backward launch (100 MHz ticks), HW_ID
+extern "C" int cn_dbg_read_wgtime_s2(unsigned *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_s2_wg_time), sizeof(cn_s2_wg_time)); }
 #endif
 // CN_S2_STAMP (tools/stamps_s2.py; never in the shipped build): every wave of workgroup 0 sums s_memtime deltas per step segment
 #ifdef CN_S2_STAMP
@@ -670,7 +680,7 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
 #else
 #define S2B_ST(i) ""
 #endif
-// prefetch of step t+2 into stage X: activations, tanh(c), c[prev], pattern type (outputErrors follow behind the e sum)
+// prefetch of step t+4 into stage X: activations, tanh(c), c[prev], pattern type (outputErrors follow behind the e sum)
 #ifdef CN_S2_DIAG_HOT
 #define S2B_PF(AXT, TH, CP, PT) \
     "global_load_dwordx4 " AXT ", %[oT], %[acts]\n\t" \
@@ -686,24 +696,13 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t"
 #define S2B_PFE(ACCA0) "global_load_dword " ACCA0 ", %[oC], %[errpf]\n\t"
 #endif
-#ifdef CN_S2_DIAG_NOSTORE
-#define S2B_STORE ""
-#else
-#define S2B_STORE "global_store_dwordx2 %[oD], v[248:249], %[delta1]\n\t"
-#endif
-#define S2B_PF_LAST(AXT, TH, CP, PT) \
-    "global_load_dwordx4 " AXT ", %[oA], %[actspf]\n\t" \
-    "global_load_dword %[" TH "], %[oC], %[thpf]\n\t" \
-    "v_mov_b32 %[" CP "], 0\n\t" \
-    "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t"
-#define S2B_NOPF ""
-#define S2B_NOPFE ""
 // the e-independent terms of the step that stage X holds; CN: register that receives c[prev] of that step (the CS of the
-// step after it).  Reads the carries of the step processed before it.
+// step after it), or 0 when that step is the last one (s[last] = all ones then).  Reads the carries of the step before it.
 #define S2B_BLOCK(NI, IG, FG, OG, TH, CP, PT, CN) \
     "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
     "v_fma_f32 %[x0], -" OG ", " OG ", " OG "\n\t" \
     "v_fma_f32 %[x1], -%[" TH "], %[" TH "], 1.0\n\t" \
+    "v_cndmask_b32_e64 %[" CN "], %[" CP "], 0, %[last]\n\t" \
     "v_cndmask_b32_e64 %[m], 1.0, 0, vcc\n\t" \
     "v_mul_f32 %[t2m], %[x0], %[" TH "]\n\t" \
     "v_mul_f32 %[x1], " OG ", %[x1]\n\t" \
@@ -714,7 +713,7 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_fma_f32 %[x0], -" FG ", " FG ", " FG "\n\t" \
     "v_fmac_f32 %[car], %[pi], %[dign]\n\t" \
     "v_fma_f32 %[x1], -" IG ", " IG ", " IG "\n\t" \
-    "v_mul_f32 %[d3m], %[x0], %[" CP "]\n\t" \
+    "v_mul_f32 %[d3m], %[x0], %[" CN "]\n\t" \
     "v_fmac_f32 %[car], %[pf], %[dfgn]\n\t" \
     "v_mul_f32 %[d4m], %[x1], " NI "\n\t" \
     "v_mul_f32 %[t2m], %[t2m], %[m]\n\t" \
@@ -723,15 +722,12 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_mul_f32 %[d2m], %[d2m], %[m]\n\t" \
     "v_mul_f32 %[d3m], %[d3m], %[m]\n\t" \
     "v_mul_f32 %[d4m], %[d4m], %[m]\n\t" \
-    "v_mul_f32 %[fgn], " FG ", %[m]\n\t" \
-    "v_mov_b32 %[" CN "], %[" CP "]\n\t"
-#define S2B_TAIL(VM, BLOCKCODE) "s_waitcnt vmcnt(" VM ")\n\t" BLOCKCODE
-#define S2B_NOTAIL ""
+    "v_mul_f32 %[fgn], " FG ", %[m]\n\t"
 // ACCA / ACCB: the stage's accumulators (A0, A1 / B2, B3: the registers that are read); CS: register holding the cell state
 // of this step; R: LDS byte offset of the tile read; WT: operand holding the lane's address in the tile written (the two
 // dword offsets of ds_write2_b32 are 8-bit fields: its second row, one pitch = 72 dwords on, fits; the tile base does not);
-// PFCODE / PFECODE: the prefetch into this stage; TAILCODE: the block of the OTHER stage behind a wait for its loads
-#define S2B_STEP(ACCA, A0, A1, ACCB, B2, B3, CS, R, WT, PFCODE, PFECODE, TAILCODE) \
+// PFCODE / PFECODE: the prefetch into this stage; BLOCKCODE: the block of the NEXT stage (behind a wait for its loads)
+#define S2B_STEP(ACCA, A0, A1, ACCB, B2, B3, CS, R, WT, PFCODE, PFECODE, BLOCKCODE) \
     S2B_ST(0) \
     "ds_read_b128 %[r00], %[av0] offset:" R "\n\t" \
     "ds_read_b128 %[r10], %[av1] offset:" R "\n\t" \
@@ -781,7 +777,9 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_add_f32 %[sb3], %[sb3], %[dog]\n\t" \
     "v_fmac_f32 %[spi], %[" CS "], %[dign]\n\t" \
     "v_fmac_f32 %[spf], %[" CS "], %[dfgn]\n\t" \
-    "s_nop 4\n\t" \
+    "s_cmp_eq_u32 %[cnt], 1\n\t" \
+    "s_cselect_b64 %[last], -1, 0\n\t" \
+    "s_nop 2\n\t" \
     "v_add_f32 %[x0], " A0 ", " A1 "\n\t" \
     "v_add_f32 %[x1], " B2 ", " B3 "\n\t" \
     "v_add_f32 %[x0], %[x0], %[x1]\n\t" \
@@ -800,24 +798,36 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_cvt_pk_bf16_f32 v248, %[dni], %[dign]\n\t" \
     S2B_ST(4) \
     "ds_write2_b32 %[" WT "], v248, v249 offset0:0 offset1:72\n\t" \
-    S2B_STORE \
+    "global_store_dwordx2 %[oD], v[248:249], %[delta1]\n\t" \
     "v_fmac_f32 %[spo], %[" CS "], %[dog]\n\t" \
-    TAILCODE \
+    "s_waitcnt vmcnt(19)\n\t" \
+    BLOCKCODE \
     "s_waitcnt lgkmcnt(0)\n\t" \
     S2B_ST(5) \
     "s_barrier\n\t" \
-    S2B_ST(6)
-// tiles: plane = 9 * 288 = 2592 bytes; tile 0 at 0, tile 1 at 2592
-#define S2B_STEP_A(PFCODE, PFECODE, TAILCODE) \
-    S2B_STEP("v[228:231]", "v228", "v229", "v[232:235]", "v234", "v235", "ccA", "0", "oT1", PFCODE, PFECODE, TAILCODE)
-#define S2B_STEP_B(PFCODE, PFECODE, TAILCODE) \
-    S2B_STEP("v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "ccB", "2592", "oT", PFCODE, PFECODE, TAILCODE)
-#define S2B_BLOCK_A S2B_BLOCK("v224", "v225", "v226", "v227", "thA", "cpA", "ptA", "ccB")
-#define S2B_BLOCK_B S2B_BLOCK("v236", "v237", "v238", "v239", "thB", "cpB", "ptB", "ccA")
-#define S2B_PFA_FULL S2B_PF("v[224:227]", "thA", "cpA", "ptA")
-#define S2B_PFA_LAST S2B_PF_LAST("v[224:227]", "thA", "cpA", "ptA")
-#define S2B_PFB_FULL S2B_PF("v[236:239]", "thB", "cpB", "ptB")
-#define S2B_PFB_LAST S2B_PF_LAST("v[236:239]", "thB", "cpB", "ptB")
+    S2B_ST(6) \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t" \
+    "s_cbranch_scc1 9f\n\t"
+// tiles: plane = 9 * 288 = 2592 bytes; tile 0 at 0, tile 1 at 2592.  Stage k: registers 200 + 12 k ...; cell-state registers
+// alternate with the step parity (ccA holds the cell state of even steps)
+#define S2B_STEP_0 S2B_STEP("v[204:207]", "v204", "v205", "v[208:211]", "v210", "v211", "ccA", "0",    "oT1", S2B_PF("v[200:203]", "th0", "cp0", "pt0"), S2B_PFE("v204"), \
+                            S2B_BLOCK("v212", "v213", "v214", "v215", "th1", "cp1", "pt1", "ccA"))
+#define S2B_STEP_1 S2B_STEP("v[216:219]", "v216", "v217", "v[220:223]", "v222", "v223", "ccB", "2592", "oT",  S2B_PF("v[212:215]", "th1", "cp1", "pt1"), S2B_PFE("v216"), \
+                            S2B_BLOCK("v224", "v225", "v226", "v227", "th2", "cp2", "pt2", "ccB"))
+#define S2B_STEP_2 S2B_STEP("v[228:231]", "v228", "v229", "v[232:235]", "v234", "v235", "ccA", "0",    "oT1", S2B_PF("v[224:227]", "th2", "cp2", "pt2"), S2B_PFE("v228"), \
+                            S2B_BLOCK("v236", "v237", "v238", "v239", "th3", "cp3", "pt3", "ccA"))
+#define S2B_STEP_3 S2B_STEP("v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "ccB", "2592", "oT",  S2B_PF("v[236:239]", "th3", "cp3", "pt3"), S2B_PFE("v240"), \
+                            S2B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB"))
+// the stages of the first four steps: step k at offsets advanced by k steps (x0 / x1 / m: scratch offsets)
+#define S2B_FIRST(AXT, A0, TH, CP, PT) \
+    "global_load_dwordx4 " AXT ", %[x0], %[acts]\n\t" \
+    "global_load_dword %[" TH "], %[x1], %[th]\n\t" \
+    "global_load_dword %[" CP "], %[x1], %[cell1]\n\t" \
+    "global_load_ubyte %[" PT "], %[m], %[pat]\n\t" \
+    "global_load_dword " A0 ", %[x1], %[err]\n\t" \
+    "v_add_u32 %[x0], %[x0], %[sA]\n\t" \
+    "v_add_u32 %[x1], %[x1], %[sC]\n\t" \
+    "v_add_u32 %[m], %[m], %[sP]\n\t"
 
 __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
 {
@@ -826,6 +836,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
     constexpr int pitch = lds_pitch(KCH * 64);       // 288
     constexpr int plane = 9 * pitch;                 // 2592: the asm carries it (and pitch / 4 = 72) as literals
     static_assert(pitch == 288 && plane == 2592, "LDS offsets of the hand-written loop");
+    static_assert(CN_GUARD_STEPS >= 5, "prefetch four steps ahead, c[prev] five");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int ug = q >> 1, sq = q & 1;
@@ -850,89 +861,76 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
     const int sv = s0 + sq;
     const int uh = unit % (HP / 2), half = unit / (HP / 2);
     const unsigned oT = (4 * sq + 2 * half) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2, oT1 = oT + plane;
-    // byte offsets of this lane at the first processed step (the last one of the forward pass of this direction) and what
-    // one step adds (mod 2^32).  The offsets move on under the first MFMAs of a step, behind its prefetch: outputErrors of
-    // step t+2, issued later in the step, use a base one step back.  The delta_op offset starts one step BEFORE the first one
-    // instead, so that it never passes the last step (mod 2^32 a negative offset would be 4 GB up).
+    // Byte offsets of this lane and what one step adds (mod 2^32).  The offsets are kept BIAS steps ahead of the time index
+    // and every base pointer BIAS steps behind, so that no offset ever passes zero: the loop moves them on under the first
+    // MFMAs of a step, behind its prefetch, also in the last step (a negative offset would be 4 GB up).
+    constexpr long BIAS = 8;
     const long t0 = d ? 0 : T - 1, dt = d ? 1 : -1;
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
     const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
-    unsigned oA = (unsigned)(t0 * stepA * 4) + lC * 16, oC = (unsigned)(t0 * stepC * 4) + lC * 4, oD = (unsigned)(t0 * stepA * 2) + lC * 8;
-    unsigned oP = (unsigned)(t0 * PS) + (unsigned)sv;
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4;
+    unsigned oD = (unsigned)((t0 + BIAS) * stepA * 2) + lC * 8, oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
     const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sD = (unsigned)(dt * stepA * 2), sP = (unsigned)(dt * PS);
-    oD -= sD;
-    const char *acts = (const char *)p.acts, *cell = (const char *)p.cell, *th = (const char *)p.th, *err = (const char *)p.err, *pat = p.pat;
-    // bases of the prefetch two steps ahead; c[prev(t)] is the cell state of the step processed after t: three steps ahead
-    const char *actspf = acts + 2 * dt * stepA * 4, *thpf = th + 2 * dt * stepC * 4, *errpf = err + (2 - 1) * dt * stepC * 4;
-    const char *cell1 = cell + dt * stepC * 4, *cellpf = cell + 3 * dt * stepC * 4, *patpf = pat + 2 * dt * PS;
-    const char *delta1 = (const char *)p.delta_op;
-    unsigned np = (unsigned)(T - 3) / 2;             // pairs of steps with a full prefetch
-    const unsigned rem = (unsigned)T - 2 * np;       // 3 or 4 steps behind them (T >= 3)
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *cell = (const char *)p.cell - BIAS * stepC * 4, *th = (const char *)p.th - BIAS * stepC * 4;
+    const char *err = (const char *)p.err - BIAS * stepC * 4, *pat = p.pat - BIAS * PS;
+    // bases of the prefetch four steps ahead; c[prev(t)] is the cell state of the step processed after t: five steps ahead.
+    // outputErrors and the delta_op store are issued behind the offsets' move to the next step: their bases are one step back.
+    const char *actspf = acts + 4 * dt * stepA * 4, *thpf = th + 4 * dt * stepC * 4, *errpf = err + (4 - 1) * dt * stepC * 4;
+    const char *cell1 = cell + dt * stepC * 4, *cellpf = cell + 5 * dt * stepC * 4, *patpf = pat + 4 * dt * PS;
+    const char *delta1 = (const char *)p.delta_op - BIAS * stepA * 2 - dt * stepA * 2;
+    unsigned cnt = (unsigned)T - 1;                  // steps behind the current one
 
     float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, dni = 0.f, dog = 0.f;
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f, spi = 0.f, spf = 0.f, spo = 0.f;
-    float ccA, ccB, thA, thB, cpA, cpB;
-    int ptA, ptB;
+    float ccA, ccB, th0, th1, th2, th3, cp0, cp1, cp2, cp3;
+    int pt0, pt1, pt2, pt3;
     u32x4 r00, r01, r02, r03, r10, r11, r12, r13;
     float x0, x1, m, t2m, wm, carm, d2m, d3m, d4m, car;
+    unsigned long long last;
 #ifdef CN_S2_STAMP
     unsigned st[7] = {0, 0, 0, 0, 0, 0, 0}, tq;
     unsigned long long tm;
     unsigned tl = (unsigned)__builtin_amdgcn_s_memtime();
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef CN_S2_WGTIME
+    const unsigned long long wg0 = __builtin_amdgcn_s_memrealtime();
+#endif
     lds_barrier();
     asm volatile(
         // (registers 2, 3 of the K-half-0 accumulators and 0, 1 of the K-half-1 accumulators collect products of rows that belong
         // to the other half; they are never read -- cleared once so that they hold numbers)
+        "v_mov_b32 v206, 0\n\tv_mov_b32 v207, 0\n\tv_mov_b32 v208, 0\n\tv_mov_b32 v209, 0\n\t"
+        "v_mov_b32 v218, 0\n\tv_mov_b32 v219, 0\n\tv_mov_b32 v220, 0\n\tv_mov_b32 v221, 0\n\t"
         "v_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\tv_mov_b32 v232, 0\n\tv_mov_b32 v233, 0\n\t"
         "v_mov_b32 v242, 0\n\tv_mov_b32 v243, 0\n\tv_mov_b32 v244, 0\n\tv_mov_b32 v245, 0\n\t"
-        // cell state of the first processed step; stages of the first two steps (T >= 3: both have a step behind them)
+        // cell state of the first processed step; the stages of the first four steps (beyond T: guard steps, never used)
         "global_load_dword %[ccA], %[oC], %[cell]\n\t"
-        "global_load_dwordx4 v[224:227], %[oA], %[acts]\n\t"
-        "global_load_dword %[thA], %[oC], %[th]\n\t"
-        "global_load_dword %[cpA], %[oC], %[cell1]\n\t"
-        "global_load_ubyte %[ptA], %[oP], %[pat]\n\t"
-        "global_load_dword v228, %[oC], %[err]\n\t"
-        "v_add_u32 %[x0], %[oA], %[sA]\n\t"
-        "v_add_u32 %[x1], %[oC], %[sC]\n\t"
-        "v_add_u32 %[m], %[oP], %[sP]\n\t"
-        "global_load_dwordx4 v[236:239], %[x0], %[acts]\n\t"
-        "global_load_dword %[thB], %[x1], %[th]\n\t"
-        "global_load_dword %[cpB], %[x1], %[cell1]\n\t"
-        "global_load_ubyte %[ptB], %[m], %[pat]\n\t"
-        "global_load_dword v240, %[x1], %[err]\n\t"
+        "v_mov_b32 %[x0], %[oA]\n\tv_mov_b32 %[x1], %[oC]\n\tv_mov_b32 %[m], %[oP]\n\t"
+        S2B_FIRST("v[200:203]", "v204", "th0", "cp0", "pt0")
+        S2B_FIRST("v[212:215]", "v216", "th1", "cp1", "pt1")
+        S2B_FIRST("v[224:227]", "v228", "th2", "cp2", "pt2")
+        S2B_FIRST("v[236:239]", "v240", "th3", "cp3", "pt3")
         "s_waitcnt vmcnt(0)\n\t"
-        S2B_BLOCK_A
-        "s_cmp_eq_u32 %[np], 0\n\t"
-        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cselect_b64 %[last], -1, 0\n\t"
+        "s_nop 1\n\t"
+        S2B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB")
         "1:\n\t"
-        S2B_STEP_A(S2B_PFA_FULL, S2B_PFE("v228"), S2B_TAIL("7", S2B_BLOCK_B))
-        S2B_STEP_B(S2B_PFB_FULL, S2B_PFE("v240"), S2B_TAIL("7", S2B_BLOCK_A))
-        "s_sub_u32 %[np], %[np], 1\n\t"
-        "s_cmp_lg_u32 %[np], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "2:\n\t"
-        "s_cmp_eq_u32 %[rem], 3\n\t"
-        "s_cbranch_scc0 3f\n\t"
-        S2B_STEP_A(S2B_PFA_LAST, S2B_PFE("v228"), S2B_TAIL("6", S2B_BLOCK_B))
-        S2B_STEP_B(S2B_NOPF, S2B_NOPFE, S2B_TAIL("2", S2B_BLOCK_A))
-        S2B_STEP_A(S2B_NOPF, S2B_NOPFE, S2B_NOTAIL)
+        S2B_STEP_0
+        S2B_STEP_1
+        S2B_STEP_2
+        S2B_STEP_3
+        "s_branch 1b\n\t"
+        "9:\n\t"
         // gradient sums of the last step (its c[prev] is 0: lastCall)
         "v_add_f32 %[sb0], %[sb0], %[dni]\n\tv_add_f32 %[sb1], %[sb1], %[dign]\n\tv_add_f32 %[sb2], %[sb2], %[dfgn]\n\tv_add_f32 %[sb3], %[sb3], %[dog]\n\t"
-        "s_branch 4f\n\t"
-        "3:\n\t"
-        S2B_STEP_A(S2B_PFA_FULL, S2B_PFE("v228"), S2B_TAIL("7", S2B_BLOCK_B))
-        S2B_STEP_B(S2B_PFB_LAST, S2B_PFE("v240"), S2B_TAIL("6", S2B_BLOCK_A))
-        S2B_STEP_A(S2B_NOPF, S2B_NOPFE, S2B_TAIL("2", S2B_BLOCK_B))
-        S2B_STEP_B(S2B_NOPF, S2B_NOPFE, S2B_NOTAIL)
-        "v_add_f32 %[sb0], %[sb0], %[dni]\n\tv_add_f32 %[sb1], %[sb1], %[dign]\n\tv_add_f32 %[sb2], %[sb2], %[dfgn]\n\tv_add_f32 %[sb3], %[sb3], %[dog]\n\t"
-        "4:\n\t"
         : [fgn] "+v"(fgn), [ecn] "+v"(ecn), [dign] "+v"(dign), [dfgn] "+v"(dfgn), [dni] "+v"(dni), [dog] "+v"(dog),
           [sb0] "+v"(sb0), [sb1] "+v"(sb1), [sb2] "+v"(sb2), [sb3] "+v"(sb3), [spi] "+v"(spi), [spf] "+v"(spf), [spo] "+v"(spo),
-          [oA] "+v"(oA), [oC] "+v"(oC), [oD] "+v"(oD), [oP] "+v"(oP), [np] "+s"(np),
-          [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [thA] "=&v"(thA), [thB] "=&v"(thB), [cpA] "=&v"(cpA), [cpB] "=&v"(cpB),
-          [ptA] "=&v"(ptA), [ptB] "=&v"(ptB),
+          [oA] "+v"(oA), [oC] "+v"(oC), [oD] "+v"(oD), [oP] "+v"(oP), [cnt] "+s"(cnt), [last] "=&s"(last),
+          [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [th0] "=&v"(th0), [th1] "=&v"(th1), [th2] "=&v"(th2), [th3] "=&v"(th3),
+          [cp0] "=&v"(cp0), [cp1] "=&v"(cp1), [cp2] "=&v"(cp2), [cp3] "=&v"(cp3),
+          [pt0] "=&v"(pt0), [pt1] "=&v"(pt1), [pt2] "=&v"(pt2), [pt3] "=&v"(pt3),
           [r00] "=&v"(r00), [r01] "=&v"(r01), [r02] "=&v"(r02), [r03] "=&v"(r03), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13),
           [x0] "=&v"(x0), [x1] "=&v"(x1), [m] "=&v"(m), [t2m] "=&v"(t2m), [wm] "=&v"(wm), [carm] "=&v"(carm),
           [d2m] "=&v"(d2m), [d3m] "=&v"(d3m), [d4m] "=&v"(d4m), [car] "=&v"(car)
@@ -940,21 +938,26 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
           , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]), [st6] "+s"(st[6]),
           [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
 #endif
-        : [w0k0] "v"(w[0][0]), [w0k1] "v"(w[0][1]), [w0k2] "v"(w[0][2]), [w0k3] "v"(w[0][3]), [w0k4] "v"(w[0][4]), [w0k5] "v"(w[0][5]), [w0k6] "v"(w[0][6]), [w0k7] "v"(w[0][7]),
-          [w1k0] "v"(w[1][0]), [w1k1] "v"(w[1][1]), [w1k2] "v"(w[1][2]), [w1k3] "v"(w[1][3]), [w1k4] "v"(w[1][4]), [w1k5] "v"(w[1][5]), [w1k6] "v"(w[1][6]), [w1k7] "v"(w[1][7]),
+        : [w0k0] "a"(w[0][0]), [w0k1] "a"(w[0][1]), [w0k2] "a"(w[0][2]), [w0k3] "a"(w[0][3]), [w0k4] "a"(w[0][4]), [w0k5] "a"(w[0][5]), [w0k6] "a"(w[0][6]), [w0k7] "a"(w[0][7]),
+          [w1k0] "a"(w[1][0]), [w1k1] "a"(w[1][1]), [w1k2] "a"(w[1][2]), [w1k3] "a"(w[1][3]), [w1k4] "a"(w[1][4]), [w1k5] "a"(w[1][5]), [w1k6] "a"(w[1][6]), [w1k7] "a"(w[1][7]),
           [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [oT1] "v"(oT1), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
           [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(cell), [cell1] "s"(cell1), [cellpf] "s"(cellpf), [th] "s"(th), [thpf] "s"(thpf),
           [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta1] "s"(delta1),
-          [sA] "s"(sA), [sC] "s"(sC), [sD] "s"(sD), [sP] "s"(sP), [rem] "s"(rem)
+          [sA] "s"(sA), [sC] "s"(sC), [sD] "s"(sD), [sP] "s"(sP)
         : "memory", "vcc", "scc",
-          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
-          "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
+          "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211",
+          "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
+          "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
 
 #ifdef CN_S2_STAMP
     if (blockIdx.x == 0 && lane == 0) {
         for (int i = 0; i < 7; ++i) cn_s2_stamp_buf[wave][i] = st[i];
         cn_s2_stamp_buf[wave][7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);      // 100 MHz ticks over the loop
     }
+#endif
+#ifdef CN_S2_WGTIME
+    if (threadIdx.x == 0 && blockIdx.x < 256) { cn_s2_wg_time[blockIdx.x][0] = (unsigned)(__builtin_amdgcn_s_memrealtime() - wg0); cn_s2_wg_time[blockIdx.x][1] = (__builtin_amdgcn_s_getreg(63492) & 0xffff) | (__builtin_amdgcn_s_getreg(63508) << 16) /* HW_ID | XCC_ID << 16 */; }
 #endif
     // fold the two sequences of each unit column, then one atomic per (gate, unit) and workgroup
     float v[7] = {sb0, sb1, sb2, sb3, spi, spf, spo};
@@ -1002,9 +1005,9 @@ bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
 // the hand-written loops cover bf16, Hp = 128, at least four time steps, and activations addressable with 32-bit byte offsets
 static bool s2_asm_applies(int prec, bool bwd, const LstmRec &p)
 {
-    if (getenv("CN_NO_S2_ASM") || prec != P_BF16 || p.Hp != 128 || p.T < (bwd ? 3 : 4)) return false;
+    if (getenv("CN_NO_S2_ASM") || prec != P_BF16 || p.Hp != 128 || p.T < (bwd ? 1 : 4)) return false;
     if (bwd && getenv("CN_NO_S2_ASM_BWD")) return false;
-    return (unsigned long long)p.T * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;
+    return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // (+16: the backward loop's offsets run 8 steps ahead)
 }
 
 template <int PREC, bool BWD, int HP>

@@ -626,19 +626,20 @@ def test_destroy_deep_cluster_network(depth):
     assert out.returncode == 0 and "destroyed ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
-@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 3), ("blstm", 250, 4), ("blstm", 250, 5), ("blstm", 250, 6), ("lstm", 128, 9), ("blstm", 256, 37),
-                                         ("blstm", 250, 64)])
+@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 1), ("blstm", 250, 2), ("blstm", 250, 3), ("blstm", 250, 4), ("blstm", 250, 5), ("blstm", 250, 6), ("lstm", 128, 9), ("blstm", 256, 37),
+                                         ("blstm", 250, 7), ("blstm", 250, 64)])
 def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
     """The hand-written (asm) time loops of cn_lstm_s2.hip against the C++ kernels of the same cut (CN_NO_S2_ASM): same
     operand order, same arithmetic, so EVERY value on a real slot must be bit-identical -- outputs, the four gate
     activations, cell states, all deltas, every weight gradient except the split-K atomics' last bits (compared at 1e-6).
-    Loop shapes: T = 3 (backward: tail only; forward: compiled kernel), 4, 5, 6 (every combination of pair count and tail
-    length of both loops), odd / even longer passes, ragged lengths, unused slots, one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
+    Loop shapes: T = 1 ... 7 (the backward loop leaves its four-step body after any step; the forward loop's pair count and
+    tail length in every combination, T < 4: compiled forward kernel), longer odd / even passes, the pass as long as the
+    buffers (prefetch into the guard steps), ragged lengths, unused slots, one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
     rng = np.random.RandomState(500 + T)
     P, C, PS = 9, 7, 11                       # 11 slots -> padded to 12, the last group half filled
     layers = net_desc(P, [(kind, size), (kind, size)], C)
     weights = random_weights(layers, rng, 0.08)
-    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]      # one unused slot
+    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]      # one unused slot; maxT = T: the last steps prefetch guard rows
     lengths[0] = T
     xs, ts = random_sequences(rng, lengths, P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)

@@ -17,8 +17,9 @@ from bench import make_weights, net_desc, synth_fraction  # noqa: E402
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 250
 PS = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+NL = int(sys.argv[4]) if len(sys.argv) > 4 else 1          # layers: the stamps are those of the LAST backward launch = the lowest layer
 pkg = ge.load_package()
-layers = net_desc(39, [("blstm", H)], 183)
+layers = net_desc(39, [("blstm", H)] * NL, 183)
 net = pkg.NeuralNetwork(layers, make_weights(layers, 1), PS, T, precision=pkg.PREC_BF16)
 frac = synth_fraction(pkg, np.random.RandomState(0), PS, 39, 183, T, T)
 for _ in range(3):

@@ -4,6 +4,8 @@ f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob('gpurun_out/prof_*/*/
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 sg = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
+if len(sg) < 3:          # the update rides on the grouped operand pack (cn_sgd_update_all)
+    sg = [i for i, r in enumerate(rows) if 'pack_group_kernel' in r['Kernel_Name']]
 a, b = sg[-3], sg[-2]
 t0 = int(rows[a]['End_Timestamp'])
 prev_end = t0
