@@ -266,9 +266,13 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     S2A_MF("v[224:227]", "a3", "w1n1") \
     PFCODE \
     S2A_MF("v[228:231]", "a0", "w0i0") \
+    "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
     S2A_MF("v[228:231]", "a1", "w1i0") \
+    "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
     S2A_MF("v[228:231]", "a2", "w0i1") \
+    "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
     S2A_MF("v[228:231]", "a3", "w1i1") \
+    "v_add_u32 %[oY], %[oY], %[sY]\n\t" \
     "v_add_f32 %[x0], v224, v225\n\t" \
     S2A_MF("v[232:235]", "a0", "w0f0") \
     "v_mul_f32 %[x0], " S2A_K2 ", %[x0]\n\t" \
@@ -315,14 +319,10 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     "v_cvt_pk_bf16_f32 %[x6], %[x6], %[x6]\n\t" \
     "v_cndmask_b32_e64 %[x6], %[x6], 0, vcc\n\t" \
     "ds_write_b16 %[oT], %[x6] offset:" WO "\n\t" \
-    "global_store_dwordx4 %[oA], v[248:251], %[acts]\n\t" \
-    "global_store_dword %[oC], %[cst], %[cell]\n\t" \
-    "global_store_dword %[oC], v253, %[th]\n\t" \
-    "global_store_short %[oY], %[x6], %[yop]\n\t" \
-    "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
-    "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
-    "v_add_u32 %[oY], %[oY], %[sY]\n\t" \
-    "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
+    "global_store_dwordx4 %[oA], v[248:251], %[acts1]\n\t" \
+    "global_store_dword %[oC], %[cst], %[cell1]\n\t" \
+    "global_store_dword %[oC], v253, %[th1]\n\t" \
+    "global_store_short %[oY], %[x6], %[yop1]\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
     "s_barrier\n\t"
 #define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "v242", "v243", "ptA", R0, R1, WO, VM, PFCODE)
@@ -363,15 +363,21 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
     const int sv = s0 + sq;
     const int k = unit & 63;
     const unsigned oT = (2 * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;
-    // byte offsets of this lane at the first processed step, and what one step adds (mod 2^32: backwards for d = 1)
+    // Byte offsets of this lane at the first processed step, and what one step adds (mod 2^32: backwards for d = 1).  The
+    // offsets are kept BIAS steps ahead of the time index and every base BIAS steps behind, so that no offset ever passes
+    // zero (a negative one would be 4 GB up): they move on in MFMA gaps behind the step's prefetch, also in the last step, and
+    // the stores of the step, issued after that, use bases one step back.
+    constexpr long BIAS = 8;
     const long t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
     const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);          // elements into a cell row block (x 16 / 4 / 2 bytes)
-    unsigned oA = (unsigned)(t0 * stepA * 4) + lC * 16, oC = (unsigned)(t0 * stepC * 4) + lC * 4, oY = (unsigned)(t0 * stepC * 2) + lC * 2;
-    unsigned oP = (unsigned)(t0 * PS) + (unsigned)sv;
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4, oY = (unsigned)((t0 + BIAS) * stepC * 2) + lC * 2;
+    unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
     const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sY = (unsigned)(dt * stepC * 2), sP = (unsigned)(dt * PS);
-    const char *acts = (const char *)p.acts, *actspf = acts + 2 * dt * stepA * 4;
-    const char *pat = p.pat, *patpf = pat + 2 * dt * PS;
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *actspf = acts + 2 * dt * stepA * 4, *acts1 = acts - dt * stepA * 4;
+    const char *pat = p.pat - BIAS * PS, *patpf = pat + 2 * dt * PS;
+    const char *cell1 = (const char *)p.cell - (BIAS + dt) * stepC * 4, *th1 = (const char *)p.th - (BIAS + dt) * stepC * 4;
+    const char *yop1 = (const char *)p.y_op - (BIAS + dt) * stepC * 2;
     unsigned np = (unsigned)(T - 2) / 2;             // pairs of steps with a prefetch (T >= 4: at least one)
     const unsigned rem = (unsigned)T - 2 * np;       // 2 or 3 steps behind them
 
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
           [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]),
           [w0o0] "v"(w[0][3][0]), [w0o1] "v"(w[0][3][1]), [w1o0] "v"(w[1][3][0]), [w1o1] "v"(w[1][3][1]),
           [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
-          [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(p.cell), [th] "s"(p.th), [yop] "s"(p.y_op),
+          [acts] "s"(acts), [actspf] "s"(actspf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
           [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem)
         : "memory", "vcc", "scc",
           "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
@@ -716,13 +722,10 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_mul_f32 %[d3m], %[x0], %[" CN "]\n\t" \
     "v_fmac_f32 %[car], %[pf], %[dfgn]\n\t" \
     "v_mul_f32 %[d4m], %[x1], " NI "\n\t" \
-    "v_mul_f32 %[t2m], %[t2m], %[m]\n\t" \
-    "v_mul_f32 %[wm], %[wm], %[m]\n\t" \
-    "v_mul_f32 %[carm], %[car], %[m]\n\t" \
-    "v_mul_f32 %[d2m], %[d2m], %[m]\n\t" \
-    "v_mul_f32 %[d3m], %[d3m], %[m]\n\t" \
-    "v_mul_f32 %[d4m], %[d4m], %[m]\n\t" \
     "v_mul_f32 %[fgn], " FG ", %[m]\n\t"
+// ... and their products with the dummy-slot factor m: one per MFMA gap of the step itself (S2B_STEP), where a VALU
+// instruction costs ~3.5 cycles instead of the 6.6 of the dependent stream behind the LDS write
+#define S2B_MASK(x) "v_mul_f32 %[" x "], %[" x "], %[m]\n\t"
 // ACCA / ACCB: the stage's accumulators (A0, A1 / B2, B3: the registers that are read); CS: register holding the cell state
 // of this step; R: LDS byte offset of the tile read; WT: operand holding the lane's address in the tile written (the two
 // dword offsets of ds_write2_b32 are 8-bit fields: its second row, one pitch = 72 dwords on, fits; the tile base does not);
@@ -754,13 +757,19 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
     "s_waitcnt lgkmcnt(5)\n\t" \
     S2B_MF(ACCA, "r01", "w0k1") \
+    S2B_MASK("t2m") \
     S2B_MF(ACCB, "r01", "w0k5") \
+    S2B_MASK("wm") \
     "s_waitcnt lgkmcnt(4)\n\t" \
     S2B_MF(ACCA, "r11", "w1k1") \
+    "v_mul_f32 %[carm], %[car], %[m]\n\t" \
     S2B_MF(ACCB, "r11", "w1k5") \
+    S2B_MASK("d2m") \
     "s_waitcnt lgkmcnt(3)\n\t" \
     S2B_MF(ACCA, "r02", "w0k2") \
+    S2B_MASK("d3m") \
     S2B_MF(ACCB, "r02", "w0k6") \
+    S2B_MASK("d4m") \
     "s_waitcnt lgkmcnt(2)\n\t" \
     S2B_MF(ACCA, "r12", "w1k2") \
     S2B_MF(ACCB, "r12", "w1k6") \
