@@ -48,10 +48,14 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     static_assert(PREC != P_F32 && HP % 64 == 0, "row-pair products: bf16 operands, whole 64-value K chunks");
     constexpr bool X3 = PREC == P_X3;
     constexpr int MELT = X3 ? 4 : 2;                 // operand element in memory (y, W_rec)
-    constexpr int PLANES = X3 ? 2 : 1;               // LDS planes of the y tile (hi, lo)
     constexpr int KCS = HP / 64;                     // 64-value K chunks
     constexpr int pitch = lds_pitch(HP);             // a tile row holds half of the K values of a sequence (bf16)
-    constexpr int DROWS = 5;                         // rows (2*seq + parity) of the two sequences + one row of zeros
+    // bf16: rows 2*seq + parity; split-bf16: "row quads" 4*seq + 2*part + parity with part 0 = hi, 1 = lo halves of y -- the two
+    // rows of a quad that the bf16 tile leaves empty.  One MFMA against W_hi then yields [y_hi; y_lo] * W_hi in the four
+    // registers of the lane that owns the quad, a second one against W_lo the same with W_lo: their sum over the four
+    // registers is the full product (y_hi + y_lo)(W_hi + W_lo) -- TWO MFMAs per product (three for hi*hi + lo*hi + hi*lo from
+    // separate hi and lo tiles, which also drops lo*lo), one tile, half the LDS operand reads.  + one row of zeros.
+    constexpr int DROWS = X3 ? 9 : 5;
     constexpr int plane = DROWS * pitch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
 
-    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
 
     // W_rec fragments of both unit groups: B lane (col = c, k slice = q) of gate g, chunk kc
     u32x8 wsp[2][4][KCS];
@@ -78,8 +82,8 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
             }
     const int spidx = sp_index(c);
     // the two views of the tile: as A-operand lane, c is the tile row and q the k slice
-    const int vrow0 = (c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4;          // rows 0,1,4,5 = (seq 0, seq 1) x (even, odd)
-    const int vrow1 = (c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4;    // rows 8,9,12,13
+    const int vrow0 = X3 ? (c < 8 ? c : 8) : ((c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4);          // bf16: rows 0,1,4,5 = (seq 0, seq 1) x (even, odd)
+    const int vrow1 = X3 ? (c >= 8 ? c - 8 : 8) : ((c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4);   // bf16: rows 8,9,12,13
     const int av0 = vrow0 * pitch + q * 16, av1 = vrow1 * pitch + q * 16;
 
     const int unit = 32 * wave + 16 * ug + c;
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     const unsigned oP = sv;
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
     const int k = unit & 63;
-    const int oT = (2 * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;
+    const int oT = ((X3 ? 4 : 2) * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;      // (split-bf16: the hi row; lo two rows on)
 
     float cst = 0.f;
     f32x4 preA, preB;
@@ -103,14 +107,15 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
 
     // accumulators live across steps (the sparse MFMA accumulates in place): register 0 = even tile row, seeded with the
     // staged pre-activation; register 1 = odd row, cleared; registers 2, 3 belong to zero rows in both views and stay 0
+    // (split-bf16: the lo rows, cleared every step like register 1)
     f32x4 accp[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) accp[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto step = [&](int it, f32x4 &pre, int &pt) {
         const int t = d ? T - 1 - it : it;
-        const char *ycur = smem + (it & 1) * PLANES * plane;
-        char *ynxt = smem + ((it + 1) & 1) * PLANES * plane;
+        const char *ycur = smem + (it & 1) * plane;
+        char *ynxt = smem + ((it + 1) & 1) * plane;
         const bool check = t >= p.Tmin;              // LstmLayer.cu:825,860
         float *actsT = p.acts + t * stepA;
         float *cellT = p.cell + t * stepC;
@@ -125,28 +130,26 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
             float v_;
             asm volatile("v_mov_b32 %0, %1" : "=&v"(v_) : "v"(pre[g]));
             accp[g][0] = v_; accp[g][1] = 0.f;
+            if constexpr (X3) { accp[g][2] = 0.f; accp[g][3] = 0.f; }
         }
         prefetch(d ? t - 2 : t + 2, pre, pt);
 
         // recurrent product (LstmLayer.cu:815-818 / :850-853), all four gates of both unit groups
         u32x4 a0[KCS], a1[KCS];
-        [[maybe_unused]] u32x4 l0[X3 ? KCS : 1], l1[X3 ? KCS : 1];
 #pragma unroll
         for (int kc = 0; kc < KCS; ++kc) {
             a0[kc] = *(const u32x4 *)(ycur + av0 + kc * 64);
             a1[kc] = *(const u32x4 *)(ycur + av1 + kc * 64);
-            if constexpr (X3) {
-                l0[kc] = *(const u32x4 *)(ycur + plane + av0 + kc * 64);
-                l1[kc] = *(const u32x4 *)(ycur + plane + av1 + kc * 64);
-            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int kc = 0; kc < KCS; ++kc) {
-                if constexpr (X3) {
-                    smma16_x3(accp[g], a0[kc], l0[kc], wsp[0][g][kc], wsl[0][g][kc], spidx);
-                    smma16_x3(accp[g], a1[kc], l1[kc], wsp[1][g][kc], wsl[1][g][kc], spidx);
+                if constexpr (X3) {          // small terms first
+                    smma16(accp[g], a0[kc], wsl[0][g][kc], spidx);
+                    smma16(accp[g], a0[kc], wsp[0][g][kc], spidx);
+                    smma16(accp[g], a1[kc], wsl[1][g][kc], spidx);
+                    smma16(accp[g], a1[kc], wsp[1][g][kc], spidx);
                 } else {
                     smma16(accp[g], a0[kc], wsp[0][g][kc], spidx);
                     smma16(accp[g], a1[kc], wsp[1][g][kc], spidx);
@@ -156,7 +159,11 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
         // ComputeBlockOutputFn, LstmLayer.cu:87-136 (bias is already inside the pre-activation)
         float s_[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { s_[g] = accp[g][0] + accp[g][1]; KEEP_TUPLE(accp[g], s_[g]); }
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (X3) s_[g] = (accp[g][0] + accp[g][1]) + (accp[g][2] + accp[g][3]);
+            else s_[g] = accp[g][0] + accp[g][1];
+            KEEP_TUPLE(accp[g], s_[g]);
+        }
         const float cp = cst;
         const float ni = tanh_ref<false>(s_[0]);
         const float ig = logistic<false>(s_[1] + cp * pi);
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
             __bf16 yh, yl;
             split_bf16(yo, yh, yl);
             *(__bf16 *)(ynxt + oT) = yh;
-            *(__bf16 *)(ynxt + plane + oT) = yl;
+            *(__bf16 *)(ynxt + oT + 2 * pitch) = yl;
         } else *(__bf16 *)(ynxt + oT) = (__bf16)yo;
         const f32x4 av = {ni, ig, fg, og};           // (dummy slots: never read back)
         *(f32x4 *)&at32<float>(actsT, oA) = av;
@@ -414,6 +421,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
         S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
         S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
         "3:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"               // (nothing the compiler does not know of may be in flight when the statement ends)
         : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [np] "+s"(np),
           [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
           [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6)
@@ -424,6 +432,191 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
           [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
           [acts] "s"(acts), [actspf] "s"(actspf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
           [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem)
+        : "memory", "vcc", "scc",
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+          "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, split-bf16 (P_X3), Hp = 128: the time loop written by hand
+// ---------------------------------------------------------------------------------------------
+// The parity mode in the same cut: fp32 y / W_rec in memory, every operand split into bf16 hi + lo (cn_lstm_device.h); the
+// tile carries a sequence's hi and lo halves in the four rows of its quad, and a product is TWO sparse MFMAs ([hi; lo] x W_lo,
+// [hi; lo] x W_hi) whose four accumulator registers are summed (lstm_fwd_s2_kernel<P_X3>).  32 MFMAs per wave and step: this
+// loop is bound by the matrix pipe, and everything else (activations, prefetch, address updates) rides in its issue gaps;
+// compiled, the same cut lost to the 8-wave kernel (one wave per SIMD has to issue its ~190 other instructions somewhere),
+// which is why the mode takes this cut only where the hand-written loops apply.  W_rec hi and lo fragments: 256 registers,
+// all in AGPRs.  Every step is the same code (guard steps, cn_api.cpp: dalloc_guarded): two stages, loop body of two steps,
+// left after any step.  Arithmetic, operand order and layout of lstm_fwd_s2_kernel<P_X3, 128> (bit-equal on real slots);
+// dummy slots as in the bf16 loop.  LDS: 9 rows of 160 bytes per tile buffer, buffers at 0 and 1440.
+#define X3A_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#define X3A_MF2(acc, A, BH, BL) X3A_MF(acc, A, BL) X3A_MF(acc, A, BH)
+// the eight MFMAs of one gate (views 0 / 1 x K chunks 0 / 1 x W_lo, W_hi); F0..F3: fillers behind each pair
+#define X3A_GATE(acc, G, F0, F1, F2, F3) \
+    X3A_MF2(acc, "a0", "h0" G "0", "l0" G "0") F0 \
+    X3A_MF2(acc, "a1", "h1" G "0", "l1" G "0") F1 \
+    X3A_MF2(acc, "a2", "h0" G "1", "l0" G "1") F2 \
+    X3A_MF2(acc, "a3", "h1" G "1", "l1" G "1") F3
+#define X3A_INIT(R0, R1, R2, R3, PX) "v_mov_b32 " R0 ", " PX "\n\tv_mov_b32 " R1 ", 0\n\tv_mov_b32 " R2 ", 0\n\tv_mov_b32 " R3 ", 0\n\t"
+#define X3A_STEP(PXT, PX0, PX1, PX2, PX3, PT, R, WO) \
+    "s_waitcnt vmcnt(10)\n\t" \
+    "ds_read_b128 %[a0], %[av0] offset:" R "\n\t" \
+    "ds_read_b128 %[a1], %[av1] offset:" R "\n\t" \
+    "ds_read_b128 %[a2], %[av0] offset:" R "+64\n\t" \
+    "ds_read_b128 %[a3], %[av1] offset:" R "+64\n\t" \
+    X3A_INIT("v224", "v225", "v226", "v227", PX0) \
+    "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
+    X3A_MF2("v[224:227]", "a0", "h0n0", "l0n0") \
+    X3A_INIT("v228", "v229", "v230", "v231", PX1) \
+    "s_waitcnt lgkmcnt(2)\n\t" \
+    X3A_MF2("v[224:227]", "a1", "h1n0", "l1n0") \
+    X3A_INIT("v232", "v233", "v234", "v235", PX2) \
+    "s_waitcnt lgkmcnt(1)\n\t" \
+    X3A_MF2("v[224:227]", "a2", "h0n1", "l0n1") \
+    X3A_INIT("v236", "v237", "v238", "v239", PX3) \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    X3A_MF2("v[224:227]", "a3", "h1n1", "l1n1") \
+    "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
+    "global_load_dwordx4 " PXT ", %[oA], %[actspf]\n\t" \
+    X3A_GATE("v[228:231]", "i", \
+        "v_add_u32 %[oA], %[oA], %[sA]\n\tv_add_u32 %[oP], %[oP], %[sP]\n\t", \
+        "v_add_u32 %[oC], %[oC], %[sC]\n\t", \
+        "v_add_f32 %[x0], v224, v225\n\tv_add_f32 %[x7], v226, v227\n\t", \
+        "v_add_f32 %[x0], %[x0], %[x7]\n\tv_mul_f32 %[x0], " S2A_K2 ", %[x0]\n\t") \
+    X3A_GATE("v[232:235]", "f", \
+        "v_exp_f32 %[x0], %[x0]\n\t", \
+        "v_add_f32 %[x1], v228, v229\n\tv_add_f32 %[x7], v230, v231\n\t", \
+        "v_add_f32 %[x1], %[x1], %[x7]\n\tv_add_f32 %[x0], 1.0, %[x0]\n\t", \
+        "v_fmac_f32 %[x1], %[pi], %[cst]\n\tv_rcp_f32 %[x0], %[x0]\n\t") \
+    X3A_GATE("v[236:239]", "o", \
+        "v_mul_f32 %[x1], " S2A_K1 ", %[x1]\n\t", \
+        "v_exp_f32 %[x1], %[x1]\n\tv_fma_f32 v248, %[x0], 2.0, -1.0\n\t", \
+        "v_add_f32 %[x2], v232, v233\n\tv_add_f32 %[x7], v234, v235\n\tv_add_f32 %[x1], 1.0, %[x1]\n\t", \
+        "v_add_f32 %[x2], %[x2], %[x7]\n\tv_rcp_f32 v249, %[x1]\n\t") \
+    "v_fmac_f32 %[x2], %[pf], %[cst]\n\t" \
+    "v_mul_f32 %[x2], " S2A_K1 ", %[x2]\n\t" \
+    "v_exp_f32 %[x2], %[x2]\n\t" \
+    "s_nop 0\n\t" \
+    "v_add_f32 %[x2], 1.0, %[x2]\n\t" \
+    "v_rcp_f32 v250, %[x2]\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32 %[x3], %[cst], v250\n\t" \
+    "v_fma_f32 v252, v248, v249, %[x3]\n\t" \
+    "v_mul_f32 %[x5], " S2A_K2 ", v252\n\t" \
+    "v_exp_f32 %[x5], %[x5]\n\t" \
+    "s_nop 1\n\t" \
+    "v_add_f32 %[x4], v236, v237\n\t" \
+    "v_add_f32 %[x7], v238, v239\n\t" \
+    "v_add_f32 %[x5], 1.0, %[x5]\n\t" \
+    "v_add_f32 %[x4], %[x4], %[x7]\n\t" \
+    "v_rcp_f32 %[x5], %[x5]\n\t" \
+    "v_fmac_f32 %[x4], %[po], v252\n\t" \
+    "v_cndmask_b32_e64 %[cst], v252, 0, vcc\n\t" \
+    "v_mul_f32 %[x4], " S2A_K1 ", %[x4]\n\t" \
+    "v_fma_f32 v253, %[x5], 2.0, -1.0\n\t" \
+    "v_exp_f32 %[x4], %[x4]\n\t" \
+    "s_nop 0\n\t" \
+    "v_add_f32 %[x4], 1.0, %[x4]\n\t" \
+    "v_rcp_f32 v251, %[x4]\n\t" \
+    "s_nop 0\n\t" \
+    "v_mul_f32 %[x6], v253, v251\n\t" \
+    "v_cndmask_b32_e64 %[x6], %[x6], 0, vcc\n\t" \
+    "v_cvt_pk_bf16_f32 %[x0], %[x6], %[x6]\n\t" \
+    "v_lshlrev_b32 %[x1], 16, %[x0]\n\t" \
+    "v_sub_f32 %[x1], %[x6], %[x1]\n\t" \
+    "v_cvt_pk_bf16_f32 %[x1], %[x1], %[x1]\n\t" \
+    "ds_write_b16 %[oT], %[x0] offset:" WO "\n\t" \
+    "ds_write_b16 %[oT], %[x1] offset:" WO "+320\n\t" \
+    "global_store_dwordx4 %[oA], v[248:251], %[acts1]\n\t" \
+    "global_store_dword %[oC], %[cst], %[cell1]\n\t" \
+    "global_store_dword %[oC], v253, %[th1]\n\t" \
+    "global_store_dword %[oC], %[x6], %[yop1]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "s_barrier\n\t" \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t" \
+    "s_cbranch_scc1 9f\n\t"
+
+__global__ __launch_bounds__(256) void lstm_fwd_s2_x3_asm_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 128, KCS = 2;
+    constexpr int pitch = lds_pitch(HP);             // 160
+    constexpr int plane = 9 * pitch;                 // 1440: the asm carries it (and 2 * pitch = 320) as literals
+    static_assert(plane == 1440 && CN_GUARD_STEPS >= 3, "LDS offsets / prefetch distance of the hand-written loop");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x8 wh[2][4][KCS], wl[2][4][KCS];
+    const float *Wd = (const float *)p.Wrec + (long)d * 4 * HP * HP;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc)
+                sp_load_split(Wd + (long)(g * HP + 32 * wave + 16 * j + c) * HP + kc * 64 + q * 16, wh[j][g][kc], wl[j][g][kc]);
+    const int spidx = sp_index(c);
+    const unsigned av0 = (c < 8 ? c : 8) * pitch + q * 16, av1 = (c >= 8 ? c - 8 : 8) * pitch + q * 16;
+
+    const int unit = 32 * wave + 16 * ug + c;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const int k = unit & 63;
+    const unsigned oT = (4 * sq + sp_parity(k)) * pitch + ((unit >> 6) * 32 + sp_pos(k)) * 2;
+    // offsets BIAS steps ahead, bases BIAS steps behind (see lstm_fwd_s2_asm_kernel); y is fp32 here: it shares the cell offset
+    constexpr long BIAS = 8;
+    const long t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4;
+    unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
+    const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sP = (unsigned)(dt * PS);
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *actspf = acts + 2 * dt * stepA * 4, *acts1 = acts - dt * stepA * 4;
+    const char *pat = p.pat - BIAS * PS, *patpf = pat + 2 * dt * PS;
+    const char *cell1 = (const char *)p.cell - (BIAS + dt) * stepC * 4, *th1 = (const char *)p.th - (BIAS + dt) * stepC * 4;
+    const char *yop1 = (const char *)p.y_op - (BIAS + dt) * stepC * 4;
+    unsigned cnt = (unsigned)T - 1;                  // steps behind the current one
+
+    float cst = 0.f;
+    int ptA, ptB;
+    u32x4 a0, a1, a2, a3;
+    float x0, x1, x2, x3, x4, x5, x6, x7;
+    lds_barrier();
+    asm volatile(
+        "global_load_ubyte %[ptA], %[oP], %[pat]\n\t"
+        "global_load_dwordx4 v[240:243], %[oA], %[acts]\n\t"
+        "v_add_u32 %[x0], %[oP], %[sP]\n\t"
+        "v_add_u32 %[x1], %[oA], %[sA]\n\t"
+        "global_load_ubyte %[ptB], %[x0], %[pat]\n\t"
+        "global_load_dwordx4 v[244:247], %[x1], %[acts]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "1:\n\t"
+        X3A_STEP("v[240:243]", "v240", "v241", "v242", "v243", "ptA", "0", "1440")
+        X3A_STEP("v[244:247]", "v244", "v245", "v246", "v247", "ptB", "1440", "0")
+        "s_branch 1b\n\t"
+        "9:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"               // (prefetches of the last two steps: see lstm_bwd_s2_asm_kernel)
+        : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oP] "+v"(oP), [cnt] "+s"(cnt),
+          [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7)
+        : [h0n0] "a"(wh[0][0][0]), [h0n1] "a"(wh[0][0][1]), [h1n0] "a"(wh[1][0][0]), [h1n1] "a"(wh[1][0][1]),
+          [h0i0] "a"(wh[0][1][0]), [h0i1] "a"(wh[0][1][1]), [h1i0] "a"(wh[1][1][0]), [h1i1] "a"(wh[1][1][1]),
+          [h0f0] "a"(wh[0][2][0]), [h0f1] "a"(wh[0][2][1]), [h1f0] "a"(wh[1][2][0]), [h1f1] "a"(wh[1][2][1]),
+          [h0o0] "a"(wh[0][3][0]), [h0o1] "a"(wh[0][3][1]), [h1o0] "a"(wh[1][3][0]), [h1o1] "a"(wh[1][3][1]),
+          [l0n0] "a"(wl[0][0][0]), [l0n1] "a"(wl[0][0][1]), [l1n0] "a"(wl[1][0][0]), [l1n1] "a"(wl[1][0][1]),
+          [l0i0] "a"(wl[0][1][0]), [l0i1] "a"(wl[0][1][1]), [l1i0] "a"(wl[1][1][0]), [l1i1] "a"(wl[1][1][1]),
+          [l0f0] "a"(wl[0][2][0]), [l0f1] "a"(wl[0][2][1]), [l1f0] "a"(wl[1][2][0]), [l1f1] "a"(wl[1][2][1]),
+          [l0o0] "a"(wl[0][3][0]), [l0o1] "a"(wl[0][3][1]), [l1o0] "a"(wl[1][3][0]), [l1o1] "a"(wl[1][3][1]),
+          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
+          [acts] "s"(acts), [actspf] "s"(actspf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
+          [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sP] "s"(sP)
         : "memory", "vcc", "scc",
           "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
           "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
@@ -446,12 +639,13 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
     static_assert(PREC != P_F32 && HP % 32 == 0, "row-pair products: bf16 operands");
     constexpr bool X3 = PREC == P_X3;
     constexpr int MELT = X3 ? 4 : 2;                 // operand element in memory (delta, W_rec^T)
-    constexpr int PLANES = X3 ? 2 : 1;
-    // K = 4*HP with k = 4*unit + gate.  A sequence takes four tile rows: (K half, parity); the product of K half h uses
-    // accumulator h and is read from the rows of that half (cn_lstm.hip "KHS"): e = accA[0] + accA[1] + accB[2] + accB[3]
-    constexpr int KCS = 4 * HP / 64, KCH = KCS / 2;
+    // K = 4*HP with k = 4*unit + gate.  A sequence takes four tile rows.  bf16: (K half, parity); the product of K half h uses
+    // accumulator h and is read from the rows of that half (cn_lstm.hip "KHS"): e = accA[0] + accA[1] + accB[2] + accB[3].
+    // split-bf16: (part, parity) with part 0 = hi, 1 = lo halves of the deltas, rows of the whole K: one MFMA against W_hi and
+    // one against W_lo per chunk, e = the sum of the accumulator's four registers (see lstm_fwd_s2_kernel).
+    constexpr int KCS = 4 * HP / 64, KCH = X3 ? KCS : KCS / 2;        // chunks in all / per tile row
     constexpr int pitch = lds_pitch(KCH * 64);
-    constexpr int DROWS = 9;                         // rows 4*seq + 2*half + parity, + one row of zeros
+    constexpr int DROWS = 9;                         // rows 4*seq + 2*(half | part) + parity, + one row of zeros
     constexpr int plane = DROWS * pitch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -460,9 +654,9 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
     const int PS = p.PS, T = p.T, dirs = p.dirs;
     const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
 
-    for (int i = threadIdx.x * 4; i < 2 * PLANES * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
     // dummy-slot table: dtab[t][s] = (t >= Tmin && patTypes[t][s0 + s] == NONE) (LstmLayer.cu:224-234 with :949,983)
-    unsigned char *dtab = (unsigned char *)smem + 2 * PLANES * plane;
+    unsigned char *dtab = (unsigned char *)smem + 2 * plane;
     for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) {
         const int tt = i >> 1;
         dtab[i] = tt >= p.Tmin && p.pat[(long)tt * PS + s0 + (i & 1)] == 0;
@@ -488,8 +682,8 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
     const unsigned oA = (unsigned)(sv * (int)arow + (d * HP + unit) * 4);
     const unsigned oC = (unsigned)(sv * (int)crow + d * HP + unit);
     const unsigned stepA = (unsigned)PS * (unsigned)arow, stepC = (unsigned)PS * (unsigned)crow;
-    const int uh = unit % (HP / 2), half = unit / (HP / 2);
-    const int oT = (4 * sq + 2 * half) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2;
+    const int uh = X3 ? unit : unit % (HP / 2), half = X3 ? 0 : unit / (HP / 2);
+    const int oT = (4 * sq + 2 * half) * pitch + ((uh >> 4) * 32 + sp_pos(4 * (uh & 15))) * 2;      // (split-bf16: the hi rows; lo two rows on)
 
     float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, ccur;
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
@@ -510,8 +704,8 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 
     auto step = [&](int it, BwdStage &pre) {
         const int t = d ? it : T - 1 - it;
-        const char *dcur = smem + (it & 1) * PLANES * plane;
-        char *dnxt = smem + ((it + 1) & 1) * PLANES * plane;
+        const char *dcur = smem + (it & 1) * plane;
+        char *dnxt = smem + ((it + 1) & 1) * plane;
         const int tprev_ = d ? t + 1 : t - 1;
         const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
         const unsigned bD = (unsigned)t * stepA;
@@ -529,33 +723,34 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 
         // BPTT product (LstmLayer.cu:939-942 / :973-976): the four gates contract into one K = 4*HP
         u32x4 a0[KCH], a1[KCH];
-        [[maybe_unused]] u32x4 l0[X3 ? KCH : 1], l1[X3 ? KCH : 1];
 #pragma unroll
         for (int kc = 0; kc < KCH; ++kc) {
             a0[kc] = *(const u32x4 *)(dcur + av0 + kc * 64);
             a1[kc] = *(const u32x4 *)(dcur + av1 + kc * 64);
-            if constexpr (X3) {
-                l0[kc] = *(const u32x4 *)(dcur + plane + av0 + kc * 64);
-                l1[kc] = *(const u32x4 *)(dcur + plane + av1 + kc * 64);
-            }
         }
         f32x4 accA = {e_, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};      // err enters as the C operand
+        float e;
+        if constexpr (X3) {
 #pragma unroll
-        for (int kc = 0; kc < KCH; ++kc) {
-            if constexpr (X3) {
-                smma16_x3(accA, a0[kc], l0[kc], wsp[0][kc], wsl[0][kc], spidx);
-                smma16_x3(accB, a0[kc], l0[kc], wsp[0][KCH + kc], wsl[0][KCH + kc], spidx);
-                smma16_x3(accA, a1[kc], l1[kc], wsp[1][kc], wsl[1][kc], spidx);
-                smma16_x3(accB, a1[kc], l1[kc], wsp[1][KCH + kc], wsl[1][KCH + kc], spidx);
-            } else {
+            for (int kc = 0; kc < KCH; ++kc) {          // small terms first
+                smma16(accA, a0[kc], wsl[0][kc], spidx);
+                smma16(accA, a0[kc], wsp[0][kc], spidx);
+                smma16(accA, a1[kc], wsl[1][kc], spidx);
+                smma16(accA, a1[kc], wsp[1][kc], spidx);
+            }
+            e = (accA[0] + accA[1]) + (accA[2] + accA[3]);
+            KEEP_TUPLE(accA, e);
+        } else {
+#pragma unroll
+            for (int kc = 0; kc < KCH; ++kc) {
                 smma16(accA, a0[kc], wsp[0][kc], spidx);
                 smma16(accB, a0[kc], wsp[0][KCH + kc], spidx);
                 smma16(accA, a1[kc], wsp[1][kc], spidx);
                 smma16(accB, a1[kc], wsp[1][KCH + kc], spidx);
             }
+            e = (accA[0] + accA[1]) + (accB[2] + accB[3]);
+            KEEP_TUPLE(accA, e); KEEP_TUPLE(accB, e);
         }
-        const float e = (accA[0] + accA[1]) + (accB[2] + accB[3]);
-        KEEP_TUPLE(accA, e); KEEP_TUPLE(accB, e);
 
         // ComputeBlockErrorsFn, LstmLayer.cu:236-285, as an explicit operation sequence (no contraction left to the compiler:
         // the hand-written loop below issues exactly these operations and is held bit-equal).  Everything that does not
@@ -599,8 +794,8 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
             for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(dv[g], h_, l_); dh[g] = h_; dl[g] = l_; }
             *(bf16x2 *)(dnxt + oT) = bf16x2{dh[0], dh[1]};
             *(bf16x2 *)(dnxt + oT + pitch) = bf16x2{dh[2], dh[3]};
-            *(bf16x2 *)(dnxt + plane + oT) = bf16x2{dl[0], dl[1]};
-            *(bf16x2 *)(dnxt + plane + oT + pitch) = bf16x2{dl[2], dl[3]};
+            *(bf16x2 *)(dnxt + oT + 2 * pitch) = bf16x2{dl[0], dl[1]};
+            *(bf16x2 *)(dnxt + oT + 3 * pitch) = bf16x2{dl[2], dl[3]};
             *(f32x4 *)&at32<float>(p.delta_op, bD + oA) = dv;
         } else {
             const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
@@ -932,6 +1127,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
         S2B_STEP_3
         "s_branch 1b\n\t"
         "9:\n\t"
+        // the prefetches of the last steps are still in flight; hipcc counts an asm load's destination as written when the
+        // statement ends and reuses those registers in the epilogue (the atomics' addresses -- seen as an intermittent memory
+        // fault of the first, cold backward pass beside the gradient GEMMs): drain before leaving
+        "s_waitcnt vmcnt(0)\n\t"
         // gradient sums of the last step (its c[prev] is 0: lastCall)
         "v_add_f32 %[sb0], %[sb0], %[dni]\n\tv_add_f32 %[sb1], %[sb1], %[dign]\n\tv_add_f32 %[sb2], %[sb2], %[dfgn]\n\tv_add_f32 %[sb3], %[sb3], %[dog]\n\t"
         : [fgn] "+v"(fgn), [ecn] "+v"(ecn), [dign] "+v"(dign), [dfgn] "+v"(dfgn), [dni] "+v"(dni), [dog] "+v"(dog),
@@ -988,13 +1187,267 @@ extern "C" int cn_dbg_read_stamps_s2(unsigned *host)      // [4][8]
 #endif
 
 // ---------------------------------------------------------------------------------------------
+// backward, split-bf16 (P_X3), Hp = 128: the time loop written by hand
+// ---------------------------------------------------------------------------------------------
+// lstm_bwd_s2_asm_kernel's structure (four stages, block of step t+1 behind the LDS write of step t, uniform steps over the
+// guard steps, loop left after any step) with the operands of lstm_bwd_s2_kernel<P_X3, 128>: fp32 deltas in memory, the tile
+// rows of a sequence's quad = hi / lo halves over the whole K = 512 (8 chunks per row), 32 MFMAs per step ([hi; lo] x W_lo,
+// [hi; lo] x W_hi per chunk and view) into ONE accumulator whose four registers are summed; W_rec^T hi and lo fragments: 256
+// AGPRs.  Bit-equal to the compiled kernel on real slots.  LDS: 9 rows of 544 bytes per tile buffer, buffers at 0 and 4896.
+// Fixed registers: stage k = 0..3: v[200+8k : 203+8k] n,i,f,o, v[204+8k : 207+8k] the accumulator; v[232:235] the four fp32
+// deltas of the step (n, i, f, o: one 16-byte store; i and f double as the carried deltas).
+#define X3B_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+#ifdef CN_X3B_NOSTORE
+#define X3B_STORE ""
+#else
+#define X3B_STORE "global_store_dwordx4 %[oA], v[232:235], %[delta1]\n\t"
+#endif
+#define X3B_MF4(acc, KC, F0, F1) \
+    X3B_MF(acc, "r0" KC, "l0k" KC) X3B_MF(acc, "r0" KC, "h0k" KC) F0 \
+    X3B_MF(acc, "r1" KC, "l1k" KC) X3B_MF(acc, "r1" KC, "h1k" KC) F1
+#ifdef CN_X3B_NOPF
+#define X3B_PF(AXT, TH, CP, PT) ""
+#else
+#define X3B_PF(AXT, TH, CP, PT) \
+    "global_load_dwordx4 " AXT ", %[oA], %[actspf]\n\t" \
+    "global_load_dword %[" TH "], %[oC], %[thpf]\n\t" \
+    "global_load_dword %[" CP "], %[oC], %[cellpf]\n\t" \
+    "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t"
+#endif
+#define X3B_BLOCK(NI, IG, FG, OG, TH, CP, PT, CN) \
+    "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
+    "v_fma_f32 %[x0], -" OG ", " OG ", " OG "\n\t" \
+    "v_fma_f32 %[x1], -%[" TH "], %[" TH "], 1.0\n\t" \
+    "v_cndmask_b32_e64 %[" CN "], %[" CP "], 0, %[last]\n\t" \
+    "v_cndmask_b32_e64 %[m], 1.0, 0, vcc\n\t" \
+    "v_mul_f32 %[t2m], %[x0], %[" TH "]\n\t" \
+    "v_mul_f32 %[x1], " OG ", %[x1]\n\t" \
+    "v_fma_f32 %[x0], -" NI ", " NI ", 1.0\n\t" \
+    "v_mul_f32 %[car], %[fgn], %[ecn]\n\t" \
+    "v_fma_f32 %[wm], %[po], %[t2m], %[x1]\n\t" \
+    "v_mul_f32 %[d2m], " IG ", %[x0]\n\t" \
+    "v_fma_f32 %[x0], -" FG ", " FG ", " FG "\n\t" \
+    "v_fmac_f32 %[car], %[pi], v233\n\t" \
+    "v_fma_f32 %[x1], -" IG ", " IG ", " IG "\n\t" \
+    "v_mul_f32 %[d3m], %[x0], %[" CN "]\n\t" \
+    "v_fmac_f32 %[car], %[pf], v234\n\t" \
+    "v_mul_f32 %[d4m], %[x1], " NI "\n\t" \
+    "v_mul_f32 %[fgn], " FG ", %[m]\n\t"
+#define X3B_MASK(x) "v_mul_f32 %[" x "], %[" x "], %[m]\n\t"
+#define X3B_RD(KC, OFF) "ds_read_b128 %[r0" KC "], %[av0] offset:" OFF "\n\tds_read_b128 %[r1" KC "], %[av1] offset:" OFF "\n\t"
+// ACC: the stage's accumulator (A0..A3 its registers); CS: cell state of this step; R0..R7: LDS byte offsets of the eight K
+// chunks of the tile read; WT / WL: operands with the lane's address of its hi / lo rows in the tile written
+#define X3B_STEP(ACC, A0, A1, A2, A3, CS, R0, R1, R2, R3, R4, R5, R6, R7, WT, WL, PFCODE, PFECODE, BLOCKCODE) \
+    X3B_RD("0", R0) X3B_RD("1", R1) X3B_RD("2", R2) X3B_RD("3", R3) X3B_RD("4", R4) X3B_RD("5", R5) X3B_RD("6", R6) X3B_RD("7", R7) \
+    "v_mov_b32 " A1 ", 0\n\t" \
+    "v_mov_b32 " A2 ", 0\n\t" \
+    "v_mov_b32 " A3 ", 0\n\t" \
+    PFCODE \
+    "s_waitcnt lgkmcnt(14)\n\t" \
+    X3B_MF4(ACC, "0", "v_add_u32 %[oA], %[oA], %[sA]\n\t", "v_add_u32 %[oC], %[oC], %[sC]\n\t") \
+    "s_waitcnt lgkmcnt(12)\n\t" \
+    X3B_MF4(ACC, "1", "v_add_u32 %[oP], %[oP], %[sP]\n\t", X3B_MASK("t2m")) \
+    "s_waitcnt lgkmcnt(10)\n\t" \
+    X3B_MF4(ACC, "2", X3B_MASK("wm"), "v_mul_f32 %[carm], %[car], %[m]\n\t") \
+    "s_waitcnt lgkmcnt(8)\n\t" \
+    X3B_MF4(ACC, "3", X3B_MASK("d2m"), X3B_MASK("d3m")) \
+    "s_waitcnt lgkmcnt(6)\n\t" \
+    X3B_MF4(ACC, "4", X3B_MASK("d4m"), "") \
+    "s_waitcnt lgkmcnt(4)\n\t" \
+    X3B_MF4(ACC, "5", "", "") \
+    "s_waitcnt lgkmcnt(2)\n\t" \
+    X3B_MF4(ACC, "6", "", "") \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    X3B_MF4(ACC, "7", "", "") \
+    "v_add_f32 %[sb0], %[sb0], v232\n\t" \
+    "v_add_f32 %[sb1], %[sb1], v233\n\t" \
+    "v_add_f32 %[sb2], %[sb2], v234\n\t" \
+    "v_add_f32 %[sb3], %[sb3], v235\n\t" \
+    "v_fmac_f32 %[spi], %[" CS "], v233\n\t" \
+    "v_fmac_f32 %[spf], %[" CS "], v234\n\t" \
+    "s_cmp_eq_u32 %[cnt], 1\n\t" \
+    "s_cselect_b64 %[last], -1, 0\n\t" \
+    "s_nop 2\n\t" \
+    "v_add_f32 %[x0], " A0 ", " A1 "\n\t" \
+    "v_add_f32 %[x1], " A2 ", " A3 "\n\t" \
+    "v_add_f32 %[x0], %[x0], %[x1]\n\t" \
+    PFECODE \
+    "v_mul_f32 v235, %[t2m], %[x0]\n\t" \
+    "v_fma_f32 %[ecn], %[x0], %[wm], %[carm]\n\t" \
+    "v_med3_f32 v235, v235, -1.0, 1.0\n\t" \
+    "v_mul_f32 v232, %[d2m], %[ecn]\n\t" \
+    "v_mul_f32 v234, %[d3m], %[ecn]\n\t" \
+    "v_mul_f32 v233, %[d4m], %[ecn]\n\t" \
+    "v_med3_f32 v232, v232, -1.0, 1.0\n\t" \
+    "v_med3_f32 v234, v234, -1.0, 1.0\n\t" \
+    "v_med3_f32 v233, v233, -1.0, 1.0\n\t" \
+    "v_cvt_pk_bf16_f32 %[hb], v234, v235\n\t" \
+    "v_cvt_pk_bf16_f32 %[ha], v232, v233\n\t" \
+    "v_and_b32 %[x1], 0xffff0000, %[hb]\n\t" \
+    "v_lshlrev_b32 %[x0], 16, %[hb]\n\t" \
+    "v_sub_f32 %[x1], v235, %[x1]\n\t" \
+    "v_sub_f32 %[x0], v234, %[x0]\n\t" \
+    "v_cvt_pk_bf16_f32 %[lb], %[x0], %[x1]\n\t" \
+    "v_and_b32 %[x1], 0xffff0000, %[ha]\n\t" \
+    "v_lshlrev_b32 %[x0], 16, %[ha]\n\t" \
+    "v_sub_f32 %[x1], v233, %[x1]\n\t" \
+    "v_sub_f32 %[x0], v232, %[x0]\n\t" \
+    "v_cvt_pk_bf16_f32 %[la], %[x0], %[x1]\n\t" \
+    "ds_write2_b32 %[" WT "], %[ha], %[hb] offset0:0 offset1:136\n\t" \
+    "ds_write2_b32 %[" WL "], %[la], %[lb] offset0:0 offset1:136\n\t" \
+    X3B_STORE \
+    "v_fmac_f32 %[spo], %[" CS "], v235\n\t" \
+    "s_waitcnt vmcnt(19)\n\t" \
+    BLOCKCODE \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "s_barrier\n\t" \
+    "s_sub_u32 %[cnt], %[cnt], 1\n\t" \
+    "s_cbranch_scc1 9f\n\t"
+#define X3B_APPLY(M, ...) M(__VA_ARGS__)
+#define X3B_EVEN "0", "64", "128", "192", "256", "320", "384", "448", "oT1", "oT1l"
+#define X3B_ODD "4896", "4960", "5024", "5088", "5152", "5216", "5280", "5344", "oT", "oTl"
+#define X3B_STEP_0 X3B_APPLY(X3B_STEP, "v[204:207]", "v204", "v205", "v206", "v207", "ccA", X3B_EVEN, X3B_PF("v[200:203]", "th0", "cp0", "pt0"), S2B_PFE("v204"), \
+                            X3B_BLOCK("v208", "v209", "v210", "v211", "th1", "cp1", "pt1", "ccA"))
+#define X3B_STEP_1 X3B_APPLY(X3B_STEP, "v[212:215]", "v212", "v213", "v214", "v215", "ccB", X3B_ODD,  X3B_PF("v[208:211]", "th1", "cp1", "pt1"), S2B_PFE("v212"), \
+                            X3B_BLOCK("v216", "v217", "v218", "v219", "th2", "cp2", "pt2", "ccB"))
+#define X3B_STEP_2 X3B_APPLY(X3B_STEP, "v[220:223]", "v220", "v221", "v222", "v223", "ccA", X3B_EVEN, X3B_PF("v[216:219]", "th2", "cp2", "pt2"), S2B_PFE("v220"), \
+                            X3B_BLOCK("v224", "v225", "v226", "v227", "th3", "cp3", "pt3", "ccA"))
+#define X3B_STEP_3 X3B_APPLY(X3B_STEP, "v[228:231]", "v228", "v229", "v230", "v231", "ccB", X3B_ODD,  X3B_PF("v[224:227]", "th3", "cp3", "pt3"), S2B_PFE("v228"), \
+                            X3B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB"))
+
+__global__ __launch_bounds__(256) void lstm_bwd_s2_x3_asm_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 128, KCS = 8;
+    constexpr int pitch = lds_pitch(KCS * 64);       // 544
+    constexpr int plane = 9 * pitch;                 // 4896: the asm carries it (and pitch / 4 = 136) as literals
+    static_assert(pitch == 544 && plane == 4896 && CN_GUARD_STEPS >= 5, "LDS offsets / prefetch distance of the hand-written loop");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x8 wh[2][KCS], wl[2][KCS];
+    const float *Wd = (const float *)p.WrecT + (long)d * 4 * HP * HP;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kc = 0; kc < KCS; ++kc)
+            sp_load_split(Wd + (long)(32 * wave + 16 * j + c) * 4 * HP + kc * 64 + q * 16, wh[j][kc], wl[j][kc]);
+    const int spidx = sp_index(c);
+    const unsigned av0 = (c < 8 ? c : 8) * pitch + q * 16, av1 = (c >= 8 ? c - 8 : 8) * pitch + q * 16;
+
+    const int unit = 32 * wave + 16 * ug + c;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const unsigned oT = (4 * sq) * pitch + ((unit >> 4) * 32 + sp_pos(4 * (unit & 15))) * 2, oT1 = oT + plane;
+    const unsigned oTl = oT + 2 * pitch, oT1l = oT1 + 2 * pitch;
+    // offsets BIAS steps ahead, bases BIAS steps behind (see lstm_bwd_s2_asm_kernel); the fp32 deltas share the activations' offset
+    constexpr long BIAS = 8;
+    const long t0 = d ? 0 : T - 1, dt = d ? 1 : -1;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4;
+    unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
+    const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sP = (unsigned)(dt * PS);
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *cell = (const char *)p.cell - BIAS * stepC * 4, *th = (const char *)p.th - BIAS * stepC * 4;
+    const char *err = (const char *)p.err - BIAS * stepC * 4, *pat = p.pat - BIAS * PS;
+    const char *actspf = acts + 4 * dt * stepA * 4, *thpf = th + 4 * dt * stepC * 4, *errpf = err + (4 - 1) * dt * stepC * 4;
+    const char *cell1 = cell + dt * stepC * 4, *cellpf = cell + 5 * dt * stepC * 4, *patpf = pat + 4 * dt * PS;
+    const char *delta1 = (const char *)p.delta_op - (BIAS + dt) * stepA * 4;
+    unsigned cnt = (unsigned)T - 1;
+
+    float fgn = 0.f, ecn = 0.f;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f, spi = 0.f, spf = 0.f, spo = 0.f;
+    float ccA, ccB, th0, th1, th2, th3, cp0, cp1, cp2, cp3;
+    int pt0, pt1, pt2, pt3;
+    u32x4 r00, r01, r02, r03, r04, r05, r06, r07, r10, r11, r12, r13, r14, r15, r16, r17;
+    float x0, x1, m, t2m, wm, carm, d2m, d3m, d4m, car;
+    unsigned ha, hb, la, lb;
+    unsigned long long last;
+    lds_barrier();
+    asm volatile(
+        // the carried deltas of the step before the first one are zero
+        "v_mov_b32 v232, 0\n\tv_mov_b32 v233, 0\n\tv_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\t"
+        "global_load_dword %[ccA], %[oC], %[cell]\n\t"
+        "v_mov_b32 %[x0], %[oA]\n\tv_mov_b32 %[x1], %[oC]\n\tv_mov_b32 %[m], %[oP]\n\t"
+        S2B_FIRST("v[200:203]", "v204", "th0", "cp0", "pt0")
+        S2B_FIRST("v[208:211]", "v212", "th1", "cp1", "pt1")
+        S2B_FIRST("v[216:219]", "v220", "th2", "cp2", "pt2")
+        S2B_FIRST("v[224:227]", "v228", "th3", "cp3", "pt3")
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_cmp_eq_u32 %[cnt], 0\n\t"
+        "s_cselect_b64 %[last], -1, 0\n\t"
+        "s_nop 1\n\t"
+        X3B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB")
+        "1:\n\t"
+        X3B_STEP_0
+        X3B_STEP_1
+        X3B_STEP_2
+        X3B_STEP_3
+        "s_branch 1b\n\t"
+        "9:\n\t"
+        // the prefetches of the last steps are still in flight; hipcc counts an asm load's destination as written when the
+        // statement ends and reuses those registers in the epilogue (the atomics' addresses): drain before leaving
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_add_f32 %[sb0], %[sb0], v232\n\tv_add_f32 %[sb1], %[sb1], v233\n\tv_add_f32 %[sb2], %[sb2], v234\n\tv_add_f32 %[sb3], %[sb3], v235\n\t"
+        : [fgn] "+v"(fgn), [ecn] "+v"(ecn),
+          [sb0] "+v"(sb0), [sb1] "+v"(sb1), [sb2] "+v"(sb2), [sb3] "+v"(sb3), [spi] "+v"(spi), [spf] "+v"(spf), [spo] "+v"(spo),
+          [oA] "+v"(oA), [oC] "+v"(oC), [oP] "+v"(oP), [cnt] "+s"(cnt), [last] "=&s"(last),
+          [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [th0] "=&v"(th0), [th1] "=&v"(th1), [th2] "=&v"(th2), [th3] "=&v"(th3),
+          [cp0] "=&v"(cp0), [cp1] "=&v"(cp1), [cp2] "=&v"(cp2), [cp3] "=&v"(cp3),
+          [pt0] "=&v"(pt0), [pt1] "=&v"(pt1), [pt2] "=&v"(pt2), [pt3] "=&v"(pt3),
+          [r00] "=&v"(r00), [r01] "=&v"(r01), [r02] "=&v"(r02), [r03] "=&v"(r03), [r04] "=&v"(r04), [r05] "=&v"(r05), [r06] "=&v"(r06), [r07] "=&v"(r07),
+          [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13), [r14] "=&v"(r14), [r15] "=&v"(r15), [r16] "=&v"(r16), [r17] "=&v"(r17),
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [m] "=&v"(m), [t2m] "=&v"(t2m), [wm] "=&v"(wm), [carm] "=&v"(carm),
+          [d2m] "=&v"(d2m), [d3m] "=&v"(d3m), [d4m] "=&v"(d4m), [car] "=&v"(car),
+          [ha] "=&v"(ha), [hb] "=&v"(hb), [la] "=&v"(la), [lb] "=&v"(lb)
+        : [h0k0] "a"(wh[0][0]), [h0k1] "a"(wh[0][1]), [h0k2] "a"(wh[0][2]), [h0k3] "a"(wh[0][3]), [h0k4] "a"(wh[0][4]), [h0k5] "a"(wh[0][5]), [h0k6] "a"(wh[0][6]), [h0k7] "a"(wh[0][7]),
+          [h1k0] "a"(wh[1][0]), [h1k1] "a"(wh[1][1]), [h1k2] "a"(wh[1][2]), [h1k3] "a"(wh[1][3]), [h1k4] "a"(wh[1][4]), [h1k5] "a"(wh[1][5]), [h1k6] "a"(wh[1][6]), [h1k7] "a"(wh[1][7]),
+          [l0k0] "a"(wl[0][0]), [l0k1] "a"(wl[0][1]), [l0k2] "a"(wl[0][2]), [l0k3] "a"(wl[0][3]), [l0k4] "a"(wl[0][4]), [l0k5] "a"(wl[0][5]), [l0k6] "a"(wl[0][6]), [l0k7] "a"(wl[0][7]),
+          [l1k0] "a"(wl[1][0]), [l1k1] "a"(wl[1][1]), [l1k2] "a"(wl[1][2]), [l1k3] "a"(wl[1][3]), [l1k4] "a"(wl[1][4]), [l1k5] "a"(wl[1][5]), [l1k6] "a"(wl[1][6]), [l1k7] "a"(wl[1][7]),
+          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [oT1] "v"(oT1), [oTl] "v"(oTl), [oT1l] "v"(oT1l), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
+          [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(cell), [cell1] "s"(cell1), [cellpf] "s"(cellpf), [th] "s"(th), [thpf] "s"(thpf),
+          [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta1] "s"(delta1),
+          [sA] "s"(sA), [sC] "s"(sC), [sP] "s"(sP)
+        : "memory", "vcc", "scc",
+          "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211",
+          "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235");
+
+    float v[7] = {sb0, sb1, sb2, sb3, spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
+    if (sq == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 static size_t s2_lds_bytes(int prec, bool bwd, int Hp, int T)
 {
-    const int PLANES = prec == P_X3 ? 2 : 1;
-    const size_t pitch = (size_t)lds_pitch(bwd ? 2 * Hp : Hp);      // bwd: KCH * 64 = (4*Hp/64/2) * 64
-    return 2 * (size_t)PLANES * (bwd ? 9 : 5) * pitch + (bwd ? (((size_t)T * 2 + 15) & ~(size_t)15) : 0);
+    const bool x3 = prec == P_X3;                                   // split-bf16: row quads (hi, lo) -- 9 rows, backward rows of the whole K
+    const size_t pitch = (size_t)lds_pitch(bwd ? (x3 ? 4 : 2) * Hp : Hp);      // bwd: KCH * 64 bytes per row
+    return 2 * (size_t)(bwd || x3 ? 9 : 5) * pitch + (bwd ? (((size_t)T * 2 + 15) & ~(size_t)15) : 0);
+}
+
+// the hand-written loops cover Hp = 128 in bf16 (both passes) and split-bf16 (see s2_x3_asm), at least four time steps in the
+// bf16 forward loop (its tail copies), and activations addressable with 32-bit byte offsets
+static bool s2_asm_applies(int prec, bool bwd, const LstmRec &p)
+{
+    if (getenv("CN_NO_S2_ASM") || prec == P_F32 || p.Hp != 128) return false;
+    if (prec == P_BF16 && !bwd && p.T < 4) return false;
+    if (bwd && getenv("CN_NO_S2_ASM_BWD")) return false;
+    return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // (+16: offsets run 8 steps ahead)
 }
 
 // The shape applies when the layer is one the row-pair products cover (bf16, Hp = 64 or 128), the caller
@@ -1002,36 +1455,29 @@ static size_t s2_lds_bytes(int prec, bool bwd, int Hp, int T)
 // workgroup a CU of its own.
 bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
 {
-    // bf16 only: the split-bf16 mode issues three MFMAs per product and is bound by the MFMA pipe, which this cut does not
-    // relieve (48 MFMAs per SIMD and step either way) while it takes away the second wave that hides the first one's VALU
-    // work: measured 6.7 M against 7.7 M frames/s on the headline net (CN_S2_X3=1 keeps it selectable for the tests)
-    if (prec == P_X3 && !getenv("CN_S2_X3")) return false;
+    // split-bf16: only where the hand-written loops exist (Hp = 128).  The mode is bound by the MFMA pipe (32 MFMAs per SIMD and
+    // step), which this cut does not relieve, while it takes away the second wave that hides the first one's VALU work: the
+    // COMPILED kernels of the cut lose to the 8-wave kernels (CN_S2_X3=1 selects them anyway, for the tests).
+    if (prec == P_X3 && !getenv("CN_S2_X3") && !s2_asm_applies(prec, bwd, p)) return false;
     if (getenv("CN_NO_S2") || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
     if (p.dirs * (p.PS / 2) > p.num_cus) return false;
     return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;
 }
 
-// the hand-written loops cover bf16, Hp = 128, at least four time steps, and activations addressable with 32-bit byte offsets
-static bool s2_asm_applies(int prec, bool bwd, const LstmRec &p)
-{
-    if (getenv("CN_NO_S2_ASM") || prec != P_BF16 || p.Hp != 128 || p.T < (bwd ? 1 : 4)) return false;
-    if (bwd && getenv("CN_NO_S2_ASM_BWD")) return false;
-    return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // (+16: the backward loop's offsets run 8 steps ahead)
-}
-
 template <int PREC, bool BWD, int HP>
 static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
 {
-    if constexpr (PREC == P_BF16 && HP == 128) {
+    if constexpr (HP == 128) {
         if (s2_asm_applies(PREC, BWD, p)) {
-            auto akern = BWD ? lstm_bwd_s2_asm_kernel : lstm_fwd_s2_asm_kernel;
+            void (*akern)(LstmRec) = PREC == P_X3 ? (BWD ? lstm_bwd_s2_x3_asm_kernel : lstm_fwd_s2_x3_asm_kernel)
+                                                  : (BWD ? lstm_bwd_s2_asm_kernel : lstm_fwd_s2_asm_kernel);
             static DeviceOnce once;
             if (once.first()) (void)hipFuncSetAttribute((const void *)akern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
             size_t lds_claim = lds;
             if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
             hipExtLaunchKernelGGL(akern, dim3(p.dirs * (p.PS / 2)), dim3(256), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
-            if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2_asm_kernel", BWD ? "bwd" : "fwd");
+            if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2%s_asm_kernel", BWD ? "bwd" : "fwd", PREC == P_X3 ? "_x3" : "");
             return;
         }
     }

@@ -358,17 +358,20 @@ def test_cluster_kernel_matches_streaming_kernel(pkg, orc, size, scale):
 
 
 @pytest.mark.parametrize("T", [1, 3, 8])
-@pytest.mark.parametrize("shape", ["s2", "rpl1", "rpl2"])
+@pytest.mark.parametrize("shape", ["s2", "s2asm", "rpl1", "rpl2"])
 @pytest.mark.parametrize("kind,size", [("blstm", 128), ("lstm", 125), ("blstm", 250)])
 def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, shape, T):
     """The 2:4 row-pair MFMA path of the register-resident kernels (bf16 and split-bf16 modes, Hp = 64 / 128) in its three
-    cuts: "s2" = two sequences per workgroup, 32 units per wave (cn_lstm_s2.hip; what a grid that fits the chip gets), and
-    the 4- and 8-sequence workgroups of cn_lstm.hip with one and two sequences per lane (CN_RPL).  Loop shapes T = 1, 3, 8, ragged lengths, a partly filled last sequence group, one- and two-directional.
+    cuts: "s2" / "s2asm" = two sequences per workgroup, 32 units per wave (cn_lstm_s2.hip; compiled kernels / the hand-written
+    loops the mode takes by default at Hp = 128), and the 4- and 8-sequence workgroups of cn_lstm.hip with one and two
+    sequences per lane (CN_RPL).  Loop shapes T = 1, 3, 8, ragged lengths, a partly filled last sequence group, one- and two-directional.
     Checked in the split-bf16 mode at the fp32 tolerances, which a misplaced operand element cannot meet."""
     rpl = 2 if shape == "rpl2" else 1
     monkeypatch.setenv("CN_RPL", str(rpl))
     if shape == "s2":
-        monkeypatch.setenv("CN_S2_X3", "1")          # (the split-bf16 mode does not take this cut by default: it is MFMA bound)
+        monkeypatch.setenv("CN_S2_X3", "1"); monkeypatch.setenv("CN_NO_S2_ASM", "1")      # the compiled kernels of the cut
+    if shape == "rpl1":
+        monkeypatch.setenv("CN_NO_S2", "1")
     rng = np.random.RandomState(300 + T + rpl + size)          # (same data for "s2" and "rpl1")
     P, C, PS = 6, 4, 13
     layers = net_desc(P, [(kind, size)], C)
@@ -382,6 +385,9 @@ def test_row_pair_sparse_products(pkg, orc, monkeypatch, kind, size, shape, T):
         if shape == "s2":
             assert net.recurrent_kernel(False) == "lstm_fwd_s2_kernel<2,%d>" % Hp
             assert net.recurrent_kernel(True) == "lstm_bwd_s2_kernel<2,%d>" % Hp
+        elif shape == "s2asm":          # what the mode takes by default: the hand-written loops where they exist (Hp = 128), else 4-sequence kernels
+            want = "lstm_%s_s2_x3_asm_kernel" if Hp == 128 else "lstm_%s_kernel<2,64,1,1>"
+            assert net.recurrent_kernel(False) == want % "fwd" and net.recurrent_kernel(True) == want % "bwd"
         else:
             assert net.recurrent_kernel(False) == "lstm_fwd_kernel<2,%d,1,%d>" % (Hp, rpl)
             assert net.recurrent_kernel(True) == "lstm_bwd_kernel<2,%d,1,%d>" % (Hp, rpl)
@@ -662,6 +668,44 @@ def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, mon
             got[mode] = (names, vals, grads)
     assert got["asm"][0] == ("lstm_fwd_s2_asm_kernel" if T >= 4 else "lstm_fwd_s2_kernel<0,128>", "lstm_bwd_s2_asm_kernel")
     assert got["cpp"][0] == ("lstm_fwd_s2_kernel<0,128>", "lstm_bwd_s2_kernel<0,128>")
+    for key, v in got["asm"][1].items():
+        assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
+    for name, g in got["asm"][2].items():
+        assert rel_err(g, got["cpp"][2][name]) < 1e-6, name
+
+
+@pytest.mark.parametrize("kind,size,T", [("blstm", 250, 1), ("blstm", 250, 2), ("blstm", 250, 5), ("lstm", 128, 9), ("blstm", 256, 37), ("blstm", 250, 64)])
+def test_hand_written_split_bf16_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
+    """The same for the split-bf16 (CN_PREC_BF16X3) hand-written loops of the s2 cut against the compiled kernels of that cut
+    (CN_S2_X3 selects the cut for both runs, CN_NO_S2_ASM the compiled kernels): every value on a real slot bit-identical."""
+    monkeypatch.setenv("CN_S2_X3", "1")
+    rng = np.random.RandomState(600 + T)
+    P, C, PS = 9, 7, 11
+    layers = net_desc(P, [(kind, size), (kind, size)], C)
+    weights = random_weights(layers, rng, 0.08)
+    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]
+    lengths[0] = T
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    real = real_mask(frac)
+    got = {}
+    for mode in ("asm", "cpp"):
+        if mode == "cpp":
+            monkeypatch.setenv("CN_NO_S2_ASM", "1")
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16X3) as net:
+            net.load_sequences(frac); net.compute_forward_pass()
+            e, c = net.error_and_correct()
+            net.compute_backward_pass()
+            names = (net.recurrent_kernel(False), net.recurrent_kernel(True))
+            vals = {"error": np.float32(e), "out": net.outputs().reshape(-1, C)[real]}
+            for lay in net.layers[1:3]:
+                for dd in range(lay.dirs):
+                    for name in ("cellStates", "niActs", "igActs", "fgActs", "ogActs", "tmpOutputs", "niDeltas", "igDeltas", "fgDeltas", "ogDeltas"):
+                        vals["%s/%d/%s" % (lay.name, dd, name)] = lay.internal(name, dd).reshape(-1, lay.H)[real]
+            grads = {lay.name: lay.weight_updates() for lay in net.trainable_layers()}
+            got[mode] = (names, vals, grads)
+    assert got["asm"][0] == ("lstm_fwd_s2_x3_asm_kernel", "lstm_bwd_s2_x3_asm_kernel")
+    assert got["cpp"][0] == ("lstm_fwd_s2_kernel<2,128>", "lstm_bwd_s2_kernel<2,128>")
     for key, v in got["asm"][1].items():
         assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
     for name, g in got["asm"][2].items():
