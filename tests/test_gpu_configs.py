@@ -42,7 +42,7 @@ def test_config0_literal_lstm128_softmax183(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_s2"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "bf16x3_s4"])
 def test_config1_headline_net_against_the_live_reference_library(pkg, orc, monkeypatch, mode):
     """BASELINE configs[1] as benchmarked -- 39 -> 3 x blstm250 -> softmax183, PS = 50 (one sequence per lane, 26 workgroups
     of the Hp = 128 register-resident kernels) -- against oracle/_ref, the REFERENCE's own compiled functors and Cpu GEMM
@@ -57,13 +57,14 @@ def test_config1_headline_net_against_the_live_reference_library(pkg, orc, monke
     weights = random_weights(layers, rng, 0.1)
     xs, ts = random_sequences(rng, sorted(rng.randint(14, 25, PS - 2).tolist(), reverse=True), P, C=C)     # two unused slots
     frac = pkg.make_fraction(xs, ts, PS)
-    if mode == "bf16x3_s2":
-        monkeypatch.setenv("CN_S2_X3", "1")
+    if mode == "bf16x3_s4":
+        monkeypatch.setenv("CN_NO_S2", "1")
     ref, net = check_network(pkg, orc, layers, weights, frac, PS, backend="ref",
                              precision=pkg.PREC_F32 if mode == "f32" else pkg.PREC_BF16X3)
     with net:
-        # f32, bf16x3: 4 sequences per workgroup; bf16x3_s2: the two-sequences-per-workgroup cut (cn_lstm_s2.hip), which bf16 takes
-        want = {"f32": "lstm_%s_kernel<1,128,1,1>", "bf16x3": "lstm_%s_kernel<2,128,1,1>", "bf16x3_s2": "lstm_%s_s2_kernel<2,128>"}[mode]
+        # f32: 4 sequences per workgroup, exact-fp32 MFMAs; bf16x3: the hand-written row-quad loops of the s2 cut (cn_lstm_s2.hip);
+        # bf16x3_s4: the 4-sequence kernels in that mode (three MFMAs per product)
+        want = {"f32": "lstm_%s_kernel<1,128,1,1>", "bf16x3": "lstm_%s_s2_x3_asm_kernel", "bf16x3_s4": "lstm_%s_kernel<2,128,1,1>"}[mode]
         assert net.recurrent_kernel(False) == want % "fwd" and net.recurrent_kernel(True) == want % "bwd"
 
 
