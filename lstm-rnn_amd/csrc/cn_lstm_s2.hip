@@ -233,6 +233,12 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
 //
 // Fixed registers (clobbered): v[224:239] the four accumulators, v[240:243] / v[244:247] the two stages, v[248:251]
 // n, i, f, o of the step (one 16-byte store), v252 = cell state before the dummy select, v253 = tanh(cell state).
+#ifdef CN_S2_STAMP_F
+__device__ unsigned cn_s2_stamp_buf_f[4][8];
+#define S2A_ST(i) "s_memtime s[98:99]\n\ts_waitcnt lgkmcnt(0)\n\ts_sub_u32 %[tq], s98, %[tl]\n\ts_add_u32 %[st" #i "], %[st" #i "], %[tq]\n\ts_mov_b32 %[tl], s98\n\t"
+#else
+#define S2A_ST(i) ""
+#endif
 #define S2A_K1 "0xbfb8aa3b"     /* -log2(e)   */
 #define S2A_K2 "0xc038aa3b"     /* -2 log2(e) */
 #define S2A_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
 // read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
 #define S2A_STEP(PX0, PX1, PX2, PX3, PT, R0, R1, WO, VM, PFCODE) \
     "s_waitcnt vmcnt(" VM ")\n\t" \
+    S2A_ST(0) \
     "ds_read_b128 %[a0], %[av0] offset:" R0 "\n\t" \
     "ds_read_b128 %[a1], %[av1] offset:" R0 "\n\t" \
     "ds_read_b128 %[a2], %[av0] offset:" R1 "\n\t" \
@@ -271,6 +278,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     S2A_MF("v[224:227]", "a2", "w0n1") \
     "s_waitcnt lgkmcnt(0)\n\t" \
     S2A_MF("v[224:227]", "a3", "w1n1") \
+    S2A_ST(1) \
     PFCODE \
     S2A_MF("v[228:231]", "a0", "w0i0") \
     "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     "v_fma_f32 v248, %[x0], 2.0, -1.0\n\t" \
     "v_add_f32 %[x1], 1.0, %[x1]\n\t" \
     S2A_MF("v[236:239]", "a3", "w1o1") \
+    S2A_ST(2) \
     "v_add_f32 %[x2], v232, v233\n\t" \
     "v_rcp_f32 v249, %[x1]\n\t" \
     "v_fmac_f32 %[x2], %[pf], %[cst]\n\t" \
@@ -325,13 +334,16 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     "v_mul_f32 %[x6], v253, v251\n\t" \
     "v_cvt_pk_bf16_f32 %[x6], %[x6], %[x6]\n\t" \
     "v_cndmask_b32_e64 %[x6], %[x6], 0, vcc\n\t" \
+    S2A_ST(3) \
     "ds_write_b16 %[oT], %[x6] offset:" WO "\n\t" \
     "global_store_dwordx4 %[oA], v[248:251], %[acts1]\n\t" \
     "global_store_dword %[oC], %[cst], %[cell1]\n\t" \
     "global_store_dword %[oC], v253, %[th1]\n\t" \
     "global_store_short %[oY], %[x6], %[yop1]\n\t" \
     "s_waitcnt lgkmcnt(0)\n\t" \
-    "s_barrier\n\t"
+    S2A_ST(4) \
+    "s_barrier\n\t" \
+    S2A_ST(5)
 #define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "v242", "v243", "ptA", R0, R1, WO, VM, PFCODE)
 #define S2A_STEP_B(R0, R1, WO, VM, PFCODE) S2A_STEP("v244", "v245", "v246", "v247", "ptB", R0, R1, WO, VM, PFCODE)
 
@@ -392,6 +404,12 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
     int ptA, ptB;
     u32x4 a0, a1, a2, a3;
     float x0, x1, x2, x3, x4, x5, x6;
+#ifdef CN_S2_STAMP_F
+    unsigned st[6] = {0, 0, 0, 0, 0, 0}, tq;
+    unsigned long long tm;
+    unsigned tl = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     lds_barrier();
     asm volatile(
         // accumulator rows 2, 3 belong to rows of zeros in both views and stay 0 for the whole pass
@@ -425,6 +443,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
         : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [np] "+s"(np),
           [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
           [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6)
+#ifdef CN_S2_STAMP_F
+          , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]),
+          [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#endif
         : [w0n0] "v"(w[0][0][0]), [w0n1] "v"(w[0][0][1]), [w1n0] "v"(w[1][0][0]), [w1n1] "v"(w[1][0][1]),
           [w0i0] "v"(w[0][1][0]), [w0i1] "v"(w[0][1][1]), [w1i0] "v"(w[1][1][0]), [w1i1] "v"(w[1][1][1]),
           [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]),
@@ -435,7 +457,16 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
         : "memory", "vcc", "scc",
           "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
           "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
+#ifdef CN_S2_STAMP_F
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) cn_s2_stamp_buf_f[wave][i] = st[i];
+        cn_s2_stamp_buf_f[wave][7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+#endif
 }
+#ifdef CN_S2_STAMP_F
+extern "C" int cn_dbg_read_stamps_s2f(unsigned *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_s2_stamp_buf_f), sizeof(cn_s2_stamp_buf_f)); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward, split-bf16 (P_X3), Hp = 128: the time loop written by hand

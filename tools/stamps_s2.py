@@ -24,11 +24,13 @@ net = pkg.NeuralNetwork(layers, make_weights(layers, 1), PS, T, precision=pkg.PR
 frac = synth_fraction(pkg, np.random.RandomState(0), PS, 39, 183, T, T)
 for _ in range(3):
     net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass(); net.synchronize()
-print(net.recurrent_kernel(True))
+FWD = os.environ.get("STAMP_FWD") == "1"        # -DCN_S2_STAMP_F build: the forward loop (segments: barrier -> stage landed / LDS
+print(net.recurrent_kernel(not FWD))              # operands + first gate's MFMAs / 12 MFMAs + fillers / tail / LDS write landed / barrier)
 lib = net.lib
 buf = (C.c_uint * 32)()
-lib.cn_dbg_read_stamps_s2.argtypes = [C.c_void_p]
-assert lib.cn_dbg_read_stamps_s2(buf) == 0
+fn = lib.cn_dbg_read_stamps_s2f if FWD else lib.cn_dbg_read_stamps_s2
+fn.argtypes = [C.c_void_p]
+assert fn(buf) == 0
 raw = np.array(buf, np.float64).reshape(4, 8)
 a = raw / T
 for w in range(4):
