@@ -654,6 +654,155 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_x3_asm_kernel(LstmRec p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, bf16, Hp = 256 on ONE CU ("s2w"; experimental: CN_S2W=1)
+// ---------------------------------------------------------------------------------------------
+// W_rec of a 256-unit direction is 512 KB of bf16 -- the whole register file of a CU.  The cluster kernels split the units
+// over two CUs and pay an L2 hop per step (0.8-1.0 us of their 1.3 us).  Here one CU keeps three of the four K chunks of
+// every fragment in registers (384 per lane) and streams the fourth from LDS every step (128 KB: 16 fragments per wave as
+// two lane-linear 16-byte planes), so a step is bound by its 64 sparse MFMAs per wave (~0.6 us) instead of the hop.
+// Cut as in the s2 kernels: two sequences per workgroup, 4 waves, a wave owns 64 units = two PAIRS of unit groups; each
+// pair accumulates through the two zero-padded views of the tile; a lane owns one (unit, sequence) of each pair.
+__global__ __launch_bounds__(256) void lstm_fwd_s2w_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 256, KCS = 4, KR = 3;         // K chunks in all / register resident
+    constexpr int pitch = lds_pitch(HP);             // 288
+    constexpr int plane = 5 * pitch;
+    constexpr int WL = 2 * plane + 64;               // (16-byte aligned) base of the streamed fragments: [wave][tile*4 + gate][half][lane][16 B]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x8 wreg[4][4][KR];
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+    char *wl = smem + WL + wave * 32768 + lane * 16;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const long w0 = (long)(g * HP + 64 * wave + 16 * u + c) * HP + q * 16;
+#pragma unroll
+            for (int kc = 0; kc < KR; ++kc) wreg[u][g][kc] = sp_load_bf16(Wd + (w0 + kc * 64) * 2);
+            const u32x8 f = sp_load_bf16(Wd + (w0 + KR * 64) * 2);
+            *(u32x4 *)(wl + (u * 4 + g) * 2048) = __builtin_shufflevector(f, f, 0, 1, 2, 3);
+            *(u32x4 *)(wl + (u * 4 + g) * 2048 + 1024) = __builtin_shufflevector(f, f, 4, 5, 6, 7);
+        }
+    const int spidx = sp_index(c);
+    const int vrow0 = (c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4;
+    const int vrow1 = (c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4;
+    const int av0 = vrow0 * pitch + q * 16, av1 = vrow1 * pitch + q * 16;
+
+    int unit[2], oT[2];
+    float pi[2], pf[2], po[2], cst[2] = {0.f, 0.f};
+    unsigned oA[2], oC[2];
+    const int sv = s0 + sq;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        unit[s] = 64 * wave + 32 * s + 16 * ug + c;
+        pi[s] = p.peep[(d * 3 + 0) * HP + unit[s]]; pf[s] = p.peep[(d * 3 + 1) * HP + unit[s]]; po[s] = p.peep[(d * 3 + 2) * HP + unit[s]];
+        oA[s] = sv * (int)arow + (d * HP + unit[s]) * 4;
+        oC[s] = sv * (int)crow + d * HP + unit[s];
+        const int k = unit[s] & 63;
+        oT[s] = (2 * sq + sp_parity(k)) * pitch + ((unit[s] >> 6) * 32 + sp_pos(k)) * 2;
+    }
+    const unsigned oP = sv;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+
+    f32x4 preA[2], preB[2];
+    int ptA, ptB;
+    auto prefetch = [&](int t, f32x4 (&pre)[2], int &pt) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        pt = (int)at32<unsigned char>(p.pat + (long)t * PS, oP);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) pre[s] = *(const f32x4 *)&at32<float>(p.acts + t * stepA, oA[s]);
+    };
+
+    auto step = [&](int it, f32x4 (&pre)[2], int &pt) {
+        const int t = d ? T - 1 - it : it;
+        const char *ycur = smem + (it & 1) * plane;
+        char *ynxt = smem + ((it + 1) & 1) * plane;
+        const bool check = t >= p.Tmin;
+        float *actsT = p.acts + t * stepA;
+        float *cellT = p.cell + t * stepC;
+        float *thT = p.th + t * stepC;
+        char *yT = (char *)p.y_op + t * stepC * 2;
+        int ptc;
+        asm volatile("v_mov_b32 %0, %1" : "=&v"(ptc) : "v"(pt));
+        const bool dummy = check && ptc == 0;
+        f32x4 g_[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("v_mov_b32 %0, %1" : "=&v"(g_[s][g]) : "v"(pre[s][g]));
+        prefetch(d ? t - 2 : t + 2, pre, pt);
+
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = f32x4{g_[s][g], 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < KCS; ++kc) {
+                const u32x4 a0 = *(const u32x4 *)(ycur + av0 + kc * 64), a1 = *(const u32x4 *)(ycur + av1 + kc * 64);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (kc < KR) {
+                        smma16(acc[g], a0, wreg[2 * s][g][kc], spidx);
+                        smma16(acc[g], a1, wreg[2 * s + 1][g][kc], spidx);
+                    } else {
+                        const char *f0 = wl + ((2 * s) * 4 + g) * 2048, *f1 = wl + ((2 * s + 1) * 4 + g) * 2048;
+                        smma16(acc[g], a0, sp_join(*(const u32x4 *)f0, *(const u32x4 *)(f0 + 1024)), spidx);
+                        smma16(acc[g], a1, sp_join(*(const u32x4 *)f1, *(const u32x4 *)(f1 + 1024)), spidx);
+                    }
+                }
+            }
+            float s_[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { s_[g] = acc[g][0] + acc[g][1]; KEEP_TUPLE(acc[g], s_[g]); }
+            const float cp = cst[s];
+            const float ni = tanh_ref<false>(s_[0]);
+            const float ig = logistic<false>(s_[1] + cp * pi[s]);
+            const float fg = logistic<false>(s_[2] + cp * pf[s]);
+            const float cs = __builtin_fmaf(ni, ig, cp * fg);
+            const float og = logistic<false>(s_[3] + cs * po[s]);
+            const float th = tanh_ref<false>(cs);
+            const float y = th * og;
+            const float yo = dummy ? 0.f : y;
+            const float co = dummy ? 0.f : cs;
+            cst[s] = co;
+            *(__bf16 *)(ynxt + oT[s]) = (__bf16)yo;
+            const f32x4 av = {ni, ig, fg, og};
+            *(f32x4 *)&at32<float>(actsT, oA[s]) = av;
+            at32<float>(cellT, oC[s]) = co;
+            at32<float>(thT, oC[s]) = th;
+            at32<__bf16>(yT, oC[s]) = (__bf16)yo;
+        }
+        lds_barrier();
+    };
+
+    prefetch(d ? T - 1 : 0, preA, ptA);
+    prefetch(d ? T - 2 : 1, preB, ptB);
+    lds_barrier();
+    if (T >= 2) {
+        step(0, preA, ptA);
+        step(1, preB, ptB);
+        int it = 2;
+        for (; it + 1 < T; it += 2) {
+            step(it, preA, ptA);
+            step(it + 1, preB, ptB);
+        }
+        if (it < T) step(it, preA, ptA);
+    } else {
+        step(0, preA, ptA);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 struct BwdStage {
