@@ -14,7 +14,9 @@
 extern "C" {
 #endif
 
-/* C[M][N] = act(A[M][K] * B[N][K]^T + bias[N]);  K % 8 == 0, N % 32 == 0;  act: 0 tanh, 1 logistic, 2 identity */
+/* C[M][N] = act(A[M][K] * B[N][K]^T + bias[N]);  K % 8 == 0, N % 32 == 0;  act: 0 tanh, 1 logistic, 2 identity;
+ * act | 0x100: the kernel writes the fp32 result AND its operand-type copy (what a hidden feed-forward layer asks for) and the
+ * copy is returned (widened to float); act | 0x200: the copy alone */
 int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K,
                    const float *bias, int act);
 /* C[M][N] = A[K][M]^T * B[K][N];  M % 32 == 0, N % 32 == 0 */

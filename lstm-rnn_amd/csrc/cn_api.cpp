@@ -1672,12 +1672,24 @@ int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
         if (bias) { HIP_CHECK(hipMalloc((void **)&dbias, (size_t)N * 4)); HIP_CHECK(hipMemcpyAsync(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice, ctx->stream)); }
         launch_pad_convert(ctx->stream, ctx->f32, dA, M, K, oA, K);
         launch_pad_convert(ctx->stream, ctx->f32, dB, N, K, oB, K);
-        GemmNT g{}; g.A = oA; g.lda = K; g.B = oB; g.ldb = K; g.C = dC; g.ldc = N; g.bias = dbias; g.act = act; g.M = M; g.N = N; g.K = K;
+        // act | 0x100: both outputs (fp32 and operand-type copy), the COPY is returned; act | 0x200: the copy alone
+        const bool both = act & 0x100, copy_only = act & 0x200;
+        void *dC2 = nullptr;
+        if (both || copy_only) HIP_CHECK(hipMalloc(&dC2, (size_t)M * N * e));
+        GemmNT g{}; g.A = oA; g.lda = K; g.B = oB; g.ldb = K; g.C = copy_only ? nullptr : dC; g.ldc = N; g.C2 = dC2; g.ldc2 = N;
+        g.bias = dbias; g.act = act & 0xff; g.M = M; g.N = N; g.K = K;
         launch_gemm_nt(ctx->stream, ctx->prec, g);
         HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(oA); hipFree(oB); hipFree(dbias);
+        if (dC2 && e == 2) {
+            std::vector<uint16_t> h((size_t)M * N);
+            HIP_CHECK(hipMemcpyAsync(h.data(), dC2, h.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            for (size_t i = 0; i < h.size(); ++i) { const uint32_t u = (uint32_t)h[i] << 16; memcpy(&C[i], &u, 4); }
+        } else {
+            HIP_CHECK(hipMemcpyAsync(C, dC2 ? dC2 : dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        hipFree(dA); hipFree(dB); hipFree(dC); hipFree(oA); hipFree(oB); hipFree(dbias); hipFree(dC2);
     });
 }
 

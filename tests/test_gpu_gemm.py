@@ -49,6 +49,53 @@ def test_gemm_nt(lib, prec, shape):
         assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()
 
 
+@pytest.mark.parametrize("shape", [(4200, 6176, 256), (9000, 3104, 320), (7000, 4128, 832)])
+def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape):
+    """Race screen of the persistent 256 x 256 kernel (counted vmcnt waits, fills in flight across barriers and tile seams, two
+    wave groups half a phase apart): nothing in it is order dependent, so 25 launches on the same operands must agree to the bit;
+    K of 4, 5 and 13 k-tiles (the seam k-tiles are the first three of a tile; odd counts flip the buffer parity per tile)."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32); bias = rng.randn(N).astype(np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        first = np.zeros((M, N), np.float32)
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, first.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+        ref = bf16_round(A) @ bf16_round(Bm).T + bias
+        assert np.abs(first - ref).max() < 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
+        out = np.zeros((M, N), np.float32)
+        for rep in range(24):
+            B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+            assert np.array_equal(out, first), (rep, np.abs(out - first).max())
+    finally:
+        L.cn_ctx_destroy(ctx)
+
+
+@pytest.mark.parametrize("flag", [0x100, 0x200])
+@pytest.mark.parametrize("act", [0, 2])
+@pytest.mark.parametrize("shape", [(300, 256, 64), (6500, 4128, 512), (25000, 1024, 1024)])
+def test_gemm_nt_operand_copy_output(lib, shape, act, flag):
+    """The operand-type (bf16) copy of the result, with and without the fp32 result beside it: the small shape runs the 128 x 128
+    kernel, the large ones the persistent 256 x 256 kernel, whose seam stores count in its vmcnt waits (16 or 8 per phase)."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K + act)
+    A = bf16_round(rng.randn(M, K)); Bm = bf16_round(rng.randn(N, K)); bias = rng.randn(N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, act | flag), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    ref = A @ Bm.T + bias
+    if act == 0:
+        ref = np.tanh(ref)
+    tol = 2e-4 * np.sqrt(K) + 2.0 ** -8 * np.abs(ref) + 1e-5          # (bf16 keeps 8 bits)
+    bad = np.abs(out - ref) - tol
+    assert bad.max() < 0, (bad.max(), np.unravel_index(bad.argmax(), bad.shape))
+
+
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(128, 32, 60), (1024, 256, 5000), (96, 160, 333), (4000, 2080, 700),
                                    (512, 64, 3000), (768, 96, 1111), (256, 416, 2000)])      # 256-row tiles: 256 x 64 (N < 128, partial N tile) and 256 x 128

@@ -9,13 +9,32 @@
 #include "../../lstm-rnn_amd/csrc/cn_internal.h"
 
 using namespace cn;
+#ifdef B8_STAMP
+namespace cn { void b8_read_stamps(unsigned *h, unsigned *clk); }
+static void print_stamps(int nk)
+{
+    unsigned h[2][2][4][5];
+    unsigned clk[11];
+    b8_read_stamps(&h[0][0][0][0], clk);
+    printf("   k loops of workgroup 0: %u k-tiles, %u cycles in %.2f us = %.2f GHz, %.0f cycles per k-tile\n", clk[2], clk[0], clk[1] / 100.0, clk[0] / (clk[1] * 10.0), (double)clk[0] / clk[2]);
+    printf("   cycles in normal / first / second / third k-tiles of a tile: group 0: %u %u %u %u, group 1: %u %u %u %u (sums over %d tiles)\n", clk[3], clk[4], clk[5], clk[6], clk[7], clk[8], clk[9], clk[10], (int)clk[2] / nk);
+    nk = (int)clk[2];
+    for (int w = 0; w < 2; ++w) for (int g = 0; g < 2; ++g) {
+        printf("   wg %d group %d, s_memtime cycles per k-tile [wait, reads+barrier, operand wait, multiply, barrier]:", w ? 100 : 0, g);
+        double tot = 0;
+        for (int a = 0; a < 4; ++a) { printf("  ph%d:", a); for (int b = 0; b < 5; ++b) { double c = (double)h[w][g][a][b] / nk; tot += c; printf(" %5.0f", c); } }
+        printf("  = %6.0f\n", tot);
+    }
+}
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 static void *rnd(size_t n16)   // n16 bf16 values, random small
 {
     std::vector<unsigned short> h(n16);
-    for (size_t i = 0; i < n16; ++i) { float f = (rand() % 2001 - 1000) / 1000.0f; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
+    static const bool zero = getenv("GEMM_BENCH_ZERO") != nullptr;     // (zero operands draw less power: the clock stays up)
+    for (size_t i = 0; i < n16; ++i) { float f = zero ? 0.f : (rand() % 2001 - 1000) / 1000.0f; unsigned u; memcpy(&u, &f, 4); h[i] = (unsigned short)(u >> 16); }
     void *d; CK(hipMalloc(&d, n16 * 2)); CK(hipMemcpy(d, h.data(), n16 * 2, hipMemcpyHostToDevice));
     return d;
 }
@@ -41,6 +60,9 @@ int main()
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         double us = ms * 1e3 / reps, bytes = (double)c.M * c.N * 4 + (double)c.M * c.K * 2 + (double)c.N * c.K * 2, fl = 2.0 * c.M * c.N * c.K;
         printf("gemm_nt M=%5d N=%4d K=%4d  %7.1f us  %6.0f GB/s (compulsory bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
+#ifdef B8_STAMP
+        if (gemm_nt_big_applies(false, g)) print_stamps(c.K / 64);
+#endif
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias));
     }
     struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"}};
