@@ -543,11 +543,15 @@ void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t don
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
     static const bool no8 = getenv("CN_NO_BIG8") != nullptr;
-    // the persistent kernel: 32-bit byte offsets into every operand, whole 16-byte stores
+    // the persistent kernel: 32-bit byte offsets into every operand, whole 16-byte stores, and at least a dozen k-tiles per tile
+    // (a seam costs about five k-tiles of time; CN_BIG8_MIN_K, read per launch, lets the tests run it on short K)
+    const char *mk = getenv("CN_BIG8_MIN_K");
+    const int min_k = mk ? atoi(mk) : 12 * 64;
     const bool fits = (unsigned long long)g.M * g.lda * 2 < 0xfffffff0ull && (unsigned long long)g.N * g.ldb * 2 < 0xfffffff0ull &&
                       (!g.C || ((unsigned long long)g.M * g.ldc * 4 < 0xfffffff0ull && g.ldc % 4 == 0 && (uintptr_t)g.C % 16 == 0)) &&
                       (!g.C2 || ((unsigned long long)g.M * g.ldc2 * 2 < 0xfffffff0ull && g.ldc2 % 4 == 0 && (uintptr_t)g.C2 % 8 == 0)) &&
-                      g.N % 4 == 0 && (g.C || g.C2);
+                      g.N % 4 == 0 && (g.C || g.C2) &&
+                      g.K >= min_k;
     if (f32) hipExtLaunchKernelGGL(gemm_nt_big_kernel<true>, dim3(nwg), dim3(512), BG_LDS, s, nullptr, done, 0, g, tiles_n, nwg);
     else if (!no8 && fits) {
         const int grid = std::min(nwg, std::max(8, cus / 8 * 8)) / 8 * 8;

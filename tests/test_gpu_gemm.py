@@ -50,12 +50,13 @@ def test_gemm_nt(lib, prec, shape):
 
 
 @pytest.mark.parametrize("shape", [(4200, 6176, 256), (9000, 3104, 320), (7000, 4128, 832)])
-def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape):
+def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape, monkeypatch):
     """Race screen of the persistent 256 x 256 kernel (counted vmcnt waits, fills in flight across barriers and tile seams, two
     wave groups half a phase apart): nothing in it is order dependent, so 25 launches on the same operands must agree to the bit;
     K of 4, 5 and 13 k-tiles (the seam k-tiles are the first three of a tile; odd counts flip the buffer parity per tile)."""
     L, B = lib
     M, N, K = shape
+    monkeypatch.setenv("CN_BIG8_MIN_K", "256")        # (by default products under a dozen k-tiles keep the plain 256 x 256 kernel)
     rng = np.random.RandomState(M + N + K)
     A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32); bias = rng.randn(N).astype(np.float32)
     ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
@@ -75,11 +76,12 @@ def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape):
 @pytest.mark.parametrize("flag", [0x100, 0x200])
 @pytest.mark.parametrize("act", [0, 2])
 @pytest.mark.parametrize("shape", [(300, 256, 64), (6500, 4128, 512), (25000, 1024, 1024)])
-def test_gemm_nt_operand_copy_output(lib, shape, act, flag):
+def test_gemm_nt_operand_copy_output(lib, shape, act, flag, monkeypatch):
     """The operand-type (bf16) copy of the result, with and without the fp32 result beside it: the small shape runs the 128 x 128
     kernel, the large ones the persistent 256 x 256 kernel, whose seam stores count in its vmcnt waits (16 or 8 per phase)."""
     L, B = lib
     M, N, K = shape
+    monkeypatch.setenv("CN_BIG8_MIN_K", "256")
     rng = np.random.RandomState(M + N + K + act)
     A = bf16_round(rng.randn(M, K)); Bm = bf16_round(rng.randn(N, K)); bias = rng.randn(N).astype(np.float32)
     out = np.zeros((M, N), np.float32)
