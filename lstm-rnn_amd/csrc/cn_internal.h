@@ -104,6 +104,8 @@ void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p);
 // launch_lstm_backward dispatch to it when it applies
 bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd);
 void launch_lstm_s2(hipStream_t s, int prec, bool bwd, const LstmRec &p, hipEvent_t done = nullptr);
+bool lstm_s2w_applies(int prec, const LstmRec &p, bool bwd);
+void launch_lstm_s2w(hipStream_t s, bool bwd, const LstmRec &p, hipEvent_t done = nullptr);
 void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t done = nullptr);   // done: see launch_gemm_nt
 // cluster variants for layers whose W_rec exceeds one CU; return false when the shape is not covered
 // `num_cus`: the CU count of the device; the spin-wait hand-off needs every member workgroup resident, so a grid larger

@@ -976,6 +976,7 @@ size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T)
 
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p)
 {
+    if (lstm_s2w_applies(prec, p, false)) { launch_lstm_s2w(s, false, p); return; }
     if (lstm_s2_applies(prec, p, false)) { launch_lstm_s2(s, prec, false, p); return; }
     if (prec == P_F32) launch_rec<P_F32, false>(s, p);
     else if (prec == P_X3) launch_rec<P_X3, false>(s, p);

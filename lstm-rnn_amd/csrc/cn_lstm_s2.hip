@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_x3_asm_kernel(LstmRec p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, bf16, Hp = 256 on ONE CU ("s2w"; experimental: CN_S2W=1)
+// forward, bf16, Hp = 256 on ONE CU ("s2w"): the compiled twin of the hand-written loop below (CN_NO_S2W_ASM=1 selects it)
 // ---------------------------------------------------------------------------------------------
 // W_rec of a 256-unit direction is 512 KB of bf16 -- the whole register file of a CU.  The cluster kernels split the units
 // over two CUs and pay an L2 hop per step (0.8-1.0 us of their 1.3 us).  Here one CU keeps three of the four K chunks of
@@ -801,6 +801,158 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2w_kernel(LstmRec p)
         step(0, preA, ptA);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// forward, bf16, Hp = 256 on ONE CU: the time loop written by hand
+// ---------------------------------------------------------------------------------------------
+// The cut of lstm_fwd_s2w_kernel above (layout, operand order per accumulator and arithmetic: bit-equal on real slots) with the
+// instruction stream of the hand-written Hp = 128 loops: one `asm volatile`, constant SGPR bases + 32-bit VGPR offsets that
+// move by a step per step, two stages two steps ahead, every step the same code (guard steps, cn_api.cpp: dalloc_guarded), the
+// loop left after any step.  W_rec: K chunks 0 and 1 of all 16 fragments of a wave in the 256 AGPRs, chunk 2 in VGPRs except
+// two fragments, those two and chunk 3 (18 fragments, 36 KB per wave) streamed from LDS every step through three 8-register
+// buffers, each refilled right behind the MFMA that consumed it (nine or more MFMAs before its next use).  The 64 MFMAs of a
+// step run gate-major, pair A then pair B, on ONE set of accumulators: pair A's activations fill the gaps of the following gates'
+// and of pair B's MFMAs, pair B's accumulators are seeded as pair A's sums are read, only pair B's output gate is exposed
+// behind the last MFMA.  The step body is generated (tools/gen_s2w_loop.py -> cn_lstm_s2w_loop.inc): the schedule is a table
+// there, and the `s_waitcnt lgkmcnt` counts of the 44 LDS reads per step are derived from it.
+// vmcnt: a step issues, in order, pair A's prefetch (2 loads), pair B's (1), pair A's stores (4), pair B's (4).
+#include "cn_lstm_s2w_loop.inc"
+#ifdef CN_S2W_STAMP
+__device__ unsigned cn_s2w_stamp_buf[4][8];
+#endif
+
+__global__ __launch_bounds__(256) void lstm_fwd_s2w_asm_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 256;
+    constexpr int pitch = lds_pitch(HP);             // 288
+    constexpr int plane = 5 * pitch;                 // 1440: the generated loop carries it as literal offsets
+    constexpr int WL = 2 * plane + 64;               // streamed fragments: [wave][fragment j][half][lane][16 B]
+    static_assert(plane == 1440 && CN_GUARD_STEPS >= 3, "LDS offsets / prefetch distance of the hand-written loop");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = blockIdx.x % p.dirs, s0 = (blockIdx.x / p.dirs) * 2;
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = threadIdx.x * 4; i < 2 * plane; i += blockDim.x * 4) *(unsigned *)(smem + i) = 0u;
+
+    // fragment (pair S, view V, gate g, chunk K): rows g * HP + 64 * wave + 16 * (2 S + V) + c of W_rec, K values [64 K, 64 K + 64)
+    const char *Wd = (const char *)p.Wrec + (long)d * 4 * HP * HP * 2;
+    auto frag = [&](int S, int V, int g, int K) { return sp_load_bf16(Wd + ((long)(g * HP + 64 * wave + 16 * (2 * S + V) + c) * HP + K * 64 + q * 16) * 2); };
+    u32x8 wa[2][2][4][2], wv[2][2][4];
+#pragma unroll
+    for (int S = 0; S < 2; ++S)
+#pragma unroll
+        for (int V = 0; V < 2; ++V)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                wa[S][V][g][0] = frag(S, V, g, 0); wa[S][V][g][1] = frag(S, V, g, 1);
+                if (!(V == 1 && g == 0)) wv[S][V][g] = frag(S, V, g, 2);
+            }
+    const unsigned wl = WL + wave * (S2W_STREAM_COUNT * 2048) + lane * 16;
+    {
+        constexpr int tab[S2W_STREAM_COUNT][4] = S2W_STREAM_TABLE;
+#pragma unroll
+        for (int j = 0; j < S2W_STREAM_COUNT; ++j) {
+            const u32x8 f = frag(tab[j][0], tab[j][1], tab[j][2], tab[j][3]);
+            *(u32x4 *)(smem + wl + j * 2048) = __builtin_shufflevector(f, f, 0, 1, 2, 3);
+            *(u32x4 *)(smem + wl + j * 2048 + 1024) = __builtin_shufflevector(f, f, 4, 5, 6, 7);
+        }
+    }
+    const int spidx = sp_index(c);
+    const int vrow0 = (c & 10) == 0 ? 2 * (c >> 2) + (c & 1) : 4;
+    const int vrow1 = (c & 10) == 8 ? 2 * ((c >> 2) & 1) + (c & 1) : 4;
+    const unsigned av0 = vrow0 * pitch + q * 16, av1 = vrow1 * pitch + q * 16;
+
+    // pair A: unit 64 wave + 16 ug + c, pair B: 32 units on (acts + 512 B, cell / tanh + 128 B, y + 64 B)
+    const int unit = 64 * wave + 16 * ug + c;
+    const float piA = p.peep[(d * 3 + 0) * HP + unit], pfA = p.peep[(d * 3 + 1) * HP + unit], poA = p.peep[(d * 3 + 2) * HP + unit];
+    const float piB = p.peep[(d * 3 + 0) * HP + unit + 32], pfB = p.peep[(d * 3 + 1) * HP + unit + 32], poB = p.peep[(d * 3 + 2) * HP + unit + 32];
+    const int sv = s0 + sq;
+    const int kA = unit & 63, kB = (unit + 32) & 63;
+    const unsigned oTA = (2 * sq + sp_parity(kA)) * pitch + ((unit >> 6) * 32 + sp_pos(kA)) * 2;
+    const unsigned oTB = (2 * sq + sp_parity(kB)) * pitch + (((unit + 32) >> 6) * 32 + sp_pos(kB)) * 2;
+    // offsets BIAS steps ahead, bases BIAS steps behind (see lstm_fwd_s2_asm_kernel)
+    constexpr long BIAS = 8;
+    const long t0 = d ? T - 1 : 0, dt = d ? -1 : 1;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4, oY = (unsigned)((t0 + BIAS) * stepC * 2) + lC * 2;
+    unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
+    const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sY = (unsigned)(dt * stepC * 2), sP = (unsigned)(dt * PS);
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *actspf = acts + 2 * dt * stepA * 4, *actspf1 = acts + dt * stepA * 4, *acts1 = acts - dt * stepA * 4;
+    const char *pat = p.pat - BIAS * PS, *patpf = pat + 2 * dt * PS;
+    const char *cell1 = (const char *)p.cell - (BIAS + dt) * stepC * 4, *th1 = (const char *)p.th - (BIAS + dt) * stepC * 4;
+    const char *yop1 = (const char *)p.y_op - (BIAS + dt) * stepC * 2;
+    unsigned cnt = (unsigned)T - 1;                  // steps behind the current one
+
+    float cstA = 0.f, cstB = 0.f;
+    int ptP, ptQ;
+    u32x4 a00, a01, a10, a11, a20, a21, a30, a31;
+    float x4, x5;
+#ifdef CN_S2W_STAMP
+    unsigned st[6] = {0, 0, 0, 0, 0, 0}, tq;
+    unsigned long long tm;
+    unsigned tl = (unsigned)__builtin_amdgcn_s_memtime();
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    lds_barrier();
+    asm volatile(
+        // accumulator rows 2, 3 belong to rows of zeros in both views and stay 0 for the whole pass
+        "v_mov_b32 v226, 0\n\tv_mov_b32 v227, 0\n\tv_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\t"
+        "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t"
+        // stages of the first two steps, the first three streamed fragments
+        "global_load_ubyte %[ptP], %[oP], %[pat]\n\t"
+        "global_load_dwordx4 v[208:211], %[oA], %[acts]\n\t"
+        "global_load_dwordx4 v[212:215], %[oA], %[acts] offset:512\n\t"
+        "v_add_u32 %[x4], %[oP], %[sP]\n\t"
+        "v_add_u32 %[x5], %[oA], %[sA]\n\t"
+        "global_load_ubyte %[ptQ], %[x4], %[pat]\n\t"
+        "global_load_dwordx4 v[216:219], %[x5], %[acts]\n\t"
+        "global_load_dwordx4 v[220:223], %[x5], %[acts] offset:512\n\t"
+        "ds_read_b128 v[176:179], %[wl]\n\t"
+        "ds_read_b128 v[180:183], %[wl] offset:1024\n\t"
+        "ds_read_b128 v[184:187], %[wl] offset:2048\n\t"
+        "ds_read_b128 v[188:191], %[wl] offset:3072\n\t"
+        "ds_read_b128 v[192:195], %[wl] offset:4096\n\t"
+        "ds_read_b128 v[196:199], %[wl] offset:5120\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        "1:\n\t"
+        S2W_STEP_P
+        S2W_STEP_Q
+        "s_branch 1b\n\t"
+        "9:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"               // (nothing the compiler does not know of may be in flight when the statement ends)
+        : [cstA] "+v"(cstA), [cstB] "+v"(cstB), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [cnt] "+s"(cnt),
+          [ptP] "=&v"(ptP), [ptQ] "=&v"(ptQ), [a00] "=&v"(a00), [a01] "=&v"(a01), [a10] "=&v"(a10), [a11] "=&v"(a11),
+          [a20] "=&v"(a20), [a21] "=&v"(a21), [a30] "=&v"(a30), [a31] "=&v"(a31), [x4] "=&v"(x4), [x5] "=&v"(x5)
+#ifdef CN_S2W_STAMP
+          , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]),
+          [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#endif
+        : S2W_W_OPERANDS,
+          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [wl] "v"(wl), [oTA] "v"(oTA), [oTB] "v"(oTB),
+          [piA] "v"(piA), [pfA] "v"(pfA), [poA] "v"(poA), [piB] "v"(piB), [pfB] "v"(pfB), [poB] "v"(poB),
+          [acts] "s"(acts), [actspf] "s"(actspf), [actspf1] "s"(actspf1), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
+          [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP)
+        : "memory", "vcc", "scc",
+          "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191",
+          "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207",
+          "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+          "v248", "v249", "v250", "v251", "v252", "v253");
+#ifdef CN_S2W_STAMP
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 6; ++i) cn_s2w_stamp_buf[wave][i] = st[i];
+        cn_s2w_stamp_buf[wave][7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+    }
+#endif
+}
+#ifdef CN_S2W_STAMP
+extern "C" int cn_dbg_read_stamps_s2f(unsigned *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_s2w_stamp_buf), sizeof(cn_s2w_stamp_buf)); }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // backward
@@ -1642,6 +1794,27 @@ bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
     if (getenv("CN_NO_S2") || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
     if (p.dirs * (p.PS / 2) > p.num_cus) return false;
     return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;
+}
+
+// Hp = 256 on one CU (forward pass, bf16): before the 2-CU cluster kernels wherever every pair of sequences gets a CU
+bool lstm_s2w_applies(int prec, const LstmRec &p, bool bwd)
+{
+    if (getenv("CN_NO_S2W") || bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2) return false;
+    if (p.dirs * (p.PS / 2) > p.num_cus) return false;
+    return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // 32-bit byte offsets, 8 steps ahead
+}
+
+void launch_lstm_s2w(hipStream_t s, bool bwd, const LstmRec &p, hipEvent_t done)
+{
+    static DeviceOnce once;
+    if (once.first()) {
+        (void)hipFuncSetAttribute((const void *)lstm_fwd_s2w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)lstm_fwd_s2w_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    const bool hand = !getenv("CN_NO_S2W_ASM");
+    const size_t lds = 2 * 5 * (size_t)lds_pitch(256) + 64 + 4 * (size_t)(hand ? S2W_STREAM_COUNT * 2048 : 32768);
+    hipExtLaunchKernelGGL(hand ? lstm_fwd_s2w_asm_kernel : lstm_fwd_s2w_kernel, dim3(p.dirs * (p.PS / 2)), dim3(256), lds, s, nullptr, done, 0, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, hand ? "lstm_fwd_s2w_asm_kernel" : "lstm_fwd_s2w_kernel");
 }
 
 template <int PREC, bool BWD, int HP>

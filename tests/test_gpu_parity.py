@@ -674,6 +674,46 @@ def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, mon
         assert rel_err(g, got["cpp"][2][name]) < 1e-6, name
 
 
+@pytest.mark.parametrize("kind,size,T", [("blstm", 500, 1), ("blstm", 500, 2), ("blstm", 500, 3), ("lstm", 250, 6), ("blstm", 512, 37), ("blstm", 500, 64)])
+def test_hand_written_wide_forward_loop_equals_its_compiled_twin_bit_for_bit(pkg, orc, monkeypatch, kind, size, T):
+    """Hp = 256 on one CU (cn_lstm_s2.hip: lstm_fwd_s2w_asm_kernel, generated step body with 64 MFMAs, 18 W fragments streamed
+    from LDS per step) against lstm_fwd_s2w_kernel, the compiled kernel of the same cut (CN_NO_S2W_ASM): every forward value on a
+    real slot bit-identical; and against the 2-CU cluster kernel it replaces (CN_NO_S2W) and the CPU oracle at the bf16
+    tolerances.  T = 1, 2, 3: the loop is left after any step; T = 64 = the buffers' length: the prefetch runs into the guard steps."""
+    rng = np.random.RandomState(700 + T)
+    P, C, PS = 9, 7, 11
+    layers = net_desc(P, [(kind, size), (kind, size)], C)
+    weights = random_weights(layers, rng, 0.05)
+    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]
+    lengths[0] = T
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    real = real_mask(frac)
+    got = {}
+    for mode, env in (("asm", None), ("cpp", "CN_NO_S2W_ASM"), ("cluster", "CN_NO_S2W")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+            net.load_sequences(frac); net.compute_forward_pass()
+            e, c = net.error_and_correct()
+            name = net.recurrent_kernel(False)
+            vals = {"error": np.float32(e), "out": net.outputs().reshape(-1, C)[real]}
+            for lay in net.layers[1:3]:
+                for dd in range(lay.dirs):
+                    for nm in ("cellStates", "niActs", "igActs", "fgActs", "ogActs", "tmpOutputs"):
+                        vals["%s/%d/%s" % (lay.name, dd, nm)] = lay.internal(nm, dd).reshape(-1, lay.H)[real]
+            got[mode] = (name, vals)
+    assert got["asm"][0] == "lstm_fwd_s2w_asm_kernel" and got["cpp"][0] == "lstm_fwd_s2w_kernel"
+    assert got["cluster"][0].startswith("lstm_fwd_cluster"), got["cluster"][0]
+    for key, v in got["asm"][1].items():
+        assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
+    ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+    ref.load_sequences(frac); ref.compute_forward_pass()
+    want = ref.outputs().reshape(-1, C)[real]
+    assert np.abs(got["asm"][1]["out"] - want).max() < 3e-2
+    assert np.abs(got["asm"][1]["out"] - got["cluster"][1]["out"]).max() < 3e-2
+
+
 @pytest.mark.parametrize("kind,size,T", [("blstm", 250, 1), ("blstm", 250, 2), ("blstm", 250, 5), ("lstm", 128, 9), ("blstm", 256, 37), ("blstm", 250, 64)])
 def test_hand_written_split_bf16_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
     """The same for the split-bf16 (CN_PREC_BF16X3) hand-written loops of the s2 cut against the compiled kernels of that cut
