@@ -102,3 +102,16 @@ def test_oracle_quirks(orc):
     wts = np.array([1.0, 2.0], np.float32); g = np.array([0.5, -1.0], np.float32); dl = np.array([0.1, 0.0], np.float32)
     L.orc_sgd_update(2, 0.1, 0.9, wts, g, dl)
     assert np.allclose(dl, [0.9 * 0.1 - 0.05, 0.1]) and np.allclose(wts, [1.04, 2.1])
+
+
+def test_generated_step_body_of_the_wide_forward_loop_is_in_sync_with_its_generator():
+    """lstm-rnn_amd/csrc/cn_lstm_s2w_loop.inc is the output of tools/gen_s2w_loop.py (schedule table -> asm string with derived
+    lgkmcnt counts): an edit of either without the other would ship a loop nobody generated."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_s2w_loop.py")], capture_output=True, text=True, check=True).stdout
+    with open(os.path.join(root, "lstm-rnn_amd", "csrc", "cn_lstm_s2w_loop.inc")) as f:
+        assert f.read() == out
+    body = out.split("#else")[1]
+    assert body.count("v_smfmac_f32_16x16x64_bf16") == 2 * 64        # two step bodies of 64 MFMAs
+    assert body.count("ds_read_b128") == 2 * (8 + 36)               # operand reads + streamed fragments
