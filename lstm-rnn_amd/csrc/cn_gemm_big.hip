@@ -355,7 +355,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big8_kernel(GemmNT p, int tiles_n
             }
         }
     };
-    auto load_bias = [&](int n0) {                              // two loads, always (they count in vmcnt)
+    // Two loads, always (they count in vmcnt).  Issued through asm so that hipcc does not know of them: a load it tracks would
+    // get a compiler-inserted vmcnt wait at its first use in the next tile's seam (vmcnt(0) across the loop's back edge: the fill
+    // stream drained once per tile).  Sound only while the compiled code does not touch biasv[] before one of the kernel's own
+    // counted waits has retired the load; tests/test_abi_and_host.py checks that on the ISA.
+    auto load_bias = [&](int n0) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = min(n0 + wc * 64 + j * 32 + (fresh_lane() & 31), p.N - 1);

@@ -115,3 +115,29 @@ def test_generated_step_body_of_the_wide_forward_loop_is_in_sync_with_its_genera
     body = out.split("#else")[1]
     assert body.count("v_smfmac_f32_16x16x64_bf16") == 2 * 64        # two step bodies of 64 MFMAs
     assert body.count("ds_read_b128") == 2 * (8 + 36)               # operand reads + streamed fragments
+
+
+def test_persistent_gemm_never_touches_its_bias_registers_before_a_counted_wait_retires_the_load(tmp_path):
+    """gemm_nt_big8_kernel fetches the next tile's bias with an asm load the compiler knows nothing about (a plain load would
+    make hipcc drain vmcnt at every tile seam); that is only sound while the compiled code leaves the destination registers alone
+    until one of the kernel's own counted waits has retired the load -- the first `s_waitcnt vmcnt(6)` behind it (third k-tile
+    of the tile, phase 1) or the `vmcnt(0)` in front of the last tile's stores.  Checked on the ISA hipcc produces here."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "big.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(root, "lstm-rnn_amd", "csrc", "cn_gemm_big.hip")], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    loads = [i for i, l in enumerate(lines) if re.match(r"\s*global_load_dword v\d+,", l)]
+    assert len(loads) == 4                                   # two per instantiation (C or C2 / both)
+    for i in loads:
+        reg = re.match(r"\s*global_load_dword (v\d+),", lines[i]).group(1)
+        for l in lines[i + 1:]:
+            if re.search(r"s_waitcnt vmcnt\((6|0)\)", l):
+                break
+            assert not re.search(r"\b%s\b" % reg, l), (reg, l)
+        else:
+            raise AssertionError("no wait behind the bias load")
