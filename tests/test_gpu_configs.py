@@ -154,6 +154,65 @@ def test_config3_lvcsr_softmax8000_bf16(pkg, orc):
             assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 6e-2, lay.name
 
 
+@pytest.mark.parametrize("precision,tol,gtol", [(0, 1e-4, 2e-4), (2, 1e-4, 2e-4), (1, 3e-2, 6e-2)])
+def test_config3_lvcsr_stack_at_sixteen_sequences_of_up_to_96_frames(pkg, orc, precision, tol, gtol):
+    """The LVCSR stack (40 -> 2 x blstm512 -> softmax 8000) at a size where the kernels run the shapes they run in the bench:
+    PS = 16 (eight workgroups per direction in the one-CU-per-pair forward loop of the bf16 mode, four 2-CU clusters per direction
+    in its backward pass and in the split-bf16 mode), T = 96 with ragged lengths, ~1 300 frames x 8000 classes against the
+    multi-threaded oracle; f32 and bf16x3 at the fp32 tolerances, bf16 at its own."""
+    orc.set_threads(8)
+    try:
+        rng = np.random.RandomState(53)
+        P, C, PS = 40, 8000, 16
+        layers = net_desc(P, [("blstm", 512)] * 2, C)
+        weights = random_weights(layers, rng, 0.05)
+        lengths = [96, 96, 91, 90, 88, 85, 85, 80, 77, 77, 70, 64, 50, 33, 17, 5]
+        xs, ts = random_sequences(rng, lengths, P, C=C)
+        frac = pkg.make_fraction(xs, ts, PS)
+        ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision)
+        with net:
+            if precision == 1:
+                assert net.recurrent_kernel(False) == "lstm_fwd_s2w_asm_kernel" and net.recurrent_kernel(True).startswith("lstm_bwd_cluster_kernel")
+            real = real_mask(frac)
+            y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+            assert np.abs(y - yr).max() < tol and np.abs(y.sum(1) - 1.0).max() < 1e-4
+            assert abs(e - e_ref) < (1e-2 if precision == 1 else 1e-4) * e_ref
+            for lay in net.trainable_layers():
+                assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < gtol, lay.name
+    finally:
+        orc.set_threads(1)
+
+
+@pytest.mark.parametrize("precision,tol,gtol", [(0, 1e-4, 2e-4), (2, 1e-4, 2e-4), (1, 3e-2, 6e-2)])
+def test_config1_reading_b_three_layers_of_250_units_per_direction(pkg, orc, precision, tol, gtol):
+    """BASELINE configs[1] in its second reading (39 -> 3 x blstm500 -> softmax 183: 250 units per direction, Hp = 256) at PS = 16,
+    T = 96, ragged, one unused slot: the one-CU-per-pair forward loop + 2-CU backward clusters (bf16), the 4-CU clusters
+    (bf16x3), the streaming kernels (f32), against the multi-threaded oracle."""
+    orc.set_threads(8)
+    try:
+        rng = np.random.RandomState(54)
+        P, C, PS = 39, 183, 16
+        layers = net_desc(P, [("blstm", 500)] * 3, C)
+        weights = random_weights(layers, rng, 0.06)
+        lengths = [96, 95, 93, 90, 90, 84, 80, 71, 66, 60, 52, 41, 30, 12, 3]
+        xs, ts = random_sequences(rng, lengths, P, C=C)
+        frac = pkg.make_fraction(xs, ts, PS)
+        ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision)
+        with net:
+            if precision == 1:
+                assert net.recurrent_kernel(False) == "lstm_fwd_s2w_asm_kernel"
+            real = real_mask(frac)
+            y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+            assert np.abs(y - yr).max() < tol
+            assert abs(e - e_ref) < (1e-2 if precision == 1 else 1e-4) * e_ref
+            if precision != 1:
+                assert c == c_ref
+            for lay in net.trainable_layers():
+                assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < gtol, lay.name
+    finally:
+        orc.set_threads(1)
+
+
 def test_config4_long_utterance_T2000_cluster_vs_oracle(pkg, orc):
     """BASELINE configs[4] layer shape: 39 -> blstm1024 -> softmax183, T = 2000, bf16 8-CU cluster kernels against the
     fp32 oracle (about 90 GFLOP of oracle work).  Ragged: one sequence ends at 1 501, the fraction has an unused slot.
