@@ -45,7 +45,9 @@ int main()
         {15600, 1024, 256, "input projection layer 2/3 (acts)"}, {15600, 1024, 64, "input projection layer 1"},
         {15600, 256, 1024, "error to preceding layer (a7)"}, {15600, 192, 256, "softmax projection"}, {15600, 256, 192, "softmax E_prev"},
         {15600, 2048, 512, "reading B input projection (Hp = 256)"}, {15600, 512, 2048, "reading B error to preceding layer"}, {32000, 4096, 1024, "long-utterance input projection (Hp = 512)"},
-        {25600, 8000, 1024, "LVCSR softmax projection"}, {25600, 1024, 8000, "LVCSR softmax E_prev"}, {25600, 2048, 1024, "LVCSR layer input projection (Hp = 256)"}};
+        {25600, 8000, 1024, "LVCSR softmax projection"}, {25600, 1024, 8000, "LVCSR softmax E_prev"}, {25600, 2048, 1024, "LVCSR layer input projection (Hp = 256)"},
+        {51200, 2048, 512, "LVCSR as run by bench.py: input projection of layers 2-4 (blstm512 = 256 per direction), T = 800"},
+        {35200, 2048, 512, "the same at T = 550"}, {51200, 512, 2048, "LVCSR error to the preceding layer"}, {51200, 8000, 512, "LVCSR softmax projection"}, {51200, 512, 8000, "LVCSR softmax E_prev"}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto &c : nt) {
