@@ -442,11 +442,12 @@ def main():
         pr = pr or args.precision
         big = name in ("lvcsr_4x512_blstm_8000", "longutt_5x1024_blstm")
         st2, wu2 = (min(args.steps, 5), min(args.warmup, 2)) if big else (args.steps, args.warmup)
-        r2, wl2 = run_workload(name, st2, wu2, pr, roofline_pass=big, min_seconds=0 if big else min(min_seconds, 0.25))
+        roof2 = big or spec == "timit_3x500_blstm_H250"      # (reading B: the other reading of the headline config gets its roofline too)
+        r2, wl2 = run_workload(name, st2, wu2, pr, roofline_pass=roof2, min_seconds=0 if big else min(min_seconds, 0.25))
         v2 = r2["frames"] / r2["seconds"]
         also[spec] = {"value": v2, "unit": "frames/s", "dtype": pr, "ms_per_step": 1e3 * r2["seconds"] / st2, "steps": st2, "repeats": r2["repeats"],
                       "parallel_sequences": r2["PS"], "seq_len": "U[%d,%d]" % (r2["tmin"], r2["tmax"])}
-        if big and "timing" in r2:
+        if roof2 and "timing" in r2:
             rr = roofline_records(r2, wl2, name, r2["PS"], pr, v2)
             also[spec].update({"roofline": rr["roofline"], "roofline_other": rr["roofline_other"], "roofline_pair": rr["roofline_pair"],
                                "roofline_mfma": rr["roofline_mfma"]})
