@@ -518,28 +518,41 @@ __global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const c
         return;
     }
     float *r = y + row * Lp;
+    // a thread owns the four columns 4 (tid + 256 q) .. + 3 of every q (16-byte loads and stores; Lp is a multiple of 32):
+    // v[k] is column col(k) = 4 (tid + 256 (k >> 2)) + (k & 3), ascending in k
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    auto col = [&](int k) { return 4 * (tid + 256 * (k >> 2)) + (k & 3); };
     float v[SMW_VPT];
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) { const int j = tid + 256 * k; v[k] = j < L ? r[j] : 0.f; }
+    for (int q = 0; q < SMW_VPT / 4; ++q) {
+        const int j0 = 4 * (tid + 256 * q);
+        const f32x4 x = j0 < Lp ? *(const f32x4 *)(r + j0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[4 * q] = x[0]; v[4 * q + 1] = x[1]; v[4 * q + 2] = x[2]; v[4 * q + 3] = x[3];
+    }
     const int tc = rowstat ? tcls[row] : -1;
     float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) if (tid + 256 * k < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
+    for (int k = 0; k < SMW_VPT; ++k) if (col(k) < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
     mx = block_reduce(mx, 1, sh); mn = block_reduce(mn, 2, sh);
     const float offset = 0.5f * (mn + mx);               // :74
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) if (tid + 256 * k < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
+    for (int k = 0; k < SMW_VPT; ++k) if (col(k) < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
     sum = block_reduce(sum, 0, sh);
     float best = 0.f, ptv = 0.f; int bi = 0;
 #pragma unroll
     for (int k = 0; k < SMW_VPT; ++k) {
-        const int j = tid + 256 * k;
+        const int j = col(k);
         if (j < L) {
-            const float w = v[k] / sum; r[j] = w;        // :152
+            const float w = v[k] / sum; v[k] = w;        // :152
             if (w > best) { best = w; bi = j; }          // ascending j per thread: first maximum kept
             if (j == tc) ptv = w;
         }
+    }
+#pragma unroll
+    for (int q = 0; q < SMW_VPT / 4; ++q) {              // (columns L .. Lp - 1 get back what they held)
+        const int j0 = 4 * (tid + 256 * q);
+        if (j0 < Lp) *(f32x4 *)(r + j0) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
     }
     if (rowstat) {
         ptv = block_reduce(ptv, 0, sh);
