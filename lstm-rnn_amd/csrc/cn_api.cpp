@@ -481,15 +481,16 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
     r.rpl = c->rpl;
-    r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = c->num_cus;
+    r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = r.cluster_cus = c->num_cus;
     // With a communicator bound, RCCL's persistent workgroups hold CUs on the communication stream while they wait for peer
     // ranks, beside the recurrent kernel of the layer below.  A cluster grid needs ALL its members resident (spin-wait
     // hand-off), so it must fit what RCCL leaves: the grid is sized against num_cus minus a margin for RCCL's channels
     // (CN_COMM_CU_MARGIN, default 32 -- RCCL's MI300-class defaults stay at or below that many workgroups per collective);
-    // a grid that no longer fits takes the streaming kernels, which make no residency assumption.
+    // a grid that no longer fits takes the streaming kernels, which make no residency assumption.  The one-CU kernels (s2, s2w,
+    // 4-sequence) make none either and keep the full count, so that a data-parallel run picks the kernels of a one-GPU run.
     if (c->comm) {
         static const int margin = getenv("CN_COMM_CU_MARGIN") ? atoi(getenv("CN_COMM_CU_MARGIN")) : 32;
-        r.num_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
+        r.cluster_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
     }
     r.kname = nullptr;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
@@ -888,6 +889,9 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
         // exchange and update can be checked on a one-GPU box: a reduction that starts early or an update that does not wait
         // shows in the trained weights
         const bool test_double = getenv("CN_COMM_TEST_DOUBLE") != nullptr;
+        if (test_double && ctx->comm_world > 1)
+            throw cn_error(CN_ERR_STATE, "cn_allreduce_grads: CN_COMM_TEST_DOUBLE is set in a job of more than one rank (it replaces the "
+                                         "gradient exchange by a stand-in and is for one-rank ordering tests only)");
         if (n == 0) {
             // the whole arena in one exchange: every gradient GEMM first, then fork the communication stream
             join_side(ctx);

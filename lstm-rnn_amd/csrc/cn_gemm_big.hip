@@ -230,6 +230,9 @@ __device__ unsigned g_b8_kind[2][4];      // cycles per k-tile kind (normal, fir
 namespace {
 
 constexpr int b8_cap(int n) { return n > 63 ? 63 : n; }         // vmcnt is six bits: a smaller count only waits longer
+// What load_bias() fetches for a product without a bias (K8, K13: bias == nullptr): the load must exist (it counts in vmcnt), so
+// it reads a word that holds 0.f.
+__device__ const float b8_zero_word[1] = {0.f};
 
 template <int OUTS>                                             // 1: C or C2, 2: both
 __global__ __launch_bounds__(512) void gemm_nt_big8_kernel(GemmNT p, int tiles_n, int nwg)
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big8_kernel(GemmNT p, int tiles_n
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = min(n0 + wc * 64 + j * 32 + (fresh_lane() & 31), p.N - 1);
-            const float *src = has_bias ? p.bias + n : (const float *)p.B;
+            const float *src = has_bias ? p.bias + n : b8_zero_word;   // no bias: the counted load fetches a word that IS 0.f
             float b;
             asm volatile("global_load_dword %0, %1, off" : "=v"(b) : "v"(src) : "memory");
             biasv[j] = b;

@@ -90,7 +90,9 @@ struct LstmRec {
     unsigned long long *xch;      // exchange granules (nullable: cluster path off), zeroed at allocation
     unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T (launch_lstm_cluster sets it and advances the counter)
     int *fault;                   // set to 1 by a bounded spin that gave up
-    int num_cus;                  // CUs of the device: a cluster grid must be resident as a whole
+    int num_cus;                  // CUs of the device (the one-CU kernels' "does the grid fit the chip in one wave" rule)
+    int cluster_cus;              // CUs a cluster grid may count on: a cluster grid must be resident as a whole (spin-wait hand-off),
+                                  // so with a communicator bound this is num_cus minus a margin for RCCL's channels
     char *kname;                  // nullable, CN_KNAME_LEN bytes: the launcher writes the name of the kernel it instantiated
 };
 constexpr int CN_KNAME_LEN = 64;

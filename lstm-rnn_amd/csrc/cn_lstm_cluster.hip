@@ -715,7 +715,7 @@ void lstm_cluster_stream_gone(hipStream_t s)
 
 bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned *epoch)
 {
-    if (!p.xch || lstm_cluster_size(prec, p.Hp, p.dirs, p.PS, p.rpl, p.num_cus) == 0) return false;
+    if (!p.xch || lstm_cluster_size(prec, p.Hp, p.dirs, p.PS, p.rpl, p.cluster_cus) == 0) return false;
     if (lstm_s2w_applies(prec, p, bwd)) return false;          // one CU per pair of sequences, no hop (cn_lstm_s2.hip)
     p.xch_epoch = *epoch;
     *epoch += (unsigned)p.T + 1;

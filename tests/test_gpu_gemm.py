@@ -49,34 +49,39 @@ def test_gemm_nt(lib, prec, shape):
         assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()
 
 
+@pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("shape", [(4200, 6176, 256), (9000, 3104, 320), (7000, 4128, 832)])
-def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape, monkeypatch):
+def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape, with_bias, monkeypatch):
     """Race screen of the persistent 256 x 256 kernel (counted vmcnt waits, fills in flight across barriers and tile seams, two
     wave groups half a phase apart): nothing in it is order dependent, so 25 launches on the same operands must agree to the bit;
-    K of 4, 5 and 13 k-tiles (the seam k-tiles are the first three of a tile; odd counts flip the buffer parity per tile)."""
+    K of 4, 5 and 13 k-tiles (the seam k-tiles are the first three of a tile; odd counts flip the buffer parity per tile).
+    with_bias = False is the call the backward pass makes (K8 / K13: bias == NULL, identity, C only): the kernel still issues
+    its two counted bias loads and must add exactly zero."""
     L, B = lib
     M, N, K = shape
     monkeypatch.setenv("CN_BIG8_MIN_K", "256")        # (by default products under a dozen k-tiles keep the plain 256 x 256 kernel)
     rng = np.random.RandomState(M + N + K)
     A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32); bias = rng.randn(N).astype(np.float32)
+    bias_p = bias.ctypes.data if with_bias else None
     ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
     try:
         first = np.zeros((M, N), np.float32)
-        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, first.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
-        ref = bf16_round(A) @ bf16_round(Bm).T + bias
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, first.ctypes.data, M, N, K, bias_p, 2), ctx)
+        ref = bf16_round(A) @ bf16_round(Bm).T + (bias if with_bias else 0.0)
         assert np.abs(first - ref).max() < 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
         out = np.zeros((M, N), np.float32)
-        for rep in range(24):
-            B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+        for rep in range(24 if with_bias else 4):
+            B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias_p, 2), ctx)
             assert np.array_equal(out, first), (rep, np.abs(out - first).max())
     finally:
         L.cn_ctx_destroy(ctx)
 
 
+@pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("flag", [0x100, 0x200])
 @pytest.mark.parametrize("act", [0, 2])
 @pytest.mark.parametrize("shape", [(300, 256, 64), (6500, 4128, 512), (25000, 1024, 1024)])
-def test_gemm_nt_operand_copy_output(lib, shape, act, flag, monkeypatch):
+def test_gemm_nt_operand_copy_output(lib, shape, act, flag, with_bias, monkeypatch):
     """The operand-type (bf16) copy of the result, with and without the fp32 result beside it: the small shape runs the 128 x 128
     kernel, the large ones the persistent 256 x 256 kernel, whose seam stores count in its vmcnt waits (16 or 8 per phase)."""
     L, B = lib
@@ -87,15 +92,33 @@ def test_gemm_nt_operand_copy_output(lib, shape, act, flag, monkeypatch):
     out = np.zeros((M, N), np.float32)
     ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
     try:
-        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, act | flag), ctx)
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K,
+                                 bias.ctypes.data if with_bias else None, act | flag), ctx)
     finally:
         L.cn_ctx_destroy(ctx)
-    ref = A @ Bm.T + bias
+    ref = A @ Bm.T + (bias if with_bias else 0.0)
     if act == 0:
         ref = np.tanh(ref)
     tol = 2e-4 * np.sqrt(K) + 2.0 ** -8 * np.abs(ref) + 1e-5          # (bf16 keeps 8 bits)
     bad = np.abs(out - ref) - tol
     assert bad.max() < 0, (bad.max(), np.unravel_index(bad.argmax(), bad.shape))
+
+
+@pytest.mark.parametrize("shape", [(1000, 1024, 256), (6500, 4128, 512), (25000, 1024, 1024)])
+def test_gemm_nt_without_bias(lib, shape):
+    """bias == NULL on every nt kernel family (128 x 128, 256 x 256, persistent 256 x 256) at the default dispatch thresholds."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K + 1)
+    A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32)
+    out = np.full((M, N), 7.0, np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, None, 2), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    ref = bf16_round(A) @ bf16_round(Bm).T
+    assert np.abs(out - ref).max() < 2e-4 * np.sqrt(K) + 1e-5 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
