@@ -59,6 +59,49 @@ typedef float real_t;
 
 #define PATTYPE_NONE 0
 
+/* ------------------------------------------------------------------------- */
+/* operand rounding (a MODEL of the product's bf16 mode, not reference code)   */
+/* ------------------------------------------------------------------------- */
+/*
+ * orc_set_operand_rounding(1): every matrix product of the path -- Matrix.cu's assignProduct / addProduct call sites
+ * (LstmLayer.cu:774-785,815-818,850-853,939-942,973-976,996-1006, FeedForwardLayer.cu:148-152,190-197,202-206) and the
+ * input / internal weight cases of ComputeWeightUpdateFn (LstmLayer.cu:370-390,410-437) -- rounds BOTH operands to bf16
+ * (round to nearest even) before multiplying, and an LSTM layer stores its outputs rounded (the HIP library keeps them in
+ * bf16 only).  Everything else is untouched fp32: accumulation in the reference's order, cell states, gate activations
+ * with libm expf, bias and peephole weights, the clipped deltas carried to the neighbouring time step, the bias / peephole
+ * gradient sums (they read the unrounded deltas), softmax, losses, the update.  This is exactly the set of values
+ * CN_PREC_BF16 rounds (`op` buffers and packed weights), so what remains between this mode and the
+ * HIP path is summation order and v_exp_f32 / v_rcp_f32 -- tests/test_gpu_bf16_pinned.py holds that to 2e-4.
+ * Mode 0 (default) is the reference's arithmetic; no statement of mode 0 changes when the mode exists: the rounded
+ * copies are made in front of the unchanged loops.
+ */
+#include <stdint.h>
+static int g_opround = 0;
+void orc_set_operand_rounding(int mode) { g_opround = mode ? 1 : 0; }
+int orc_get_operand_rounding(void) { return g_opround; }
+
+static real_t bf16_rne(real_t v)
+{
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    if ((u & 0x7f800000u) == 0x7f800000u) return v;              /* inf / nan: as is */
+    u += 0x7fffu + ((u >> 16) & 1u);
+    u &= 0xffff0000u;
+    memcpy(&v, &u, 4);
+    return v;
+}
+static real_t *rounded_copy(const real_t *src, size_t n)
+{
+    real_t *q = (real_t *)malloc(sizeof(real_t) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) q[i] = bf16_rne(src[i]);
+    return q;
+}
+/* operands of one product: rounded copies in mode 1, the caller's arrays otherwise */
+#define MM_OPERANDS(na, nb) \
+    real_t *aq_ = NULL, *bq_ = NULL; \
+    if (g_opround) { aq_ = rounded_copy(a, (size_t)(na)); bq_ = rounded_copy(b, (size_t)(nb)); a = aq_; b = bq_; }
+#define MM_RELEASE() do { free(aq_); free(bq_); } while (0)
+
 /* helpers/NumericLimits.cuh:39-43 */
 #define NL_MIN      1.1754944e-038f
 #define NL_MAX      3.4028235e+038f
@@ -138,6 +181,7 @@ static void mm_nn(real_t *c, const real_t *a, int rowsA, int colsA,
                   const real_t *b, int rowsB, int colsB, int add)
 {
     int total = rowsA * colsB;
+    MM_OPERANDS((size_t)rowsA * colsA, (size_t)rowsB * colsB)
     ORC_PAR((long)total * colsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offRowA = a + (idx % rowsA);
@@ -147,6 +191,7 @@ static void mm_nn(real_t *c, const real_t *a, int rowsA, int colsA,
             x += offRowA[i * rowsA] * offColB[i];
         c[idx] = add ? c[idx] + x : x;
     }
+    MM_RELEASE();
 }
 
 /* C(colsA x colsB) (+)= A^T * B,  A(rowsA x colsA), B(rowsA x colsB)
@@ -155,6 +200,7 @@ static void mm_tn(real_t *c, const real_t *a, int rowsA, int colsA,
                   const real_t *b, int rowsB, int colsB, int add)
 {
     int total = colsA * colsB;
+    MM_OPERANDS((size_t)rowsA * colsA, (size_t)rowsB * colsB)
     ORC_PAR((long)total * rowsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offColA = a + (idx % colsA) * rowsA;
@@ -164,6 +210,7 @@ static void mm_tn(real_t *c, const real_t *a, int rowsA, int colsA,
             x += offColA[i] * offColB[i];
         c[idx] = add ? c[idx] + x : x;
     }
+    MM_RELEASE();
 }
 
 /* C(rowsA x rowsB) (+)= A * B^T,  A(rowsA x colsA), B(rowsB x colsA)
@@ -173,6 +220,7 @@ static void mm_nt(real_t *c, const real_t *a, int rowsA, int colsA,
 {
     (void)colsB;
     int total = rowsA * rowsB;
+    MM_OPERANDS((size_t)rowsA * colsA, (size_t)rowsB * colsA)
     ORC_PAR((long)total * colsA)
     for (int idx = 0; idx < total; ++idx) {
         const real_t *offRowA = a + (idx % rowsA);
@@ -185,6 +233,7 @@ static void mm_nt(real_t *c, const real_t *a, int rowsA, int colsA,
         }
         c[idx] = add ? c[idx] + x : x;
     }
+    MM_RELEASE();
 }
 
 /* exported for direct unit tests of the three product kinds */
@@ -224,6 +273,7 @@ typedef struct {
     const char *patTypes;
     const real_t *w;          /* flat weights, LstmLayer.hpp:36-55 */
     real_t *dir[2][B_COUNT];  /* per-direction internals */
+    real_t *dq[2][4];         /* operand rounding mode: bf16 copies of the four delta vectors (NULL otherwise) */
 } lstm_t;
 
 static void lstm_bind(lstm_t *l, int P, int L, int bidir, real_t bias, int PS, int maxT,
@@ -232,6 +282,7 @@ static void lstm_bind(lstm_t *l, int P, int L, int bidir, real_t bias, int PS, i
     l->P = P; l->L = L; l->dirs = bidir ? 2 : 1; l->H = L / l->dirs;
     l->PS = PS; l->T = T; l->Tmin = Tmin; l->bias = bias;
     l->patTypes = patTypes; l->w = w;
+    memset(l->dq, 0, sizeof l->dq);
     size_t per = (size_t)PS * maxT * l->H;     /* LstmLayer.cu:554 */
     for (int d = 0; d < l->dirs; ++d)
         for (int b = 0; b < B_COUNT; ++b)
@@ -303,6 +354,9 @@ static real_t block_output(const lstm_t *l, int d, int prevOutputDistance,
     return tanh_fn(cellState) * ogAct;
 }
 
+/* the value of a block output as the layer keeps it: fp32, or bf16 in the operand rounding mode */
+#define STORE_Y(v) (g_opround ? bf16_rne(v) : (v))
+
 /*
  * LstmLayer<Cpu>::computeForwardPass, LstmLayer.cu:763-886.
  *   x    : preceding layer outputs [N][P]
@@ -331,7 +385,7 @@ void orc_lstm_forward(int P, int L, int bidir, real_t bias, int PS, int maxT, in
                       l.dir[0][B_TMPOUT] + (size_t)(t - 1) * n, H, PS, 1);
         for (int i = 0; i < n; ++i)            /* :822-828 */
             l.dir[0][B_TMPOUT][(size_t)n * t + i] =
-                block_output(&l, 0, -n, n * t + i, t == 0, t >= Tmin);
+                STORE_Y(block_output(&l, 0, -n, n * t + i, t == 0, t >= Tmin));
     }
 
     /* :832-865 backward states */
@@ -343,7 +397,7 @@ void orc_lstm_forward(int P, int L, int bidir, real_t bias, int PS, int maxT, in
                           l.dir[1][B_TMPOUT] + (size_t)(t + 1) * n, H, PS, 1);
             for (int i = 0; i < n; ++i)        /* :857-863 */
                 l.dir[1][B_TMPOUT][(size_t)n * t + i] =
-                    block_output(&l, 1, +n, n * t + i, t == T - 1, t >= Tmin);
+                    STORE_Y(block_output(&l, 1, +n, n * t + i, t == T - 1, t >= Tmin));
         }
     }
 
@@ -510,6 +564,10 @@ static real_t weight_update(const lstm_t *l, const real_t *plOutputs, int weight
 
     static const int deltaBuf[4] = { B_NIDELTA, B_IGDELTA, B_FGDELTA, B_OGDELTA };
     const real_t *offDeltas = &l->dir[isBwStateWeight ? 1 : 0][deltaBuf[weightTypeY]][tgtBlockIdx];
+    /* operand rounding mode: the input / internal cases are matrix products (rounded operands: plOutputs arrives rounded,
+     * tmpOutputs are stored rounded); the bias / peephole sums read the unrounded deltas */
+    if (l->dq[0][0] && (weightTypeX == 0x0 || weightTypeX == 0x8))
+        offDeltas = &l->dq[isBwStateWeight ? 1 : 0][weightTypeY][tgtBlockIdx];
 
     if (skipFirstPattern) {
         offOutputs += parallelSequences * offOutputsInc;
@@ -591,9 +649,20 @@ void orc_lstm_backward(int P, int L, int bidir, real_t bias, int PS, int maxT, i
 
     /* :1012-1044 weight updates */
     int nw = orc_lstm_weight_count(P, L, bidir);
+    real_t *xq = NULL;
+    if (g_opround) {
+        xq = rounded_copy(x, (size_t)N * P); x = xq;
+        for (int d = 0; d < l.dirs; ++d)
+            for (int g = 0; g < 4; ++g) l.dq[d][g] = rounded_copy(l.dir[d][deltaBuf[g]], (size_t)N * H);
+    }
     ORC_PAR((long)nw * N)
     for (int i = 0; i < nw; ++i)
         wu[i] = weight_update(&l, x, i);
+    if (g_opround) {
+        free(xq);
+        for (int d = 0; d < l.dirs; ++d)
+            for (int g = 0; g < 4; ++g) free(l.dq[d][g]);
+    }
 }
 
 /* ------------------------------------------------------------------------- */

@@ -69,6 +69,8 @@ def lib():
     L.orc_binary_correct.restype = ci
     L.orc_post_backward.argtypes = [ci, ci, ci, i8p, f32p, f32p, f32p]
     L.orc_set_threads.argtypes = [ci]
+    L.orc_set_operand_rounding.argtypes = [ci]
+    L.orc_get_operand_rounding.restype = ci
     L.orc_get_threads.restype = ci
     L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", "1")))
     _lib = L
@@ -84,6 +86,38 @@ def set_threads(n):
 
 def get_threads():
     return int(lib().orc_get_threads())
+
+
+def set_operand_rounding(mode):
+    """None / "f32": the reference's fp32 arithmetic (default).  "bf16": a MODEL of CN_PREC_BF16 -- every matrix product
+    rounds both operands to bf16 (x, y[t-1], W_in / W_rec, the four deltas, the output layer's deltas) and LSTM layers store
+    their outputs rounded; accumulation, states, activations (libm), bias / peephole terms and their gradient sums stay
+    fp32 in the reference's order (currennt_oracle.c, "operand rounding").  The HIP bf16 path is then held to the oracle at
+    summation-order + v_exp_f32 / v_rcp_f32 distance instead of 3e-2.  Only the C restatement has the mode
+    (OracleNetwork(backend="oracle")); oracle/_ref is the reference's object code and has no such switch."""
+    if mode not in (None, "f32", "bf16"):
+        raise ValueError("operand rounding mode must be None, 'f32' or 'bf16'")
+    lib().orc_set_operand_rounding(1 if mode == "bf16" else 0)
+
+
+def get_operand_rounding():
+    return "bf16" if lib().orc_get_operand_rounding() else None
+
+
+class operand_rounding:
+    """with oracle.operand_rounding("bf16"): ...  (restores the previous mode)"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_operand_rounding()
+        set_operand_rounding(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_operand_rounding(self.prev)
+        return False
 
 
 _REF_PATH = os.path.join(_HERE, "_ref", "libcurrennt_ref.so")

@@ -1,0 +1,155 @@
+"""-m gpu: the BENCHMARKED arithmetic (CN_PREC_BF16) pinned tightly.
+
+The fp32 oracle is 3e-2 away from the bf16 mode by design (operand precision).  With `oracle.set_operand_rounding("bf16")`
+the oracle rounds exactly the values the HIP path rounds -- both operands of every matrix product: x, y[t-1], W_in / W_rec, the
+four stored deltas, the output layer's deltas (LstmLayer.cu:774-785,815-818,850-853,939-942,973-976,996-1006 and the product
+cases of ComputeWeightUpdateFn :370-437; FeedForwardLayer.cu:148-152,190-197,202-206 through Matrix.cu:41-183) -- and keeps fp32
+accumulation, fp32 state, libm activations and unrounded bias / peephole sums.  What is left between the two is summation order,
+v_exp_f32 / v_rcp_f32, and the rare bf16 value that lands on the other side of a rounding boundary because of those: the
+tolerances below are therefore 2e-4 on posteriors and 2e-3 of the layer's maximum on gradients and propagated errors (the 3e-2
+tests in test_gpu_parity.py / test_gpu_configs.py stay as the DISTANCE TO THE FP32 ORACLE, not as the pin of the kernels).
+
+Shapes: the kernels the bench lines run -- the hand-written s2 loops at PS = 50 for T = 5, 67, 300 (loop body multiples and
+tails of the 2-/4-step bodies), reading B at PS = 16 (one-CU-per-pair forward loop + 2-CU backward clusters), one blstm1024
+layer (8-CU clusters), the C = 8000 softmax kernels."""
+import numpy as np
+import pytest
+
+from helpers import net_desc, random_sequences, random_weights, real_mask
+from test_gpu_parity import rel_err
+
+pytestmark = pytest.mark.gpu
+
+POSTERIOR_TOL_BF16_PINNED = 2e-4
+GRAD_TOL_BF16_PINNED = 2e-3
+
+
+def check_pinned(pkg, orc, layers, weights, frac, PS, kernels=None, post_tol=POSTERIOR_TOL_BF16_PINNED, grad_tol=GRAD_TOL_BF16_PINNED,
+                 internals=False):
+    """HIP bf16 mode against the operand-rounding oracle: posteriors, error, #correct, every gradient, every propagated error
+    vector, LSTM layer outputs (bf16 values on both sides)."""
+    threads = orc.get_threads()
+    orc.set_threads(max(threads, 8))
+    try:
+        with orc.operand_rounding("bf16"):
+            ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+            ref.load_sequences(frac); ref.compute_forward_pass()
+            e_ref = ref.calculate_error(); c_ref = ref.count_correct_classifications()
+            ref.compute_backward_pass()
+    finally:
+        orc.set_threads(threads)
+    report = {}
+    with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+        net.load_sequences(frac); net.compute_forward_pass()
+        e, c = net.error_and_correct()
+        net.compute_backward_pass()
+        if kernels:
+            assert net.recurrent_kernel(False) == kernels[0], net.recurrent_kernel(False)
+            assert net.recurrent_kernel(True) == kernels[1], net.recurrent_kernel(True)
+        real = real_mask(frac)
+        C = layers[-1]["size"]
+        y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
+        report["posterior"] = float(np.abs(y - yr).max())
+        assert report["posterior"] < post_tol, report
+        assert abs(e - e_ref) <= 2e-4 * max(1.0, abs(e_ref)), (e, e_ref)
+        assert abs(c - c_ref) <= max(1, int(2e-3 * real.sum())), (c, c_ref)     # (an argmax may flip between near-equal posteriors)
+        for lay in net.trainable_layers():
+            rl = ref.layer(lay.name)
+            report["grad/" + lay.name] = rel_err(lay.weight_updates(), rl.weightUpdates)
+            assert report["grad/" + lay.name] < grad_tol, report
+            if lay.prev.trainable:
+                pe = lay.prev.output_errors().reshape(-1, lay.prev.size)[real]
+                per = rl.prev.outputErrors[:net.N * lay.prev.size].reshape(-1, lay.prev.size)[real]
+                report["err/" + lay.prev.name] = rel_err(pe, per)
+                assert report["err/" + lay.prev.name] < grad_tol, report
+            if lay.type in ("lstm", "blstm"):
+                # layer outputs: bf16 values on both sides; a value may sit one bf16 step (2^-8 relative) away where the
+                # fp32 value in front of the rounding differed in its last bits -- rare, bounded, counted
+                a = lay.outputs().reshape(-1, lay.size)[real]
+                b = rl.outputs[:net.N * lay.size].reshape(-1, lay.size)[real]
+                d = np.abs(a - b)
+                assert d.max() <= 2.0 ** -7 * max(1e-3, np.abs(b).max()), (lay.name, d.max())
+                report["y_off/" + lay.name] = float((d > 0).mean())
+                assert report["y_off/" + lay.name] < 2e-2, report
+                if internals:
+                    for dd in range(lay.dirs):
+                        for name in ("cellStates", "niActs", "igActs", "fgActs", "ogActs"):
+                            u = lay.internal(name, dd).reshape(-1, lay.H)[real]
+                            v = rl.internal(name, dd)[:net.N * lay.H].reshape(-1, lay.H)[real]
+                            assert np.abs(u - v).max() < 2e-3 * max(1.0, np.abs(v).max()), (name, dd, np.abs(u - v).max())
+    return report
+
+
+def headline_case(pkg, T, PS=50, seed=70):
+    rng = np.random.RandomState(seed + T)
+    P, C = 39, 183
+    layers = net_desc(P, [("blstm", 250)] * 3, C)
+    weights = random_weights(layers, rng, 0.1)
+    lo = max(1, int(0.8 * T))
+    lengths = sorted([T] + rng.randint(lo, T + 1, PS - 3).tolist(), reverse=True)        # ragged, two unused slots
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    return layers, weights, pkg.make_fraction(xs, ts, PS), PS
+
+
+@pytest.mark.parametrize("T", [5, 67, 300])
+def test_headline_net_hand_written_loops(pkg, orc, T):
+    """39 -> 3 x blstm250 -> softmax183 at PS = 50 (the bench line's kernels: lstm_{fwd,bwd}_s2_asm_kernel, K = 64 / 256 input
+    projections, K = 1024 error products, grouped gradient GEMMs), T = 5 (shorter than the prefetch distance), 67 (odd: tails of
+    the 2- and 4-step loop bodies), 300 (the benchmarked length)."""
+    layers, weights, frac, PS = headline_case(pkg, T)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel"))
+    print("bf16 pinned, T = %d:" % T, {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+def test_single_layer_internals_hand_written_loops(pkg, orc):
+    """One blstm250 layer at PS = 50, T = 40: gate activations and cell states of the hand-written forward loop against the
+    rounding oracle (2e-3: a flipped bf16 y[t-1] moves a pre-activation by ~1e-4)."""
+    rng = np.random.RandomState(71)
+    P, C, PS = 39, 183, 50
+    layers = net_desc(P, [("blstm", 250)], C)
+    weights = random_weights(layers, rng, 0.1)
+    xs, ts = random_sequences(rng, sorted(rng.randint(25, 41, PS).tolist(), reverse=True), P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel"), internals=True)
+
+
+def test_reading_b_one_cu_forward_loop_and_two_cu_backward_clusters(pkg, orc):
+    """39 -> 3 x blstm500 -> softmax183 (250 units per direction, Hp = 256) at PS = 16, T = 96: lstm_fwd_s2w_asm_kernel (generated
+    step body) and the 2-CU backward cluster kernel."""
+    rng = np.random.RandomState(72)
+    P, C, PS = 39, 183, 16
+    layers = net_desc(P, [("blstm", 500)] * 3, C)
+    weights = random_weights(layers, rng, 0.06)
+    lengths = [96, 95, 93, 90, 90, 84, 80, 71, 66, 60, 52, 41, 30, 12, 3]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2w_asm_kernel", "lstm_bwd_cluster_kernel<0,256,128,1>"))
+    print("bf16 pinned, reading B:", {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+def test_one_blstm1024_layer_eight_cu_clusters(pkg, orc):
+    """39 -> blstm1024 -> softmax183 (512 units per direction) at PS = 16, T = 64: the 8-CU cluster kernels of the long-utterance
+    config."""
+    rng = np.random.RandomState(73)
+    P, C, PS = 39, 183, 16
+    layers = net_desc(P, [("blstm", 1024)], C)
+    weights = random_weights(layers, rng, 0.04)
+    lengths = [64, 64, 63, 60, 58, 55, 51, 50, 44, 40, 33, 30, 21, 12, 7, 2]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_cluster_kernel<0,512,64,1>", "lstm_bwd_cluster_kernel<0,512,64,1>"))
+    print("bf16 pinned, blstm1024:", {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+def test_softmax_8000_classes(pkg, orc):
+    """40 -> 2 x blstm512 -> softmax 8000 at PS = 16, T = 48: the block-per-pattern softmax kernels, bf16 deltas of the output layer
+    into K13 / K14 (FeedForwardLayer.cu:190-206)."""
+    rng = np.random.RandomState(74)
+    P, C, PS = 40, 8000, 16
+    layers = net_desc(P, [("blstm", 512)] * 2, C)
+    weights = random_weights(layers, rng, 0.05)
+    lengths = [48, 48, 45, 44, 40, 37, 33, 30, 28, 25, 20, 16, 12, 9, 5, 2]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS)
+    print("bf16 pinned, softmax 8000:", {k: float("%.3g" % v) for k, v in rep.items()})
