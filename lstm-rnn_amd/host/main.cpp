@@ -216,8 +216,13 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
                 for (size_t i = 0; i < frac.targetClasses().size(); ++i) if (frac.targetClasses()[i] >= 0) st += frac.targetClasses()[i];
                 for (size_t i = 0; i < frac.outputs().size(); ++i) sx += 1000.0 * frac.outputs()[i];
                 for (size_t i = 0; i < frac.patTypes().size(); ++i) none += frac.patTypes()[i] == PATTYPE_NONE;
-                printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s\n", idx++, frac.maxSeqLength(),
-                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.numSequences() ? frac.seqInfo(0).seqTag.c_str() : "-");
+                // tags = the sequences of the fraction, slot by slot (the length sort is std::sort like the reference's,
+                // DataSet.cpp:603-605: ties land in an implementation-defined order, which a checker has to be told)
+                std::string order;
+                for (int i = 0; i < frac.numSequences(); ++i) order += (i ? "," : "") + frac.seqInfo(i).seqTag;
+                printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s tags=%s\n", idx++, frac.maxSeqLength(),
+                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.numSequences() ? frac.seqInfo(0).seqTag.c_str() : "-",
+                       frac.numSequences() ? order.c_str() : "-");
             }
             return 0;
         }
