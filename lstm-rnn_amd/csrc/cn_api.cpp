@@ -103,7 +103,9 @@ struct cn_ctx {
 
     // data-parallel training: RCCL communicator of this rank, its stream and the newest reduction's event
     ncclComm_t comm = nullptr;
+    IpcComm *ipc = nullptr;                    // CN_COMM_BACKEND=ipc: the test backend (cn_comm_ipc.cpp) in place of RCCL
     int comm_rank = 0, comm_world = 0;
+    bool has_comm() const { return comm != nullptr || ipc != nullptr; }
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_comm = nullptr, ev_comm_fork = nullptr;
     bool comm_pending = false;
@@ -319,7 +321,7 @@ void rccl_check(ncclResult_t e, const char *what)
 #define RCCL_CHECK(x) rccl_check((x), #x)
 void require_comm(cn_ctx *c, const char *who)
 {
-    if (!c->comm) throw cn_error(CN_ERR_STATE, std::string(who) + ": no communicator bound to this context (call cn_comm_init first)");
+    if (!c->has_comm()) throw cn_error(CN_ERR_STATE, std::string(who) + ": no communicator bound to this context (call cn_comm_init first)");
 }
 // run `f(stream)` on the side stream after everything enqueued on the main stream so far
 // (fork_attached: ev_fork already completes with the last main-stream kernel, see fork_event)
@@ -488,7 +490,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     // (CN_COMM_CU_MARGIN, default 32 -- RCCL's MI300-class defaults stay at or below that many workgroups per collective);
     // a grid that no longer fits takes the streaming kernels, which make no residency assumption.  The one-CU kernels (s2, s2w,
     // 4-sequence) make none either and keep the full count, so that a data-parallel run picks the kernels of a one-GPU run.
-    if (c->comm) {
+    if (c->has_comm()) {
         static const int margin = getenv("CN_COMM_CU_MARGIN") ? atoi(getenv("CN_COMM_CU_MARGIN")) : 32;
         r.cluster_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
     }
@@ -758,6 +760,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         if (ctx->copy) { hipStreamSynchronize(ctx->copy); hipStreamDestroy(ctx->copy); }
         if (ctx->comm_stream) hipStreamSynchronize(ctx->comm_stream);
         if (ctx->comm) { (void)rccl().CommDestroy(ctx->comm); ctx->comm = nullptr; }
+        if (ctx->ipc) { ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr; }
         if (ctx->comm_stream) { hipStreamDestroy(ctx->comm_stream); hipEventDestroy(ctx->ev_comm); hipEventDestroy(ctx->ev_comm_fork); }
         for (int i = 0; i < 2; ++i) {
             if (ctx->h_stage[i]) hipHostFree(ctx->h_stage[i]);
@@ -831,6 +834,7 @@ int cn_comm_unique_id(char *id)
     if (!id) { g_last_error = "cn_comm_unique_id: id is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         static_assert(sizeof(ncclUniqueId) == CN_COMM_ID_BYTES, "CN_COMM_ID_BYTES must match ncclUniqueId");
+        if (ipc_backend_selected()) { ipc_unique_id(id, CN_COMM_ID_BYTES); return; }
         ncclUniqueId u;
         RCCL_CHECK(rccl().GetUniqueId(&u));
         memcpy(id, &u, sizeof(u));
@@ -842,11 +846,16 @@ int cn_comm_init(cn_ctx *ctx, const char *id, int rank, int world)
     if (!ctx || !id) { g_last_error = "cn_comm_init: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         if (world < 1 || rank < 0 || rank >= world) throw cn_error(CN_ERR_BAD_ARG, "cn_comm_init: rank " + std::to_string(rank) + " outside world of " + std::to_string(world));
-        if (ctx->comm) throw cn_error(CN_ERR_STATE, "cn_comm_init: this context already has a communicator");
+        if (ctx->has_comm()) throw cn_error(CN_ERR_STATE, "cn_comm_init: this context already has a communicator");
         HIP_CHECK(hipSetDevice(ctx->device));
-        ncclUniqueId u;
-        memcpy(&u, id, sizeof(u));
-        RCCL_CHECK(rccl().CommInitRank(&ctx->comm, world, u, rank));
+        if (ipc_backend_selected()) {
+            try { ctx->ipc = ipc_comm_create(id, rank, world); }
+            catch (const std::exception &e) { throw cn_error(CN_ERR_COMM, e.what()); }
+        } else {
+            ncclUniqueId u;
+            memcpy(&u, id, sizeof(u));
+            RCCL_CHECK(rccl().CommInitRank(&ctx->comm, world, u, rank));
+        }
         ctx->comm_rank = rank; ctx->comm_world = world;
         if (!ctx->comm_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
@@ -860,11 +869,12 @@ int cn_comm_destroy(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_comm_destroy: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        if (!ctx->comm) return;
+        if (!ctx->has_comm()) return;
         HIP_CHECK(hipSetDevice(ctx->device));
         HIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        RCCL_CHECK(rccl().CommDestroy(ctx->comm));
+        if (ctx->ipc) { ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr; }
+        else RCCL_CHECK(rccl().CommDestroy(ctx->comm));
         ctx->comm = nullptr; ctx->comm_world = 0; ctx->comm_rank = 0; ctx->comm_pending = false;
     });
 }
@@ -875,6 +885,13 @@ int cn_comm_info(const cn_ctx *ctx, int *rank, int *world)
     if (rank) *rank = ctx->comm_rank;
     if (world) *world = ctx->comm_world;
     return CN_OK;
+}
+
+// the test backend's exchange (host-blocking); a failure marks the segment so that the peers leave their barriers at once
+static void ipc_reduce(cn_ctx *ctx, float *buf, size_t n)
+{
+    try { ipc_allreduce(ctx->ipc, buf, n, ctx->comm_stream); }
+    catch (const std::exception &e) { ipc_comm_mark_failed(ctx->ipc); throw cn_error(CN_ERR_COMM, e.what()); }
 }
 
 int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
@@ -900,6 +917,7 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
             float *g = ctx->arena + ctx->total;
             Timed tm(ctx, KC_COMM, ctx->comm_stream);
             if (test_double) launch_scale(ctx->comm_stream, g, ctx->total, 2.0f);
+            else if (ctx->ipc) ipc_reduce(ctx, g, ctx->total);
             else if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
         } else {
             for (int i = 0; i < n; ++i) {
@@ -908,6 +926,7 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
                 stream_wait_layer(l, ctx->comm_stream);
                 Timed tm(ctx, KC_COMM, ctx->comm_stream);          // (events on the communication stream: the exchange itself, not its wait)
                 if (test_double) launch_scale(ctx->comm_stream, l->wu, (size_t)l->nw, 2.0f);
+                else if (ctx->ipc) ipc_reduce(ctx, l->wu, (size_t)l->nw);
                 else RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
             }
         }
@@ -1351,6 +1370,18 @@ int cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int
         require_comm(ctx, "cn_loss_read_global");
         HIP_CHECK(hipSetDevice(ctx->device));
         float *g = ctx->d_loss + 4, h[2];
+        if (ctx->ipc) {
+            HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+            if (reset) HIP_CHECK(hipMemsetAsync(ctx->d_loss_acc, 0, sizeof(h), ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            check_fault(ctx);
+            int cc; memcpy(&cc, &h[1], sizeof(int));
+            try { ipc_allreduce_loss(ctx->ipc, &h[0], &cc); }
+            catch (const std::exception &e) { ipc_comm_mark_failed(ctx->ipc); throw cn_error(CN_ERR_COMM, e.what()); }
+            if (error_sum) *error_sum = h[0];
+            if (correct_sum) *correct_sum = cc;
+            return;
+        }
         RCCL_CHECK(rccl().GroupStart());
         RCCL_CHECK(rccl().AllReduce(ctx->d_loss_acc, g, 1, ncclFloat32, ncclSum, ctx->comm, ctx->stream));
         RCCL_CHECK(rccl().AllReduce(ctx->d_loss_acc + 1, g + 1, 1, ncclInt32, ncclSum, ctx->comm, ctx->stream));

@@ -1,0 +1,205 @@
+// CN_COMM_BACKEND=ipc -- a TEST backend of the gradient exchange for boxes with fewer GPUs than ranks.
+//
+// RCCL refuses two ranks on one device, so on a one-GPU box the world > 1 flow of the C++ driver (fork, rendezvous, shard of
+// every fraction per rank, per-layer exchange behind the backward pass, global loss, rank-0 file writing) could never
+// run.  With CN_COMM_BACKEND=ipc in the environment cn_comm_unique_id / cn_comm_init / cn_allreduce_grads /
+// cn_loss_read_global keep their contract but exchange through the host: the ranks (processes that may share a device) meet in a
+// POSIX shared-memory segment named by the id, publish hipIpc handles of a staging buffer each, and an all-reduce is
+//   copy my gradient into my staging buffer -> barrier -> sum the staging buffers of ALL ranks in rank order into my gradient
+//   (peers' buffers through hipIpcOpenMemHandle) -> barrier.
+// Every rank adds the same numbers in the same order: the replicas stay bit-identical, as with RCCL's ring.  The call blocks the
+// host (two barriers per exchange) -- it is a functional double, never a measurement, and bench.py refuses it for `value`.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "cn_internal.h"
+
+namespace cn {
+
+namespace {
+
+constexpr int IPC_MAX_RANKS = 8;
+constexpr unsigned IPC_MAGIC = 0x434e4950u;      // "CNIP"
+
+struct Slot {
+    hipIpcMemHandle_t handle;                    // staging buffer of this rank
+    std::atomic<unsigned long long> generation;  // bumped when the buffer was reallocated (peers reopen the handle)
+    std::atomic<unsigned long long> capacity;    // floats
+    float err; int correct;                      // cn_loss_read_global
+};
+struct Shared {
+    std::atomic<unsigned> magic;
+    std::atomic<unsigned> arrived;               // sense-reversing barrier
+    std::atomic<unsigned> sense;
+    std::atomic<unsigned> failed;                // a rank gave up: everybody leaves
+    Slot slot[IPC_MAX_RANKS];
+};
+
+double now_s()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+void hipck(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string("ipc communicator: ") + what + ": " + hipGetErrorString(e));
+}
+
+}  // namespace
+
+struct IpcComm {
+    Shared *sh = nullptr;
+    std::string name;
+    int rank = 0, world = 1;
+    unsigned my_sense = 0;
+    float *staging = nullptr; size_t capacity = 0;
+    float *peer[IPC_MAX_RANKS] = {};
+    unsigned long long peer_gen[IPC_MAX_RANKS] = {};
+    double timeout_s = 120.0;
+
+    void barrier(const char *what)
+    {
+        my_sense ^= 1u;
+        if (sh->arrived.fetch_add(1) + 1 == (unsigned)world) {
+            sh->arrived.store(0);
+            sh->sense.store(my_sense);
+            return;
+        }
+        const double t0 = now_s();
+        while (sh->sense.load() != my_sense) {
+            if (sh->failed.load()) throw std::runtime_error(std::string("ipc communicator: another rank failed (rank ") + std::to_string(rank) + " was in " + what + ")");
+            if (now_s() - t0 > timeout_s) {
+                sh->failed.store(1);
+                throw std::runtime_error("ipc communicator: rank " + std::to_string(rank) + " of " + std::to_string(world) + " waited " +
+                                         std::to_string((int)timeout_s) + " s for its peers in " + what);
+            }
+            usleep(20);
+        }
+    }
+};
+
+bool ipc_backend_selected()
+{
+    const char *b = getenv("CN_COMM_BACKEND");
+    return b && !strcmp(b, "ipc");
+}
+
+// rank 0: create the segment; its name is the id
+void ipc_unique_id(char *id, size_t bytes)
+{
+    static std::atomic<unsigned> serial{0};
+    memset(id, 0, bytes);
+    snprintf(id, bytes, "/cn_ipc_%d_%u_%lx", (int)getpid(), serial.fetch_add(1), (unsigned long)(now_s() * 1e6));
+    int fd = shm_open(id, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) throw std::runtime_error(std::string("ipc communicator: shm_open(") + id + ") failed");
+    if (ftruncate(fd, sizeof(Shared)) != 0) { close(fd); shm_unlink(id); throw std::runtime_error("ipc communicator: ftruncate failed"); }
+    void *p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { shm_unlink(id); throw std::runtime_error("ipc communicator: mmap failed"); }
+    memset(p, 0, sizeof(Shared));
+    ((Shared *)p)->magic.store(IPC_MAGIC);
+    munmap(p, sizeof(Shared));
+}
+
+IpcComm *ipc_comm_create(const char *id, int rank, int world)
+{
+    if (world > IPC_MAX_RANKS) throw std::runtime_error("ipc communicator: at most " + std::to_string(IPC_MAX_RANKS) + " ranks");
+    if (id[0] != '/' || strncmp(id, "/cn_ipc_", 8)) throw std::runtime_error("ipc communicator: the id does not come from cn_comm_unique_id with CN_COMM_BACKEND=ipc");
+    IpcComm *c = new IpcComm;
+    c->name = id; c->rank = rank; c->world = world;
+    if (const char *t = getenv("CN_COMM_IPC_TIMEOUT")) c->timeout_s = atof(t);
+    int fd = shm_open(id, O_RDWR, 0600);
+    if (fd < 0) { delete c; throw std::runtime_error(std::string("ipc communicator: rank ") + std::to_string(rank) + " cannot open " + id); }
+    void *p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete c; throw std::runtime_error("ipc communicator: mmap failed"); }
+    c->sh = (Shared *)p;
+    if (c->sh->magic.load() != IPC_MAGIC) { munmap(p, sizeof(Shared)); delete c; throw std::runtime_error("ipc communicator: segment not initialised"); }
+    try {
+        c->barrier("cn_comm_init");
+    } catch (...) {
+        if (rank == 0) shm_unlink(id);
+        munmap(p, sizeof(Shared)); delete c;
+        throw;
+    }
+    if (rank == 0) shm_unlink(id);           // every rank holds a mapping now: nothing stays behind in /dev/shm
+    return c;
+}
+
+void ipc_comm_destroy(IpcComm *c)
+{
+    if (!c) return;
+    for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
+    if (c->staging) (void)hipFree(c->staging);
+    if (c->sh) munmap(c->sh, sizeof(Shared));
+    delete c;
+}
+
+void ipc_comm_mark_failed(IpcComm *c) { if (c && c->sh) c->sh->failed.store(1); }
+
+// all-reduce(SUM, fp32, in place) of buf[0..n) over the ranks; blocks the host; `st` is the stream the caller ordered behind
+// the producer of buf
+void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st)
+{
+    if (n == 0) { c->barrier("cn_allreduce_grads"); c->barrier("cn_allreduce_grads"); return; }
+    Slot &mine = c->sh->slot[c->rank];
+    if (n > c->capacity) {
+        if (c->staging) hipck(hipFree(c->staging), "hipFree");
+        const size_t cap = n + n / 2 + 1024;
+        hipck(hipMalloc((void **)&c->staging, cap * sizeof(float)), "hipMalloc(staging)");
+        c->capacity = cap;
+        hipck(hipIpcGetMemHandle(&mine.handle, c->staging), "hipIpcGetMemHandle");
+        mine.capacity.store(cap);
+        mine.generation.fetch_add(1);
+    }
+    hipck(hipMemcpyAsync(c->staging, buf, n * sizeof(float), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+    hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    c->barrier("cn_allreduce_grads (gradients staged)");
+    SumRanks sr{};
+    sr.n = c->world;
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) { sr.src[r] = c->staging; continue; }
+        Slot &s = c->sh->slot[r];
+        const unsigned long long gen = s.generation.load();
+        if (gen != c->peer_gen[r]) {
+            if (c->peer[r]) hipck(hipIpcCloseMemHandle(c->peer[r]), "hipIpcCloseMemHandle");
+            c->peer[r] = nullptr;
+            hipIpcMemHandle_t h = s.handle;
+            hipck(hipIpcOpenMemHandle((void **)&c->peer[r], h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+            c->peer_gen[r] = gen;
+        }
+        if (s.capacity.load() < n) throw std::runtime_error("ipc communicator: ranks disagree about the size of an exchange");
+        sr.src[r] = c->peer[r];
+    }
+    launch_sum_ranks(st, buf, sr, n);
+    hipck(hipGetLastError(), "sum kernel");
+    hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    c->barrier("cn_allreduce_grads (sums formed)");      // nobody overwrites a staging buffer a peer still reads
+}
+
+// sums of (error, #correct) over the ranks, in rank order on every rank
+void ipc_allreduce_loss(IpcComm *c, float *err, int *correct)
+{
+    c->sh->slot[c->rank].err = *err;
+    c->sh->slot[c->rank].correct = *correct;
+    c->barrier("cn_loss_read_global");
+    float e = 0.f; int k = 0;
+    for (int r = 0; r < c->world; ++r) { e += c->sh->slot[r].err; k += c->sh->slot[r].correct; }
+    c->barrier("cn_loss_read_global");
+    *err = e; *correct = k;
+}
+
+}  // namespace cn

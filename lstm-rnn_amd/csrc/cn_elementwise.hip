@@ -927,6 +927,19 @@ void launch_scale(hipStream_t s, float *x, size_t n, float a)
 {
     if (n) hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024)), dim3(256), 0, s, x, n, a);
 }
+// dst = src[0] + src[1] + ... (rank order: every rank forms the same sum) -- the test backend of the gradient exchange
+__global__ void sum_ranks_kernel(float *dst, SumRanks sr, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = sr.src[0][i];
+        for (int r = 1; r < sr.n; ++r) v += sr.src[r][i];
+        dst[i] = v;
+    }
+}
+void launch_sum_ranks(hipStream_t s, float *dst, const SumRanks &sr, size_t n)
+{
+    if (n) hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024)), dim3(256), 0, s, dst, sr, n);
+}
 
 __global__ void sgd_kernel(float *w, const float *wu, float *wd, size_t n, float lr, float mom)
 {

@@ -173,6 +173,19 @@ void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, 
 // sse
 // UpdateWeightFn over a flat range
 void launch_scale(hipStream_t s, float *x, size_t n, float a);     // x *= a
+// dst[i] = src[0][i] + src[1][i] + ... in that order (cn_comm_ipc.cpp: the test backend of the gradient exchange)
+struct SumRanks { const float *src[8]; int n; };
+void launch_sum_ranks(hipStream_t s, float *dst, const SumRanks &sr, size_t n);
+
+// ---- CN_COMM_BACKEND=ipc: test backend of cn_comm_* for ranks that share a device (cn_comm_ipc.cpp) ----------------
+struct IpcComm;
+bool ipc_backend_selected();
+void ipc_unique_id(char *id, size_t bytes);
+IpcComm *ipc_comm_create(const char *id, int rank, int world);
+void ipc_comm_destroy(IpcComm *c);
+void ipc_comm_mark_failed(IpcComm *c);
+void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st);
+void ipc_allreduce_loss(IpcComm *c, float *err, int *correct);
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
 // (host row n = t*PS + s maps to device row t*PSp + s)

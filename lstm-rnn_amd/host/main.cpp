@@ -236,7 +236,10 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
         NeuralNetwork::WeightsInit wi = { config.weightsDistributionIsNormal(), config.weightsDistributionUniformMin(),
                                           config.weightsDistributionUniformMax(), config.weightsDistributionNormalSigma(),
                                           config.weightsDistributionNormalMean(), config.randomSeed() };
-        NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device() + dp.rank, &wi);
+        // one rank per GPU: device --device + rank.  CN_DP_SAME_DEVICE=1 (tests on a one-GPU box, together with the library's
+        // CN_COMM_BACKEND=ipc): every rank on --device
+        const bool sameDevice = dp.active && getenv("CN_DP_SAME_DEVICE") != 0;
+        NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device() + (sameDevice ? 0 : dp.rank), &wi);
         if (dp.active) {
             // rendezvous: rank 0 draws the id and hands it to the other ranks through their pipes, then every rank joins
             char id[CN_COMM_ID_BYTES];
@@ -253,6 +256,9 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
                 }
             }
             neuralNetwork.initDataParallel(id, dp.rank, dp.world);
+            // test hook (tests/test_host_driver.py): this rank gives up after the rendezvous, the others are in their first exchange
+            if (getenv("CN_DP_TEST_FAIL_RANK") && atoi(getenv("CN_DP_TEST_FAIL_RANK")) == dp.rank)
+                throw std::runtime_error("test hook CN_DP_TEST_FAIL_RANK: this rank fails on purpose");
         }
         if (!trainingSet->empty() && trainingSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
             throw std::runtime_error("Post output layer size != target pattern size of the training set");
@@ -361,6 +367,9 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
 // exit code = the first failing rank's (the others are terminated, they would wait in a collective for ever).
 int runDataParallel(const Configuration &config, int world)
 {
+    if (getenv("CN_DP_SAME_DEVICE"))
+        printf("Data-parallel training with %d ranks on device %d (CN_DP_SAME_DEVICE: a test mode), %d parallel sequences per rank.\n", world, config.device(), config.parallelSequences());
+    else
     printf("Data-parallel training on %d GPU%s (devices %d..%d), %d parallel sequences per GPU.\n", world, world == 1 ? "" : "s",
            config.device(), config.device() + world - 1, config.parallelSequences());
     fflush(stdout);

@@ -317,3 +317,65 @@ def test_driver_csv_writer(pkg, orc, tmp_path):
             assert vals.shape == (n, 4) and np.abs(vals - y[:n, i, :]).max() < 1e-4
             k += 1
     assert k == len(xs)
+
+
+def _error_rows(out):
+    """(classification error %, error per sequence) of the training column of every epoch row of the driver's table"""
+    rows = []
+    for l in out.splitlines():
+        if l.strip()[:1].isdigit() and "|" in l:
+            cells = [c.strip() for c in l.split("|")]
+            rows.append(tuple(float(v.rstrip("%")) for v in cells[2].split()))
+    return rows
+
+
+TWO_RANK_ENV = dict(CN_COMM_BACKEND="ipc", CN_DP_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CN_COMM_IPC_TIMEOUT="60")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stochastic", ["true", "false"])
+def test_driver_two_ranks_on_one_gpu(pkg, tmp_path, stochastic):
+    """`currennt_hip --gpus 2` with BOTH ranks alive (the reference has no counterpart, main.cpp:526-541): fork before
+    any GPU call, rendezvous id through the pipe, DataSet::setShard under two live ranks, one gradient exchange per layer behind
+    its backward pass (batch mode: one exchange of the epoch sum), cn_loss_read_global, rank 0 writes the files.  RCCL refuses two
+    ranks on one device, so the library's exchange runs on its test backend (CN_COMM_BACKEND=ipc: hipIpc handles of the peers'
+    gradients + a sum kernel in rank order, cn_comm_ipc.cpp) and both ranks use device 0 (CN_DP_SAME_DEVICE) -- never a measurement.
+    9 sequences, 2 ranks x 2 parallel sequences: global fractions of 4, 4 and 1 sequences, so rank 1's share of the last one is
+    EMPTY (an all-dummy fraction keeps the collectives matched).  The run must end in the network of the single-process run over
+    the union fractions (parallel_sequences 4): sums over patterns in another order, nothing else (Optimizer.cu:37-104)."""
+    lens = (11, 5, 9, 3, 14, 7, 8, 12, 6)
+    layers, weights, xs, ts, nc, net = problem(tmp_path, lens)
+    common = [BIN, "--train", "true", "--stochastic", stochastic, "--train_file", nc, "--val_file", nc, "--network", net,
+              "--max_epochs", "3", "--learning_rate", "1e-2", "--momentum", "0.9"]
+    plain, dp = str(tmp_path / "plain.jsn"), str(tmp_path / "dp.jsn")
+    a = subprocess.run(common + ["--parallel_sequences", "4", "--save_network", plain], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0, a.stdout + a.stderr
+    b = subprocess.run(common + ["--parallel_sequences", "2", "--gpus", "2", "--save_network", dp], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, **TWO_RANK_ENV))
+    assert b.returncode == 0, b.stdout + b.stderr
+    assert "Data-parallel training with 2 ranks on device 0" in b.stdout
+    ra, rb = _error_rows(a.stdout), _error_rows(b.stdout)
+    assert len(ra) == len(rb) == 3
+    for (ca, ea), (cb, eb) in zip(ra, rb):
+        assert abs(ca - cb) < 0.011 and abs(ea - eb) < 2e-3 * max(1.0, abs(ea)), (ra, rb)      # printed with 2 / 3 decimals
+    wa, wb = _weights_of(plain), _weights_of(dp)
+    moved = 0.0
+    for n in wa:
+        assert np.abs(wa[n] - wb[n]).max() < 2e-5, n
+        w0 = np.concatenate([np.asarray(weights[n][k], np.float64).reshape(-1) for k in ("input", "bias", "internal")])
+        moved = max(moved, np.abs(wb[n] - w0).max())
+    assert moved > 1e-3                                                  # (the comparison is not one of two untrained networks)
+
+
+@pytest.mark.gpu
+def test_driver_two_ranks_one_fails(pkg, tmp_path):
+    """A rank that fails says `rank 1: FAILED: ...` on stderr and exits with code 2 (main.cpp:492-495); the launcher ends the
+    others (they would wait in the exchange for ever) and hands that code on."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    out = subprocess.run([BIN, "--train", "true", "--stochastic", "true", "--train_file", nc, "--network", net, "--parallel_sequences", "2",
+                          "--gpus", "2", "--max_epochs", "2", "--save_network", str(tmp_path / "x.jsn")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, CN_DP_TEST_FAIL_RANK="1", **TWO_RANK_ENV))
+    assert out.returncode == 2, (out.returncode, out.stdout, out.stderr)
+    assert "rank 1: FAILED: test hook" in out.stderr and "rank 1 exited with code 2" in out.stderr
+    assert not os.path.exists(str(tmp_path / "x.jsn"))
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("cn_ipc_")]          # the rendezvous segment is gone

@@ -50,7 +50,13 @@ int main()
         {35200, 2048, 512, "the same at T = 550"}, {51200, 512, 2048, "LVCSR error to the preceding layer"}, {51200, 8000, 512, "LVCSR softmax projection"}, {51200, 512, 8000, "LVCSR softmax E_prev"}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // GEMM_BENCH_MDIV=<d>: every M (nt) / K (tn) divided by d -- how the products scale with the number of frames
+    const int mdiv = getenv("GEMM_BENCH_MDIV") ? atoi(getenv("GEMM_BENCH_MDIV")) : 1;
+    const int nshapes = getenv("GEMM_BENCH_FIRST") ? atoi(getenv("GEMM_BENCH_FIRST")) : 1000;
+    int ishape = 0;
     for (auto &c : nt) {
+        if (ishape++ >= nshapes) break;
+        c.M /= mdiv;
         void *A = rnd((size_t)c.M * c.K), *B = rnd((size_t)c.N * c.K);
         float *C, *bias; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMalloc((void **)&bias, c.N * 4)); CK(hipMemset(bias, 0, c.N * 4));
         GemmNT g{}; g.A = A; g.lda = c.K; g.B = B; g.ldb = c.K; g.C = C; g.ldc = c.N; g.bias = bias; g.act = ACT_IDENTITY; g.M = c.M; g.N = c.N; g.K = c.K;
@@ -69,6 +75,7 @@ int main()
     }
     struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"}};
     for (auto &c : tn) {
+        c.K /= mdiv;
         void *A = rnd((size_t)c.K * c.M), *B = rnd((size_t)c.K * c.N);
         float *C; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMemset(C, 0, (size_t)c.M * c.N * 4));
         GemmTN g{}; g.A = A; g.lda = c.M; g.B = B; g.ldb = c.N; g.C = C; g.ldc = c.N; g.M = c.M; g.N = c.N; g.K = c.K;
