@@ -240,7 +240,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # CN_BENCH_BACKEND=gloo: test mode for boxes with fewer GPUs than ranks (ranks share devices; the reductions go
     # through the host).  It exercises the world > 1 control flow and stream ordering with real sums; never a measurement.
+    # CN_BENCH_BACKEND=ipc: the same test situation, but the exchange is the LIBRARY's (cn_comm_init / cn_allreduce_grads /
+    # cn_loss_read_global on its CN_COMM_BACKEND=ipc test backend); torch.distributed (gloo) carries the control plane only.
     backend = os.environ.get("CN_BENCH_BACKEND", "nccl")
+    if backend == "ipc":
+        os.environ["CN_COMM_BACKEND"] = "ipc"
     if backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d needs %d GPUs, this node has %d (one rank per GPU over RCCL; no device sharing)"
                          % (world, world, torch.cuda.device_count()))
@@ -252,7 +256,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=rendezvous_s))
         else:
-            dist.init_process_group(backend, timeout=datetime.timedelta(seconds=rendezvous_s))
+            dist.init_process_group("gloo" if backend == "ipc" else backend, timeout=datetime.timedelta(seconds=rendezvous_s))
 
     def bounded(what, seconds, fn, *a):
         """Run a blocking collective set-up call under a watchdog: a rank whose call does not return in time says which rank and
@@ -283,7 +287,7 @@ def main():
     # The gradient exchange is the library's own RCCL communicator (cn_comm_init / cn_allreduce_grads); torch.distributed
     # carries the control plane only (rendezvous id, barrier, max-over-ranks timing).  CN_BENCH_BACKEND=gloo swaps in the
     # torch path (compute_backward_pass_allreduce) as the test double for boxes with fewer GPUs than ranks.
-    native_comm = use_comm and backend == "nccl"
+    native_comm = use_comm and backend in ("nccl", "ipc")
 
     def barrier():
         if world > 1:
@@ -455,7 +459,8 @@ def main():
     if rank == 0:
         exch = "none"
         if use_comm:
-            exch = ("flat" if flat_exchange else "per-layer, overlapped") + (" (library RCCL communicator)" if native_comm else " (torch.distributed test double)")
+            exch = ("flat" if flat_exchange else "per-layer, overlapped") + ((" (library communicator on its ipc TEST backend: not a measurement)" if backend == "ipc" else
+                                                                              " (library RCCL communicator)") if native_comm else " (torch.distributed test double)")
         out = {
             "metric": "train frames/sec (node), 3x250 BLSTM 39->183" if args.workload.startswith("timit_3x") else "train frames/sec (node), " + args.workload,
             "value": value, "unit": "frames/s",

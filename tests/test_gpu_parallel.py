@@ -156,15 +156,18 @@ def test_per_layer_learning_rate_in_fused_update(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (fused, lay.name)
 
 
+@pytest.mark.parametrize("backend", ["gloo", "ipc"])
 @pytest.mark.parametrize("flat", [False, True])
-def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
+def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat, backend):
     """bench.py with WORLD_SIZE = 2 on a one-GPU box: CN_BENCH_BACKEND=gloo lets both ranks share the device and
     reduces through the host, so the world > 1 control flow (per-layer exchange from the communication stream, or
-    the flat exchange; barrier; max-over-ranks timing) runs with real sums.  Replicas must end bit-identical."""
+    the flat exchange; barrier; max-over-ranks timing) runs with real sums.  Replicas must end bit-identical.
+    backend "ipc": the exchange is the LIBRARY's own (cn_comm_init, one cn_allreduce_grads per layer on the communication stream,
+    cn_loss_read_global) on its test backend for ranks that share a device (cn_comm_ipc.cpp)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29300 + os.getpid() % 250 + int(flat)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--master-port", str(29300 + os.getpid() % 250 + int(flat) + 2 * (backend == "ipc")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND="gloo", CN_BENCH_MIN_SECONDS="0")   # one repetition
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND=backend, CN_BENCH_MIN_SECONDS="0")   # one repetition
     if flat:
         env["CN_BENCH_FLAT_ALLREDUCE"] = "1"
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -172,7 +175,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat):
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp2 over sequences"
     assert d["check"]["replicas_identical"] is True and np.isfinite(d["check"]["error_sum"])
-    assert d["check"]["allreduce"].startswith("flat" if flat else "per-layer, overlapped") and "test double" in d["check"]["allreduce"]
+    assert d["check"]["allreduce"].startswith("flat" if flat else "per-layer, overlapped")
+    assert ("test double" if backend == "gloo" else "ipc TEST backend") in d["check"]["allreduce"]
     # the same five steps in ONE process on the union of the two ranks' fractions (16 sequences per fraction): gradients
     # are sums over patterns, so the data-parallel run must move the weights the same way.  An exchange that read a
     # layer's gradient before it was complete, or an update that did not wait for the exchange, shows up here.
