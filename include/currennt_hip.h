@@ -224,6 +224,15 @@ int  cn_layer_set_learning_rate(cn_layer *layer, float learning_rate);
 /* the same update for every trainable layer of the context in one launch; layers with a learning rate of their own
  * (cn_layer_set_learning_rate) are updated with it */
 int  cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum);
+/* Arms the update of the COMING backward pass (the per-fraction protocol of Optimizer.cu:86-94, hybrid online/batch learning):
+ * each layer applies UpdateWeightFn with these values -- or its own learning rate -- as soon as its own gradient is complete,
+ * on the stream that computed it (behind its all-reduce when a communicator is bound), instead of for all layers behind the
+ * last backward kernel.  The result is the one of cn_layer_backward on every layer followed by cn_sgd_update_all: a layer's
+ * weights are last read by its own backward pass, so the layers below never see the difference; only a cn_layer_read of
+ * CN_BUF_WEIGHTS between the two calls would.  The following cn_sgd_update_all(ctx, same values) -- or cn_sgd_update per
+ * layer -- completes the step (waits, handles layers no backward call reached) and disarms; it is an error to start another
+ * backward pass before it.  Not for batch learning (the epoch sum is formed first) nor with weight noise.        [async] */
+int  cn_ctx_arm_update(cn_ctx *ctx, float learning_rate, float momentum);
 
 /* ---- data-parallel training over the GPUs of one node (no counterpart in the reference, which
  *      drives a single device: main.cpp:526-541) ------------------------------------------------------------

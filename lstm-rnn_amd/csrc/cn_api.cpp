@@ -91,6 +91,8 @@ struct cn_ctx {
     int *d_fault = nullptr;       // device fault word (bounded spins)
     float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
     cn_layer *rowstat_of = nullptr;
+    bool loss_deferred = false;   // cn_loss_accumulate of the current fraction has not been enqueued yet: it rides on the output
+                                  // layer's backward launch (softmax_mcc_bwd_kernel) or is flushed by whoever needs the sums / the rows
 
     // host fractions (cn_fraction_load): packed into pinned memory, uploaded on a copy stream into one of two
     // device staging areas while the previous fraction still computes, re-laid out by fraction_load_kernel
@@ -109,6 +111,11 @@ struct cn_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_comm = nullptr, ev_comm_fork = nullptr;
     bool comm_pending = false;
+
+    // cn_ctx_arm_update: the momentum-SGD step of the coming backward pass is applied layer by layer, as soon as a layer's own
+    // gradient is complete (on the stream that computed it), instead of for all layers behind the last backward kernel
+    bool armed = false;
+    float arm_lr = 0.f, arm_mom = 0.f;
 
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
@@ -160,6 +167,7 @@ struct cn_layer {
     float own_lr = -1.f;                  // JSON "learningRate" (TrainableLayer.cu:58); negative: the optimizer's
     std::vector<float> pending_w;         // set_weights before the arena exists
     bool dirty = true;                    // packed copies out of date
+    bool updated = false;                 // armed update: this layer's step has been enqueued behind its gradient already
 
     // packed copies
     void *Win = nullptr, *WinT = nullptr, *Wrec = nullptr, *WrecT = nullptr;
@@ -473,6 +481,15 @@ void require_loaded(cn_ctx *c)
     if (!c->loaded) throw cn_error(CN_ERR_STATE, "no fraction loaded (call cn_fraction_load first)");
 }
 
+// a deferred cn_loss_accumulate that did not find a backward launch to ride on: the one-workgroup reduction now
+void flush_loss(cn_ctx *c)
+{
+    if (!c->loss_deferred) return;
+    c->loss_deferred = false;
+    Timed tm(c, KC_OTHER);
+    launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
+}
+
 // ---- forward / backward sequences -----------------------------------------------------------
 void lstm_rec_args(cn_layer *l, LstmRec &r)
 {
@@ -511,6 +528,26 @@ void check_rec_lds(const cn_layer *l, bool bwd)
                        " KB of LDS per workgroup (160 KB available)" + (c->prec == P_F32 ? "; use CN_PREC_BF16 or CN_PREC_BF16X3 for layers this wide" : "") +
                        " or shorter fractions (truncate_seq)");
 }
+
+// One layer's weight update + operand copies as one launch of the grouped pack kernel on `st`.
+// mode 1: gradient from the flat weightUpdates; mode 2: from the packed accumulators (unpack fused in, cn_elementwise.hip)
+void launch_layer_update(hipStream_t st, cn_layer *l, int mode, float lr, float mom, hipEvent_t done)
+{
+    cn_ctx *c = l->ctx;
+    PackGroup grp{};
+    PackItem &it = grp.item[grp.n++];
+    it.lstm = l->lstm ? 1 : 0;
+    if (l->lstm) it.lg = lstm_geom(l); else it.fg = ff_geom(l);
+    it.bias = l->bias; it.w = l->w; it.Win = l->Win; it.WinT = l->WinT; it.Wrec = l->Wrec; it.WrecT = l->WrecT;
+    it.bias_p = l->bias_p; it.peep_p = l->peep_p;
+    it.update = mode; it.w_rw = l->w; it.wu = l->wu; it.wd = l->wd; it.wu_rw = l->wu;
+    it.lr = l->own_lr >= 0.f ? l->own_lr : lr; it.mom = mom;
+    it.g_in = l->dWin; it.g_rec = l->dWrec; it.g_bias = l->dbias; it.g_peep = l->dpeep;
+    launch_pack_group(st, c->f32, grp, done);
+    l->dirty = false; l->pack_pending = false; l->updated = true;
+}
+// armed update without a communicator: unpack + update + operand copies ride on ONE launch behind the gradient GEMMs
+bool armed_fused(const cn_layer *l) { return l->ctx->armed && !l->ctx->has_comm(); }
 
 void lstm_forward(cn_layer *l)
 {
@@ -591,7 +628,8 @@ void lstm_backward(cn_layer *l)
         }
         {
             Timed tm(c, KC_OTHER, st);
-            launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu, join);
+            if (armed_fused(l)) launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join);
+            else launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu, join);
         }
         return join != nullptr;
     }, fork_attached);
@@ -613,6 +651,7 @@ void ff_forward(cn_layer *l)
         launch_gemm_nt(c->stream, c->prec, g);
     }
     if (softmax) {
+        flush_loss(c);                         // (the row statistics are about to be overwritten)
         Timed tm(c, KC_OTHER);
         const bool stat = c->d_rowstat != nullptr;
         launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp, stat ? c->d_tcls : nullptr, stat ? c->d_rowstat : nullptr);
@@ -630,7 +669,10 @@ void ff_backward(cn_layer *l)
         Timed tm(c, KC_OTHER);
         if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
             // bf16 mode: the fp32 outputErrors stay unwritten (read back from the bf16 operand copy if anyone asks)
-            launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias);
+            const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
+            launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
+                                   with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr);
+            if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
         } else {
             l->err_in_delta = false;
@@ -662,7 +704,8 @@ void ff_backward(cn_layer *l)
         }
         {
             Timed tm(c, KC_OTHER, st);
-            launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu, join);
+            if (armed_fused(l)) launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join);
+            else launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu, join);
         }
         return join != nullptr;
     }, fork_attached);
@@ -928,6 +971,8 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
                 if (test_double) launch_scale(ctx->comm_stream, l->wu, (size_t)l->nw, 2.0f);
                 else if (ctx->ipc) ipc_reduce(ctx, l->wu, (size_t)l->nw);
                 else RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
+                // armed update: the layer's step follows its reduction on the communication stream
+                if (ctx->armed && !l->updated) launch_layer_update(ctx->comm_stream, l, 1, ctx->arm_lr, ctx->arm_mom, nullptr);
             }
         }
         HIP_CHECK(hipEventRecord(ctx->ev_comm, ctx->comm_stream));
@@ -1142,6 +1187,7 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
         if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
         finalize(ctx);
         join_side(ctx);                      // gradient GEMMs of the previous fraction still read the activations
+        flush_loss(ctx);                     // (a deferred loss sum counts the rows of the fraction that is being replaced)
         const size_t PS = ctx->PS, PSp = ctx->PSp;
         const size_t N = (size_t)T * PSp;
         Timed tm(ctx, KC_OTHER);
@@ -1282,6 +1328,8 @@ int cn_layer_backward(cn_layer *layer)
         HIP_CHECK(hipSetDevice(c->device));
         require_loaded(c);
         finalize(c);
+        if (layer->trainable && layer->updated)
+            throw cn_error(CN_ERR_STATE, "cn_layer_backward: the armed update of this layer's previous backward pass has not been completed (call cn_sgd_update_all / cn_sgd_update first)");
         if (layer->lstm) lstm_backward(layer);
         else if (layer->trainable) ff_backward(layer);
         else if (layer->post) {
@@ -1311,6 +1359,7 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
             else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
                 launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
             else {
+                flush_loss(c);
                 launch_post_eval(c->stream, post_kind(post), o->out_f32, post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss, true);
                 c->rowstat_of = nullptr;       // the softmax row statistics were overwritten
             }
@@ -1336,6 +1385,14 @@ int cn_loss_accumulate(cn_layer *post)
         if (!post->post) throw cn_error(CN_ERR_BAD_ARG, "cn_loss_accumulate: not a post output layer");
         require_loaded(c);
         cn_layer *o = post->prev;
+        flush_loss(c);
+        // Training: the backward pass of the output layer follows; its launch (softmax_mcc_bwd_kernel) takes the sum along in one
+        // extra workgroup, so nothing is enqueued here.  Whoever needs the sums or overwrites the rows first flushes (flush_loss).
+        static const bool defer_off = getenv("CN_NO_LOSS_DEFER") != nullptr;
+        if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o && !c->timing && !defer_off && softmax_mcc_bwd_takes_loss(o->Lp)) {
+            c->loss_deferred = true;
+            return;
+        }
         Timed tm(c, KC_OTHER);
         if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
             launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
@@ -1353,6 +1410,7 @@ int cn_loss_read(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset)
     if (!ctx) { g_last_error = "cn_loss_read: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         HIP_CHECK(hipSetDevice(ctx->device));
+        flush_loss(ctx);
         float h[2];
         HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
         if (reset) HIP_CHECK(hipMemsetAsync(ctx->d_loss_acc, 0, sizeof(h), ctx->stream));
@@ -1369,6 +1427,7 @@ int cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int
     return guarded([&] {
         require_comm(ctx, "cn_loss_read_global");
         HIP_CHECK(hipSetDevice(ctx->device));
+        flush_loss(ctx);
         float *g = ctx->d_loss + 4, h[2];
         if (ctx->ipc) {
             HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1555,6 +1614,16 @@ int cn_ctx_weights_touched(cn_ctx *ctx)
     return CN_OK;
 }
 
+int cn_ctx_arm_update(cn_ctx *ctx, float learning_rate, float momentum)
+{
+    if (!ctx) { g_last_error = "cn_ctx_arm_update: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        for (cn_layer *l : ctx->layers)
+            if (l->updated) throw cn_error(CN_ERR_STATE, "cn_ctx_arm_update: the previous armed update has not been completed (cn_sgd_update_all)");
+        ctx->armed = true; ctx->arm_lr = learning_rate; ctx->arm_mom = momentum;
+    });
+}
+
 int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
 {
     if (!layer) { g_last_error = "cn_sgd_update: layer is NULL"; return CN_ERR_BAD_ARG; }
@@ -1564,6 +1633,16 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_sgd_update: layer has no weights");
         finalize(c);
         join_side(c);
+        if (layer->updated) {            // cn_ctx_arm_update: this layer's step ran behind its gradient; nothing left but the wait above
+            const float want = layer->own_lr >= 0.f ? layer->own_lr : c->arm_lr;
+            if (learning_rate != want || momentum != c->arm_mom)
+                throw cn_error(CN_ERR_STATE, "cn_sgd_update: learning rate / momentum differ from what cn_ctx_arm_update armed and applied");
+            layer->updated = false;
+            bool any = false;
+            for (cn_layer *o : c->layers) any = any || o->updated;
+            if (!any) c->armed = false;
+            return;
+        }
         Timed tm(c, KC_OTHER);
         launch_sgd(c->stream, layer->w, layer->wu, layer->wd, (size_t)layer->nw, learning_rate, momentum);
         layer->dirty = true;
@@ -1585,9 +1664,23 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         HIP_CHECK(hipSetDevice(ctx->device));
         finalize(ctx);
         join_side(ctx);
+        // cn_ctx_arm_update: layers whose step ran behind their gradient are complete (the wait above orders this stream behind
+        // them); what follows handles the rest (none, normally)
+        bool any_updated = false;
+        for (cn_layer *l : ctx->layers) any_updated = any_updated || l->updated;
+        if (any_updated && (learning_rate != ctx->arm_lr || momentum != ctx->arm_mom))
+            throw cn_error(CN_ERR_STATE, "cn_sgd_update_all: learning rate / momentum differ from what cn_ctx_arm_update armed and applied");
+        ctx->armed = false;
+        struct ClearUpdated { cn_ctx *c; ~ClearUpdated() { for (cn_layer *l : c->layers) l->updated = false; } } clear_updated{ctx};
         Timed tm(ctx, KC_OTHER);
         int ntrain = 0;
-        for (cn_layer *l : ctx->layers) if (l->trainable) ++ntrain;
+        for (cn_layer *l : ctx->layers) if (l->trainable && !l->updated) ++ntrain;
+        if (ntrain == 0) return;
+        if (any_updated) {               // some layers were not reached by the armed pass (no backward call for them): one launch each
+            for (cn_layer *l : ctx->layers)
+                if (l->trainable && !l->updated) launch_layer_update(ctx->stream, l, 1, learning_rate, momentum, nullptr);
+            return;
+        }
         // The operand copies of the new weights are rebuilt right away, all layers in ONE launch on this stream
         // (pack_group_kernel): it costs about as much as the first layer's copy alone did, which was on the critical
         // path anyway, and the other layers' copies no longer need a fork event, the side stream and a wait.

@@ -44,24 +44,31 @@ __device__ __forceinline__ int pad_col(int i, int prevH, int prevHp)
 // ---------------------------------------------------------------------------------------------
 // The weight at flat index fi as the operand copies should see it: as stored, or (upd) after the momentum-SGD step, which this
 // thread then also writes back (same arithmetic as sgd_kernel: separate multiplies and adds, no contraction).
-struct PackUpd { float *w_rw; const float *wu; float *wd; float lr, mom; };
-template <bool UPD>
-__device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, long fi)
+// UPD = 2: the gradient of this weight is still in its PACKED accumulator `gp` (scaled by gscale: the bias gradient of a
+// feed-forward layer is bias * column sum, FeedForwardLayer.cu:94-100): it is read, cleared for the next backward pass and
+// written to the flat weightUpdates on the way (what lstm_unpack_kernel / ff_unpack_kernel do in the unfused sequence).
+struct PackUpd { float *w_rw; const float *wu; float *wd; float lr, mom; float *wu_rw; };
+template <int UPD>
+__device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, long fi, float *gp = nullptr, float gscale = 1.0f)
 {
-    if constexpr (UPD) {
-        const float dl = __fsub_rn(__fmul_rn(u.mom, u.wd[fi]), __fmul_rn(u.lr, u.wu[fi]));   // SteepestDescentOptimizer.cu:51
+    if constexpr (UPD != 0) {
+        float g;
+        if constexpr (UPD == 2) { g = *gp; *gp = 0.f; if (gscale != 1.0f) g = __fmul_rn(gscale, g); u.wu_rw[fi] = g; }
+        else g = u.wu[fi];
+        const float dl = __fsub_rn(__fmul_rn(u.mom, u.wd[fi]), __fmul_rn(u.lr, g));          // SteepestDescentOptimizer.cu:51
         u.wd[fi] = dl;
         const float v = __fadd_rn(u.w_rw[fi], dl);                                            // :55
         u.w_rw[fi] = v;
         return v;
     } else return w[fi];
 }
+struct PackGrad { float *g_in, *g_rec, *g_bias, *g_peep; };
 
 // (first / count: the workgroups [first, first + count) of the launch work on this layer: pack_group_kernel)
-template <bool F32, bool UPD = false>
+template <bool F32, int UPD = 0>
 __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, const float *w, void *Win, void *WinT,
                                                void *Wrec, void *WrecT, float *bias_p, float *peep_p, int first, int count,
-                                               const PackUpd &upd = PackUpd{})
+                                               const PackUpd &upd = PackUpd{}, const PackGrad &pg = PackGrad{})
 {
     const int P = g.P, Pp = g.Pp, L = g.L, H = g.H, Hp = g.Hp, dirs = g.dirs;
     const long R = (long)dirs * 4 * Hp;                 // packed gate rows
@@ -75,7 +82,7 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             const int d = r / (4 * Hp), j = (r / 4) % Hp, gg = r % 4;
             const int i = unpad_col(pc, P, g.prevH, g.prevHp, g.prevDirs);
             float v = 0.f;
-            if (j < H && i >= 0) v = pack_fetch<UPD>(w, upd, (long)gg * L * P + (long)d * H * P + (long)j * P + i);
+            if (j < H && i >= 0) v = pack_fetch<UPD>(w, upd, (long)gg * L * P + (long)d * H * P + (long)j * P + i, pg.g_in + (long)r * Pp + pc);   // dWin[r][pc]
             st_op<F32>(Win, (long)r * Pp + pc, v);
             st_op<F32>(WinT, (long)pc * R + r, v);
         } else if (idx < nIn + nRec) {
@@ -84,17 +91,18 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             const int gg = rem / (Hp * Hp), j = (rem / Hp) % Hp, i = rem % Hp;
             float v = 0.f;
             if (j < H && i < H)
-                v = pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i);
+                v = pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i,
+                                    pg.g_rec + ((long)d * 4 * Hp + 4 * j + gg) * Hp + i);                                    // dWrec[d][4j + g][i]
             st_op<F32>(Wrec, ((long)d * 4 * Hp + gg * Hp + j) * Hp + i, v);
             st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + 4 * j + gg, v);
         } else if (idx < nIn + nRec + nB) {
             const int k = idx - nIn - nRec;
             const int d = k / (4 * Hp), j = (k / 4) % Hp, gg = k % 4;
-            bias_p[k] = (j < H) ? bias * pack_fetch<UPD>(w, upd, 4L * L * P + gg * L + d * H + j) : 0.f;   // LstmLayer.cu:97-100
+            bias_p[k] = (j < H) ? bias * pack_fetch<UPD>(w, upd, 4L * L * P + gg * L + d * H + j, pg.g_bias + k) : 0.f;   // LstmLayer.cu:97-100
         } else {
             const int k = idx - nIn - nRec - nB;
             const int d = k / (3 * Hp), pp = (k / Hp) % 3, j = k % Hp;
-            peep_p[k] = (j < H) ? pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j) : 0.f;
+            peep_p[k] = (j < H) ? pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j, pg.g_peep + k) : 0.f;
         }
     }
 }
@@ -159,21 +167,21 @@ void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, flo
 // feed-forward weight packing (flat layout: [j][i] P x L column-major then L bias weights,
 // FeedForwardLayer.cu:148,160)
 // ---------------------------------------------------------------------------------------------
-template <bool F32, bool UPD = false>
+template <bool F32, int UPD = 0>
 __device__ __forceinline__ void ff_pack_body(const FfGeom &g, float bias, const float *w, void *W, void *WT, float *bias_p, int first, int count,
-                                             const PackUpd &upd = PackUpd{})
+                                             const PackUpd &upd = PackUpd{}, const PackGrad &pg = PackGrad{})
 {
     const long nW = (long)g.Lp * g.Pp, total = nW + g.Lp;
     for (long idx = (blockIdx.x - first) * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)count * blockDim.x) {
         if (idx < nW) {
             const int j = idx / g.Pp, pc = idx % g.Pp;
             const int i = unpad_col(pc, g.P, g.prevH, g.prevHp, g.prevDirs);
-            float v = (j < g.L && i >= 0) ? pack_fetch<UPD>(w, upd, (long)j * g.P + i) : 0.f;
+            float v = (j < g.L && i >= 0) ? pack_fetch<UPD>(w, upd, (long)j * g.P + i, pg.g_in + (long)j * g.Pp + pc) : 0.f;
             st_op<F32>(W, (long)j * g.Pp + pc, v);
             st_op<F32>(WT, (long)pc * g.Lp + j, v);
         } else {
             const int j = idx - nW;
-            bias_p[j] = (j < g.L) ? bias * pack_fetch<UPD>(w, upd, (long)g.L * g.P + j) : 0.f;            // FeedForwardLayer.cu:59
+            bias_p[j] = (j < g.L) ? bias * pack_fetch<UPD>(w, upd, (long)g.L * g.P + j, pg.g_bias + j, bias) : 0.f;            // FeedForwardLayer.cu:59
         }
     }
 }
@@ -194,9 +202,15 @@ __global__ void pack_group_kernel(PackGroup grp)
     const PackItem &it = grp.item[i];
     const int count = (i + 1 < grp.n ? grp.first[i + 1] : (int)gridDim.x) - grp.first[i];
     if (it.update) {      // cn_sgd_update_all: the weight update rides on the pack (one launch instead of two on the critical tail)
-        const PackUpd upd{it.w_rw, it.wu, it.wd, it.lr, it.mom};
-        if (it.lstm) lstm_pack_body<F32, true>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd);
-        else         ff_pack_body<F32, true>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd);
+        const PackUpd upd{it.w_rw, it.wu, it.wd, it.lr, it.mom, it.wu_rw};
+        if (it.update == 2) {   // armed update: ... and so does the unpacking of the gradient
+            const PackGrad pg{it.g_in, it.g_rec, it.g_bias, it.g_peep};
+            if (it.lstm) lstm_pack_body<F32, 2>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd, pg);
+            else         ff_pack_body<F32, 2>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd, pg);
+            return;
+        }
+        if (it.lstm) lstm_pack_body<F32, 1>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd);
+        else         ff_pack_body<F32, 1>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd);
         return;
     }
     if (it.lstm) lstm_pack_body<F32>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count);
@@ -582,24 +596,28 @@ void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, 
 }
 
 // fixed-order reduction of the row statistics: loss2[0] += -sum(log p), loss2[1] (int) += #correct
-__global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2, float scale)
+// One workgroup, fixed summation order (reproducible): 1024 "virtual threads" v take rows v, v + 1024, ... (four loads in flight
+// at a time: a plain strided loop is a chain of N/1024 memory round trips, 10 us at N = 17 500), 16 virtual waves are folded with
+// xor shuffles, their sums added in wave order.  A workgroup of fewer threads walks the virtual threads in passes and forms the
+// SAME sums in the same order (softmax_mcc_bwd_kernel's extra workgroup: the reduction rides beside the backward rows).
+__device__ __forceinline__ void rowstat_reduce_body(const float2 *rowstat, int N, float *loss2, float scale)
 {
-    // one workgroup, fixed summation order (reproducible).  The loads of a thread are independent of each other: four
-    // are in flight at a time (a plain strided loop is a chain of N/1024 memory round trips, 10 us at N = 17 500).
     __shared__ float sl[16]; __shared__ int sc[16];
-    float l4[4] = {0.f, 0.f, 0.f, 0.f}; int c4[4] = {0, 0, 0, 0};
-    for (int i0 = threadIdx.x; i0 < N; i0 += 4 * 1024) {
-        float2 v[4];
+    for (int vt = threadIdx.x; vt < 1024; vt += blockDim.x) {
+        float l4[4] = {0.f, 0.f, 0.f, 0.f}; int c4[4] = {0, 0, 0, 0};
+        for (int i0 = vt; i0 < N; i0 += 4 * 1024) {
+            float2 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024; v[k] = i < N ? rowstat[i] : make_float2(0.f, 0.f); }
+            for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024; v[k] = i < N ? rowstat[i] : make_float2(0.f, 0.f); }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { l4[k] += v[k].x; c4[k] += (int)v[k].y; }
+            for (int k = 0; k < 4; ++k) { l4[k] += v[k].x; c4[k] += (int)v[k].y; }
+        }
+        float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        int c = c4[0] + c4[1] + c4[2] + c4[3];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); c += __shfl_xor(c, o); }
+        if ((vt & 63) == 0) { sl[vt >> 6] = l; sc[vt >> 6] = c; }
     }
-    float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
-    int c = c4[0] + c4[1] + c4[2] + c4[3];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); c += __shfl_xor(c, o); }
-    if ((threadIdx.x & 63) == 0) { sl[threadIdx.x >> 6] = l; sc[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float lt = 0.f; int ct = 0;
@@ -607,6 +625,10 @@ __global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2
         for (int w = 0; w < 16; ++w) { lt += sl[w]; ct += sc[w]; }
         loss2[0] += scale * lt; ((int *)loss2)[1] += ct;
     }
+}
+__global__ void rowstat_reduce_kernel(const float2 *rowstat, int N, float *loss2, float scale)
+{
+    rowstat_reduce_body(rowstat, N, loss2, scale);
 }
 void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset, float scale)
 {
@@ -640,10 +662,14 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 // Requires Lp <= 256 (column sums live in 4 registers per lane).
 // `err` may be null in bf16 mode: the fp32 outputErrors of the layer are then not materialised (nothing on the training path reads
 // them: the products take the bf16 operand copy), which is 4 of the 10 bytes per element this HBM-bound pass moves.
+// `loss2` != null: ONE extra workgroup (the last) sums the row statistics of the forward pass into loss2 (cn_loss_accumulate
+// deferred into this launch: 9 us of a one-workgroup kernel off the critical path).
 template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                                       float *err, void *delta_op, float *colsum)
+                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2)
 {
+    if (loss2 && blockIdx.x == gridDim.x - 1) { rowstat_reduce_body(rowstat, N, loss2, -1.0f); return; }
+    const unsigned nwg = gridDim.x - (loss2 ? 1u : 0u);
     // One row is a chain of dependent loads (target class -> its posterior -> the row), so a wave works on RB
     // rows at a time to keep RB chains in flight.  The column sums end in one atomic per column and WORKGROUP:
     // they are same-address atomics, so the grid stays at one workgroup per CU (2048 workgroups: 50 us).
@@ -651,7 +677,7 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     __shared__ float part[4][256];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long row0 = ((long)blockIdx.x * 4 + wv) * RB; row0 < N; row0 += (long)gridDim.x * 4 * RB) {
+    for (long row0 = ((long)blockIdx.x * 4 + wv) * RB; row0 < N; row0 += (long)nwg * 4 * RB) {
         int tc[RB]; bool real[RB]; float et[RB], off[RB], pt_[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
@@ -738,8 +764,9 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
     }
 }
 
+bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum)
+                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2)
 {
     if (N <= 0) return;
     if (Lp > 256) {
@@ -749,8 +776,9 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
         return;
     }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
-    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
-    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
+    if (loss2) ++blocks;
+    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2);
+    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -137,6 +137,10 @@ struct PackItem {
     // update == 1: the momentum-SGD step of SteepestDescentOptimizer.cu:39-59 is applied on the way (every flat weight is read by
     // exactly one packed position, so the thread that packs it also updates it): wd = mom*wd - lr*wu; w += wd
     int update; float *w_rw; const float *wu; float *wd; float lr, mom;
+    // update == 2 (cn_ctx_arm_update, no communicator): the gradient is taken straight from the PACKED accumulators the gradient
+    // GEMMs / recurrent kernel summed into (every packed position is visited by exactly one thread, which also clears it and
+    // writes the flat weightUpdates entry): unpack + update + operand copies in ONE launch behind the layer's gradient GEMMs
+    float *wu_rw; float *g_in, *g_rec, *g_bias, *g_peep;      // lstm: dWin, dWrec, dbias, dpeep; ff: dW (g_in), colsum (g_bias)
 };
 struct PackGroup { PackItem item[PACK_GROUP_MAX]; int first[PACK_GROUP_MAX]; int n; };
 void launch_pack_group(hipStream_t s, bool f32, PackGroup &grp, hipEvent_t done = nullptr);
@@ -163,8 +167,11 @@ void launch_post_eval(hipStream_t s, int kind, const float *y, const float *tgt,
 void launch_post_backward(hipStream_t s, int kind, const float *y, const float *tgt, const char *pat, int N, int L, int Lp, float *err);
 void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N);
 // multiclass error injection + softmax Jacobian + delta copy + bias column sums in one pass (Lp <= 256)
+// rowstat / loss2 (nullable; narrow rows only, softmax_mcc_bwd_takes_loss): the launch also sums the forward pass's row
+// statistics into loss2 like launch_rowstat_reduce(..., reset = false) would, in one extra workgroup
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum);
+                            float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr);
+bool softmax_mcc_bwd_takes_loss(int Lp);
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
 // multiclass_classification: loss/#correct reduction and error injection

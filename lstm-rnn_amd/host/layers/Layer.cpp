@@ -78,6 +78,8 @@ TrainableLayer::TrainableLayer(cn_ctx *ctx, const json::Value &layerChild, const
     , m_learningRate(layerChild.hasMember("learningRate") ? (real_t)layerChild["learningRate"].getDouble() : -1)
 {
     if (!layerChild.hasMember("bias")) throw std::runtime_error("Missing value 'bias' in layer '" + name() + "'");   // TrainableLayer.cu:61-62
+    // the layer's own learning rate (TrainableLayer.cu:58) is also what an armed update (cn_ctx_arm_update) applies to it
+    if (m_learningRate >= 0) cn_layer_set_learning_rate(m_handle, m_learningRate);
     if (weightsSection && weightsSection->hasMember(name())) {                                                    // :68-101
         const json::Value &w = (*weightsSection)[name()];
         if (!w.isObject()) throw std::runtime_error("Weights section for layer '" + name() + "' is not an object");

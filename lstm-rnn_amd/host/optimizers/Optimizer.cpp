@@ -76,6 +76,7 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
                     layer->setWeights(noisy);
                 }
             }
+            if (m_hybridOnlineBatch && !(m_weightNoiseSigma > 0)) _armUpdate();
             m_neuralNetwork.computeBackwardPass();
             if (m_weightNoiseSigma > 0) {
                 hipCheck(cn_ctx_join(m_neuralNetwork.context()), m_neuralNetwork.context());   // gradient GEMMs still read the noisy operands
@@ -272,6 +273,12 @@ SteepestDescentOptimizer::SteepestDescentOptimizer(NeuralNetwork &neuralNetwork,
                                                    real_t momentum, bool hybridOnlineBatch)
     : Optimizer(neuralNetwork, trainingSet, validationSet, testSet, maxEpochs, maxEpochsNoBest, validateEvery, testEvery, hybridOnlineBatch)
     , m_learningRate(learningRate), m_momentum(momentum) {}
+
+void SteepestDescentOptimizer::_armUpdate()
+{
+    NeuralNetwork &nn = _neuralNetwork();
+    hipCheck(cn_ctx_arm_update(nn.context(), m_learningRate, m_momentum), nn.context());
+}
 
 void SteepestDescentOptimizer::_updateWeights()
 {

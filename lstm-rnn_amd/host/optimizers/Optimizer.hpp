@@ -41,6 +41,9 @@ public:
 
 protected:
     virtual void _updateWeights() = 0;
+    // hybrid online/batch learning without weight noise: the update of the coming backward pass may be applied layer by layer
+    // behind each layer's gradient (cn_ctx_arm_update); _updateWeights() then only completes it
+    virtual void _armUpdate() {}
     real_t _processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates, real_t *classError);   // Optimizer.cu:37-104
     void _scoreValidationSet();                                         // validation part of train()
     bool _dueThisEpoch(const data_sets::DataSet &set, int every) const;
@@ -79,6 +82,7 @@ public:
     void importState(const json::Value &jsonDoc);
 protected:
     void _updateWeights();                                              // SteepestDescentOptimizer.cu:67-94
+    void _armUpdate();
 private:
     real_t m_learningRate, m_momentum;
 };

@@ -330,6 +330,11 @@ class NeuralNetwork:
             lr = lay.learning_rate if lay.learning_rate >= 0.0 else learning_rate
             B.check(self.lib.cn_sgd_update(lay.handle, lr, momentum), self.ctx)
 
+    def arm_update(self, learning_rate, momentum):
+        """cn_ctx_arm_update: the coming backward pass applies each layer's momentum-SGD step as soon as that layer's gradient is
+        complete; follow the backward pass with update_weights_fused(same values) (or update_weights), which completes the step."""
+        B.check(self.lib.cn_ctx_arm_update(self.ctx, learning_rate, momentum), self.ctx)
+
     def update_weights_fused(self, learning_rate, momentum):
         """One launch for all layers; layers with a JSON learningRate of their own keep it (cn_layer_set_learning_rate)."""
         B.check(self.lib.cn_sgd_update_all(self.ctx, learning_rate, momentum), self.ctx)

@@ -750,3 +750,61 @@ def test_hand_written_split_bf16_loops_equal_the_compiled_kernels_bit_for_bit(pk
         assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
     for name, g in got["asm"][2].items():
         assert rel_err(g, got["cpp"][2][name]) < 1e-6, name
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_armed_update_equals_update_after_the_backward_pass(pkg, precision):
+    """cn_ctx_arm_update: each layer's UpdateWeightFn step (SteepestDescentOptimizer.cu:39-59) rides on the launch that unpacks
+    its gradient, behind its own gradient GEMMs, instead of one launch for all layers behind the last backward kernel.  A layer's
+    weights are last read by its own backward pass, so four momentum steps must end in the same weights (gradient sums are
+    split-K atomics: equal to ~1e-6), the flat weightUpdates stay readable, a JSON learningRate of a layer is honoured, and both
+    ways of completing the step (cn_sgd_update_all, cn_sgd_update per layer) work."""
+    rng = np.random.RandomState(90 + precision)
+    P, C, PS = 13, 9, 8
+    layers = net_desc(P, [("blstm", 64), ("feedforward_tanh", 24), ("lstm", 32)], C)
+    layers[2]["learningRate"] = 3e-3
+    weights = random_weights(layers, rng, 0.2)
+    fracs = []
+    for k in range(2):
+        xs, ts = random_sequences(rng, [17, 16, 16, 12, 9, 9, 4], P, C=C)
+        fracs.append(pkg.make_fraction(xs, ts, PS))
+    lr, mom = 1e-2, 0.9
+    res = {}
+    for mode in ("plain", "armed_all", "armed_per_layer"):
+        with pkg.NeuralNetwork(layers, weights, PS, 17, precision=precision) as net:
+            for step in range(4):
+                net.load_sequences(fracs[step % 2]); net.compute_forward_pass(); net.calculate_error()
+                if mode != "plain":
+                    net.arm_update(lr, mom)
+                net.compute_backward_pass()
+                if mode == "armed_per_layer":
+                    net.update_weights(lr, mom)
+                else:
+                    net.update_weights_fused(lr, mom)
+            res[mode] = ({l.name: l.weights() for l in net.trainable_layers()}, {l.name: l.weight_updates() for l in net.trainable_layers()})
+    for mode in ("armed_all", "armed_per_layer"):
+        for name, w in res["plain"][0].items():
+            assert np.abs(res[mode][0][name] - w).max() < 2e-6 * max(1.0, np.abs(w).max()), (mode, name)
+            g = res["plain"][1][name]
+            assert np.abs(res[mode][1][name] - g).max() < 1e-5 * max(1e-3, np.abs(g).max()), (mode, name, "weightUpdates")
+    moved = max(np.abs(res["plain"][0][l["name"]] - np.concatenate([np.ravel(weights[l["name"]][k]) for k in ("input", "bias", "internal")])).max()
+                for l in layers if l["name"] in weights)
+    assert moved > 1e-3
+
+
+def test_armed_update_state_errors(pkg):
+    """A second backward pass before the armed step was completed, and a completing call with other values, are refused."""
+    rng = np.random.RandomState(91)
+    layers = net_desc(5, [("lstm", 8)], 3)
+    weights = random_weights(layers, rng, 0.2)
+    xs, ts = random_sequences(rng, [6, 5], 5, C=3)
+    frac = pkg.make_fraction(xs, ts, 2)
+    with pkg.NeuralNetwork(layers, weights, 2, 6) as net:
+        net.load_sequences(frac); net.compute_forward_pass(); net.calculate_error()
+        net.arm_update(1e-2, 0.9); net.compute_backward_pass()
+        with pytest.raises(pkg.CurrenntHipError, match="differ from what cn_ctx_arm_update"):
+            net.update_weights_fused(2e-2, 0.9)
+        net.arm_update(1e-2, 0.9) if False else None
+        net.load_sequences(frac); net.compute_forward_pass(); net.calculate_error()
+        with pytest.raises(pkg.CurrenntHipError, match="armed update"):
+            net.compute_backward_pass()

@@ -3,10 +3,9 @@ import csv, glob, sys
 f = sys.argv[1] if len(sys.argv) > 1 else sorted(glob.glob('gpurun_out/prof_*/*/*kernel_trace.csv'))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-sg = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
-if len(sg) < 3:          # the update rides on the grouped operand pack (cn_sgd_update_all)
-    sg = [i for i, r in enumerate(rows) if 'pack_group_kernel' in r['Kernel_Name']]
-a, b = sg[-3], sg[-2]
+# a step = from one fraction_load_kernel (the first kernel of a step) to the kernel in front of the next one
+sg = [i for i, r in enumerate(rows) if 'fraction_load_kernel' in r['Kernel_Name']]
+a, b = sg[-3] - 1, sg[-2] - 1
 t0 = int(rows[a]['End_Timestamp'])
 prev_end = t0
 agg = {}
