@@ -48,6 +48,8 @@
 #include <type_traits>
 #include <mutex>
 
+#define KEEP_TUPLE(tuple, after) asm volatile("" :: "v"(tuple), "v"(after))
+
 namespace cn {
 
 typedef unsigned long long u64;
@@ -633,6 +635,194 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, PARTIAL-SUM exchange (round 4; one sequence per lane)
+// ---------------------------------------------------------------------------------------------
+// The kernel above splits the BPTT product e[i] = err[i] + sum_k WrecT[i][k] delta[k] (LstmLayer.cu:936-943,970-977) by OUTPUT
+// unit: a member needs the deltas of ALL units, so every lane publishes its four deltas (2 granules in bf16, 4 in the split
+// mode) and polls (CS - 1) x that many, writes the partners' deltas into its LDS tile and passes a second barrier before the
+// second part of the product.  This kernel splits by K instead: a member multiplies ITS OWN deltas (k in its units x 4 gates,
+// already in its LDS tile) with the rows of WrecT of ALL units -- the same number of MFMAs and the same number of W_rec
+// registers -- and hands each partner the partial sums of the partner's units: ONE fp32 granule per lane and partner, the
+// partners' parts first (their trip through L2 runs beside the own part's MFMAs), no partner data in LDS, ONE barrier per
+// step.  e = (err + own part) + partner parts in member order: fp32 sums, the same terms in another order.
+// Split-bf16 mode: the two spare rows of a sequence's row quad carry the lo halves of its deltas (cn_lstm_s2.hip, "row
+// quads"): [hi; lo] x W_hi + [hi; lo] x W_lo = two MFMAs per chunk instead of three, one tile plane instead of two.
+// Granule slot of (destination member, source member, thread): ((dest * CS + src) * NT + tid), two step parities.
+template <int PREC, int HP, int UPC>
+__global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_psum_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool X3 = PREC == P_X3;
+    constexpr int MELT = X3 ? 4 : 2;
+    constexpr bool TH = CN_TH_STORE && UPC <= 64;
+    constexpr int CS = HP / UPC, NT = UPC * 4;
+    constexpr int KCO = 4 * UPC / 64;                // K = 64 chunks of a member's own deltas (k = 4*unit + gate)
+    constexpr int pitch = lds_pitch(KCO * 64);       // a tile row: 32 stored values per chunk
+    constexpr int plane = 16 * pitch;
+    int cluster, member;
+    cluster_of<CS>(cluster, member);
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    if (cluster >= dirs * (PS / 4)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * 4;
+    const int lunit = 16 * wave + c, unit = member * UPC + lunit;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+    // the (n, i) pair of this lane's unit in the even row of its sequence's quad; (f, o) one row further; lo halves two rows further
+    const int toff = (4 * q) * pitch + (lunit >> 4) * 64 + sp_pos(4 * (lunit & 15)) * 2;
+    const int spidx = sp_index(c);
+
+    for (int i = tid * 4; i < 2 * plane; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    bool gaveup = false;
+
+    // W_rec^T fragments: part jp = the rows of member (member + jp) % CS's units, columns = the K chunks of THIS member's deltas
+    u32x8 wsp[CS * KCO];
+    [[maybe_unused]] u32x8 wsl[X3 ? CS * KCO : 1];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * MELT;
+#pragma unroll
+    for (int jp = 0; jp < CS; ++jp)
+#pragma unroll
+        for (int kq = 0; kq < KCO; ++kq) {
+            const long w0 = (long)(((member + jp) % CS) * UPC + lunit) * 4 * HP + (member * KCO + kq) * 64 + q * 16;
+            if constexpr (X3) sp_load_split((const float *)Wd + w0, wsp[jp * KCO + kq], wsl[jp * KCO + kq]);
+            else wsp[jp * KCO + kq] = sp_load_bf16(Wd + w0 * 2);
+        }
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+
+    const int sv = s0 + q;
+    const int oP = sv, oA = sv * (int)arow + (d * HP + unit) * 4, oC = sv * (int)crow + d * HP + unit;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    u64 *xbase = p.xch + (long)cluster * 2 * CS * CS * NT;
+
+    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, ccur;
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
+
+    const int tfirst = d ? 0 : T - 1;
+    ClBwdPre<1> preA, preB;
+    auto prefetch = [&](int t, ClBwdPre<1> &pre) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const int tprev = d ? t + 1 : t - 1;
+        const bool hasprev = tprev >= 0 && tprev < T;
+        pre.pt[0] = (p.pat + (long)t * PS)[oP];
+        pre.e[0] = (p.err + t * stepC)[oC];
+        pre.a[0] = *(const f32x4 *)(p.acts + t * stepA + oA);
+        pre.cp[0] = (p.cell + (hasprev ? tprev : t) * stepC)[oC];
+        if constexpr (TH) pre.th[0] = (p.th + t * stepC)[oC];
+    };
+
+    auto step = [&](int it, ClBwdPre<1> &pre) {
+        const int t = d ? it : T - 1 - it;
+        const char *dcur = smem + (it & 1) * plane;
+        char *dnxt = smem + ((it + 1) & 1) * plane;
+        const bool check = t >= p.Tmin;
+        const int tprev_ = d ? t + 1 : t - 1;
+        const bool hasprev_ = tprev_ >= 0 && tprev_ < T;
+        char *deltaT = (char *)p.delta_op + t * stepA * MELT;
+        u64 *xslot = xbase + (long)(it & 1) * CS * CS * NT;
+
+        const char ptc = pre.pt[0];
+        const float cp = hasprev_ ? pre.cp[0] : 0.f;
+        const f32x4 a_ = pre.a[0];
+        [[maybe_unused]] float th_ = 0.f;
+        if constexpr (TH) th_ = pre.th[0];
+        const float e_in = pre.e[0];
+
+        // this member's deltas of the previous step (zero tile at it = 0): read once, used by every part
+        u32x4 a[KCO];
+#pragma unroll
+        for (int kq = 0; kq < KCO; ++kq) a[kq] = *(const u32x4 *)(dcur + c * pitch + kq * 64 + q * 16);
+        auto part = [&](int jp, float c0) {
+            f32x4 acc = {c0, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kq = 0; kq < KCO; ++kq) {
+                if constexpr (X3) smma16(acc, a[kq], wsl[jp * KCO + kq], spidx);      // small terms first
+                smma16(acc, a[kq], wsp[jp * KCO + kq], spidx);
+            }
+            const float v = X3 ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : acc[0] + acc[1];
+            KEEP_TUPLE(acc, v);
+            return v;
+        };
+        // the partners' parts first: published at once, their trip through L2 runs beside the own part below
+        if (it > 0) {
+#pragma unroll
+            for (int jp = 1; jp < CS; ++jp) {
+                const float v = part(jp, 0.f);
+                const int dest = (member + jp) % CS;
+                publish(xslot + ((long)dest * CS + member) * NT + tid, p.xch_epoch + it + 1, __float_as_uint(v));
+            }
+        }
+        float e = part(0, e_in);                     // err enters as the C operand (LstmLayer.cu:939: addProduct into tmpOutputErrors)
+        if (it > 0) {
+            const u64 *slots[CS - 1];
+            unsigned vals[CS - 1];
+#pragma unroll
+            for (int j = 0; j < CS - 1; ++j) slots[j] = xslot + ((long)member * CS + (member + 1 + j) % CS) * NT + tid;
+            consume_all<CS - 1>(slots, p.xch_epoch + it + 1, p.fault, vals, gaveup);
+#pragma unroll
+            for (int j = 0; j < CS - 1; ++j) e += __uint_as_float(vals[j]);
+        }
+        prefetch(d ? t + 2 : t - 2, pre);            // behind the poll (it drains vmcnt)
+
+        const bool dummy = check && ptc == 0;
+        // ComputeBlockErrorsFn, LstmLayer.cu:236-285
+        const float ni = a_[0], ig = a_[1], fg = a_[2], og = a_[3];
+        const float cs = ccur;
+        const float th = TH ? th_ : tanh_ref<false>(cs);
+        float dog = og * (1.0f - og) * th * e;
+        float ec = og * (1.0f - th * th) * e + po * dog;
+        ec += fgn * ecn + pi * dign + pf * dfgn;
+        float dni = ig * (1.0f - ni * ni) * ec;
+        float dfg = fg * (1.0f - fg) * cp * ec;
+        float dig = ig * (1.0f - ig) * ni * ec;
+        dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
+        dni = dummy ? 0.f : dni; dig = dummy ? 0.f : dig; dfg = dummy ? 0.f : dfg; dog = dummy ? 0.f : dog;
+        ec = dummy ? 0.f : ec;
+        fgn = dummy ? 0.f : fg;
+        ecn = ec; dign = dig; dfgn = dfg;
+        ccur = cp;
+        sb[0] += dni; sb[1] += dig; sb[2] += dfg; sb[3] += dog;
+        spi += cp * dig; spf += cp * dfg; spo += cs * dog;
+        if constexpr (X3) {
+            const f32x4 dv = {dni, dig, dfg, dog};
+            const float ds[4] = {dni, dig, dfg, dog};
+            bf16x4 dh, dl;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { __bf16 h_, l_; split_bf16(ds[g], h_, l_); dh[g] = h_; dl[g] = l_; }
+            const uint2 hb = __builtin_bit_cast(uint2, dh), lb = __builtin_bit_cast(uint2, dl);
+            *(unsigned *)(dnxt + toff) = hb.x; *(unsigned *)(dnxt + toff + pitch) = hb.y;
+            *(unsigned *)(dnxt + toff + 2 * pitch) = lb.x; *(unsigned *)(dnxt + toff + 3 * pitch) = lb.y;
+            *(f32x4 *)((float *)deltaT + oA) = dv;
+        } else {
+            const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+            const u64 bits = __builtin_bit_cast(u64, dv);
+            *(unsigned *)(dnxt + toff) = (unsigned)bits;
+            *(unsigned *)(dnxt + toff + pitch) = (unsigned)(bits >> 32);
+            *(bf16x4 *)((__bf16 *)deltaT + oA) = dv;
+        }
+        lds_barrier();
+    };
+
+    ccur = (p.cell + tfirst * stepC)[oC];
+    prefetch(tfirst, preA);
+    prefetch(d ? 1 : T - 2, preB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA);
+        if (it + 1 < T) step(it + 1, preB);
+    }
+
+    float v[7] = {sb[0], sb[1], sb[2], sb[3], spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
+    if (q == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 template <int PREC, int HP, int UPC, int RPL, bool BWD>
@@ -645,6 +835,23 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     // (no clearing per launch: tags continue from LstmRec::xch_epoch, which the caller advances by T + 1 per launch, so
     // the granules a previous launch left behind never match; the memset kernel and its stream bubble cost ~7 us per
     // layer pass)
+    if constexpr (BWD && RPL == 1) {
+        // One sequence per lane: the partial-sum exchange.  Measured (round 4, DESIGN A.5): the split-bf16 mode gains 5 % per step of
+        // reading B (two MFMAs per chunk instead of three, 3 instead of 12 polled granules per thread); in bf16 the critical path
+        // of a step is the same as with the delta exchange (delta -> LDS -> barrier -> MFMAs -> hop, in another order) and the
+        // kernel measures 3-4 % SLOWER (2-CU and 8-CU shapes alike), so bf16 keeps the delta exchange.
+        // CN_BWD_PSUM=1 / CN_NO_BWD_PSUM=1 force either one (A/B, tests).
+        const bool psum = getenv("CN_BWD_PSUM") ? true : (getenv("CN_NO_BWD_PSUM") ? false : PREC == P_X3);
+        if (psum) {
+            auto kp = lstm_bwd_cluster_psum_kernel<PREC, HP, UPC>;
+            static DeviceOnce attr_once_p;
+            if (attr_once_p.first()) (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            const size_t lds_p = 2 * 16 * (size_t)lds_pitch(4 * UPC);
+            hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), lds_p, s, p);
+            if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_bwd_cluster_psum_kernel<%d,%d,%d>", PREC, HP, UPC);
+            return;
+        }
+    }
     auto kern = BWD ? lstm_bwd_cluster_kernel<PREC, HP, UPC, RPL> : lstm_fwd_cluster_kernel<PREC, HP, UPC, RPL>;
     static DeviceOnce attr_once;
     if (attr_once.first()) {
@@ -683,7 +890,9 @@ size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int n
     if (CS == 0) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     const int NT = (Hp / CS) * 4;
-    return (size_t)nclusters * 2 * CS * rpl * (prec == P_X3 ? 4 : 2) * NT * sizeof(u64);     // (the backward kernel's granules)
+    const size_t delta_scheme = (size_t)nclusters * 2 * CS * rpl * (prec == P_X3 ? 4 : 2) * NT * sizeof(u64);     // (the delta-exchange backward kernel's granules)
+    const size_t psum_scheme = (size_t)nclusters * 2 * CS * CS * NT * sizeof(u64);                                  // lstm_bwd_cluster_psum_kernel
+    return delta_scheme > psum_scheme ? delta_scheme : psum_scheme;
 }
 
 // Cluster launches of one device go through one gate: a cluster kernel needs ALL its workgroups resident, and two such

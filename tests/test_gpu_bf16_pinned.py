@@ -158,3 +158,21 @@ def test_softmax_8000_classes(pkg, orc):
     frac = pkg.make_fraction(xs, ts, PS)
     rep = check_pinned(pkg, orc, layers, weights, frac, PS)
     print("bf16 pinned, softmax 8000:", {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+@pytest.mark.parametrize("size,kernel", [(500, "lstm_bwd_cluster_psum_kernel<0,256,128>"), (1024, "lstm_bwd_cluster_psum_kernel<0,512,64>")])
+def test_partial_sum_exchange_backward_clusters_in_bf16(pkg, orc, monkeypatch, size, kernel):
+    """lstm_bwd_cluster_psum_kernel (members exchange fp32 partial sums of the BPTT product instead of deltas, LstmLayer.cu:936-943)
+    is the default in the split-bf16 mode only (in bf16 it measured 3-4 % slower than the delta exchange, DESIGN A.5); CN_BWD_PSUM=1
+    selects it in bf16: the 2-CU and the 8-CU shapes against the bf16-operand oracle at the pinned tolerances."""
+    monkeypatch.setenv("CN_BWD_PSUM", "1")
+    monkeypatch.setenv("CN_NO_S2W", "1")          # (forward pass on the cluster kernels too: the exchange buffer is shared by both passes)
+    rng = np.random.RandomState(75 + size)
+    P, C, PS = 39, 183, 16
+    layers = net_desc(P, [("blstm", size)] * 2, C)
+    weights = random_weights(layers, rng, 0.05)
+    lengths = [40, 40, 39, 37, 33, 30, 30, 28, 22, 20, 17, 15, 11, 8, 3, 1]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    fwd = "lstm_fwd_cluster_kernel<0,256,128,1>" if size == 500 else "lstm_fwd_cluster_kernel<0,512,64,1>"
+    check_pinned(pkg, orc, layers, weights, frac, PS, kernels=(fwd, kernel))

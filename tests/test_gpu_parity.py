@@ -247,12 +247,14 @@ X3_CASES = {
 }
 
 
-@pytest.mark.parametrize("case", sorted(X3_CASES))
-def test_bf16x3_parity_mode(pkg, orc, case):
+@pytest.mark.parametrize("case", sorted(X3_CASES) + ["blstm500_cluster/delta_exchange"])
+def test_bf16x3_parity_mode(pkg, orc, case, monkeypatch):
     """CN_PREC_BF16X3 (operands split into bf16 hi + lo inside the kernels, three bf16 MFMAs per product, fp32
     accumulation): the SAME tolerances as the exact-fp32 mode -- posteriors max-abs < 1e-4 (BASELINE.json), error 1e-4
     relative, #correct exact, gradients and propagated errors within 2e-4 of the layer's max."""
-    P, hidden, C, lengths, PS, scale = X3_CASES[case]
+    if case.endswith("/delta_exchange"):          # the backward cluster kernel that exchanges deltas (three MFMAs per chunk), kept for A/B
+        monkeypatch.setenv("CN_NO_BWD_PSUM", "1")
+    P, hidden, C, lengths, PS, scale = X3_CASES[case.split("/")[0]]
     rng = np.random.RandomState(71)
     layers = net_desc(P, hidden, C)
     weights = random_weights(layers, rng, scale)
@@ -262,7 +264,8 @@ def test_bf16x3_parity_mode(pkg, orc, case):
     with net:
         if "cluster" in case:
             assert net.recurrent_kernel(False) == "lstm_fwd_cluster_kernel<2,256,64,1>"
-            assert net.recurrent_kernel(True) == "lstm_bwd_cluster_kernel<2,256,64,1>"
+            # backward: partial sums exchanged, lo halves in the spare rows of the row quads (two MFMAs per chunk)
+            assert net.recurrent_kernel(True) == ("lstm_bwd_cluster_kernel<2,256,64,1>" if case.endswith("/delta_exchange") else "lstm_bwd_cluster_psum_kernel<2,256,64>")
 
 
 def test_bf16x3_mode_stays_on_the_oracle_through_training(pkg, orc):
