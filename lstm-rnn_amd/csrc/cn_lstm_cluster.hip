@@ -151,7 +151,11 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool X3 = PREC == P_X3;
-    constexpr int MELT = X3 ? 4 : 2, PLANES = X3 ? 2 : 1;
+    // QUAD (split-bf16, one sequence per lane): the two spare rows of a sequence's row quad carry the lo halves of y under the hi
+    // halves (cn_lstm_s2.hip, "row quads"): [hi; lo] x W_lo + [hi; lo] x W_hi = TWO sparse MFMAs per chunk and gate instead of
+    // three (and the lo x lo term on top), one tile plane instead of two; the sum is over all four accumulator registers.
+    constexpr bool QUAD = X3 && RPL == 1;
+    constexpr int MELT = X3 ? 4 : 2, PLANES = (X3 && !QUAD) ? 2 : 1;
     // SP: 2:4 row-pair products (cn_lstm_device.h): a sequence takes two tile rows, a K = 64 chunk is one sparse MFMA and the
     // tile rows are half as long; a member part is UPC / 64 chunks of 32 stored values per row
     constexpr bool SP = (CN_SPARSE || X3) && UPC % 64 == 0;
@@ -244,10 +248,11 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             for (int j = j0; j < j1; ++j) {
                 const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
                 [[maybe_unused]] u32x4 al;
-                if constexpr (X3) al = *(const u32x4 *)(ycur + plane + c * pitch + j * 64 + q * 16);
+                if constexpr (X3 && !QUAD) al = *(const u32x4 *)(ycur + plane + c * pitch + j * 64 + q * 16);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if constexpr (X3) smma16_x3(acc[g], a, al, wsp[g][j], wsl[g][j], spidx);
+                    if constexpr (QUAD) { smma16(acc[g], a, wsl[g][j], spidx); smma16(acc[g], a, wsp[g][j], spidx); }
+                    else if constexpr (X3) smma16_x3(acc[g], a, al, wsp[g][j], wsl[g][j], spidx);
                     else if constexpr (SP) smma16(acc[g], a, wsp[g][j], spidx);
                     else mma16<false>(acc[g], a, wreg[g][j]);
                 }
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
                     if constexpr (X3) {
                         __bf16 yh, yl;
                         split_bf16(__builtin_bit_cast(float, vals[j * RPL + r]), yh, yl);
-                        *(__bf16 *)dst = yh; *(__bf16 *)(dst + plane) = yl;
+                        *(__bf16 *)dst = yh; *(__bf16 *)(dst + (QUAD ? 2 * pitch : plane)) = yl;
                     } else *(unsigned short *)dst = (unsigned short)vals[j * RPL + r];
                 }
             lds_barrier();
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             const float cp = cst[r];
             float s_[4];                                 // recurrent sums of this sequence (SP: its two tile rows)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) s_[g] = SP ? acc[g][(2 * r) & 3] + acc[g][(2 * r + 1) & 3] : acc[g][r];
+            for (int g = 0; g < 4; ++g) s_[g] = QUAD ? (acc[g][0] + acc[g][1]) + (acc[g][2] + acc[g][3]) : (SP ? acc[g][(2 * r) & 3] + acc[g][(2 * r + 1) & 3] : acc[g][r]);
             // ComputeBlockOutputFn, LstmLayer.cu:87-136
             const float ni = tanh_ref<false>(s_[0] + g_[r][0]);
             const float ig = logistic<false>(s_[1] + g_[r][1] + cp * pi);
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
                 publish(mine, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned, yo));
                 __bf16 yh, yl;
                 split_bf16(yo, yh, yl);
-                *(__bf16 *)(ynxt + tile_off(0, r)) = yh; *(__bf16 *)(ynxt + plane + tile_off(0, r)) = yl;
+                *(__bf16 *)(ynxt + tile_off(0, r)) = yh; *(__bf16 *)(ynxt + (QUAD ? 2 * pitch : plane) + tile_off(0, r)) = yl;
             } else {
                 publish(mine, p.xch_epoch + it + 1, __builtin_bit_cast(unsigned short, yb));
                 *(__bf16 *)(ynxt + tile_off(0, r)) = yb;       // the tile is member-relative: own units first
