@@ -671,7 +671,7 @@ void ff_backward(cn_layer *l)
             // bf16 mode: the fp32 outputErrors stay unwritten (read back from the bf16 operand copy if anyone asks)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
-                                   with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr);
+                                   with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6);
             if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
         } else {
@@ -778,8 +778,10 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_NO_ATTACHED_FORKS")) c->attach_forks = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
-        HIP_CHECK(hipMalloc((void **)&c->d_loss, 6 * sizeof(float)));          // per call | running sums | sums over all ranks
-        HIP_CHECK(hipMemsetAsync(c->d_loss, 0, 6 * sizeof(float), c->stream));
+        // per call | running sums | sums over all ranks | 16 x {sum, count} partials + arrival counter of the loss sum that rides on
+        // the output layer's backward launch (softmax_mcc_bwd_kernel)
+        HIP_CHECK(hipMalloc((void **)&c->d_loss, (6 + 2 * 16 + 2) * sizeof(float)));
+        HIP_CHECK(hipMemsetAsync(c->d_loss, 0, (6 + 2 * 16 + 2) * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
         HIP_CHECK(hipMalloc((void **)&c->d_fault, sizeof(int)));
         HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));

@@ -662,14 +662,48 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 // Requires Lp <= 256 (column sums live in 4 registers per lane).
 // `err` may be null in bf16 mode: the fp32 outputErrors of the layer are then not materialised (nothing on the training path reads
 // them: the products take the bf16 operand copy), which is 4 of the 10 bytes per element this HBM-bound pass moves.
-// `loss2` != null: ONE extra workgroup (the last) sums the row statistics of the forward pass into loss2 (cn_loss_accumulate
-// deferred into this launch: 9 us of a one-workgroup kernel off the critical path).
+// `loss2` != null: SIXTEEN extra workgroups (the last ones) sum the row statistics of the forward pass into loss2
+// (cn_loss_accumulate deferred into this launch: 9 us of a one-workgroup kernel off the critical path).  Workgroup w forms the sum
+// of "virtual wave" w of rowstat_reduce_body -- the same loads, the same adds, the same shuffles --, the last one to arrive adds
+// the sixteen sums in wave order: bit-identical to the one-workgroup kernel, a sixteenth of its time.
+constexpr int MCC_LOSS_WGS = 16;
+__device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N, float *loss2, float scale, int w, float *part)
+{
+    if (threadIdx.x >= 64) return;
+    const int vt = 64 * w + threadIdx.x;
+    float l4[4] = {0.f, 0.f, 0.f, 0.f}; int c4[4] = {0, 0, 0, 0};
+    for (int i0 = vt; i0 < N; i0 += 4 * 1024) {
+        float2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = i0 + k * 1024; v[k] = i < N ? rowstat[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { l4[k] += v[k].x; c4[k] += (int)v[k].y; }
+    }
+    float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    int c = c4[0] + c4[1] + c4[2] + c4[3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); c += __shfl_xor(c, o); }
+    if (threadIdx.x == 0) {
+        unsigned *cnt = (unsigned *)(part + 2 * MCC_LOSS_WGS);
+        __hip_atomic_store(&part[2 * w], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((int *)&part[2 * w + 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1) {
+            float lt = 0.f; int ct = 0;
+            for (int k = 0; k < MCC_LOSS_WGS; ++k) {
+                lt += __hip_atomic_load(&part[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ct += __hip_atomic_load((int *)&part[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            loss2[0] += scale * lt; ((int *)loss2)[1] += ct;
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero again for the next launch)
+        }
+    }
+}
 template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2)
+                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2, float *loss_part)
 {
-    if (loss2 && blockIdx.x == gridDim.x - 1) { rowstat_reduce_body(rowstat, N, loss2, -1.0f); return; }
-    const unsigned nwg = gridDim.x - (loss2 ? 1u : 0u);
+    const unsigned nwg = gridDim.x - (loss2 ? (unsigned)MCC_LOSS_WGS : 0u);
+    if (loss2 && blockIdx.x >= nwg) { rowstat_reduce_wave(rowstat, N, loss2, -1.0f, (int)(blockIdx.x - nwg), loss_part); return; }
     // One row is a chain of dependent loads (target class -> its posterior -> the row), so a wave works on RB
     // rows at a time to keep RB chains in flight.  The column sums end in one atomic per column and WORKGROUP:
     // they are same-address atomics, so the grid stays at one workgroup per CU (2048 workgroups: 50 us).
@@ -766,7 +800,7 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
 
 bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2)
+                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part)
 {
     if (N <= 0) return;
     if (Lp > 256) {
@@ -776,9 +810,10 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
         return;
     }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
-    if (loss2) ++blocks;
-    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2);
-    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2);
+    if (loss2 && !loss_part) loss2 = nullptr;
+    if (loss2) blocks += MCC_LOSS_WGS;
+    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part);
+    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -168,9 +168,10 @@ void launch_post_backward(hipStream_t s, int kind, const float *y, const float *
 void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N);
 // multiclass error injection + softmax Jacobian + delta copy + bias column sums in one pass (Lp <= 256)
 // rowstat / loss2 (nullable; narrow rows only, softmax_mcc_bwd_takes_loss): the launch also sums the forward pass's row
-// statistics into loss2 like launch_rowstat_reduce(..., reset = false) would, in one extra workgroup
+// statistics into loss2 like launch_rowstat_reduce(..., reset = false) would (the same sums in the same order), in sixteen extra workgroups
+// `loss_part`: 16 x {float sum, int count} + one arrival counter (zero between launches) for the sixteen reduction workgroups
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr);
+                            float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr);
 bool softmax_mcc_bwd_takes_loss(int Lp);
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
