@@ -683,19 +683,26 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
     int c = c4[0] + c4[1] + c4[2] + c4[3];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); c += __shfl_xor(c, o); }
+    // the last workgroup to arrive adds the sixteen sums in wave order; its lanes fetch them side by side (a chain of dependent
+    // L2 round trips in one thread cost 6 us here)
+    unsigned *cnt = (unsigned *)(part + 2 * MCC_LOSS_WGS);
+    int last = 0;
     if (threadIdx.x == 0) {
-        unsigned *cnt = (unsigned *)(part + 2 * MCC_LOSS_WGS);
         __hip_atomic_store(&part[2 * w], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store((int *)&part[2 * w + 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1) {
-            float lt = 0.f; int ct = 0;
-            for (int k = 0; k < MCC_LOSS_WGS; ++k) {
-                lt += __hip_atomic_load(&part[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ct += __hip_atomic_load((int *)&part[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            loss2[0] += scale * lt; ((int *)loss2)[1] += ct;
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero again for the next launch)
-        }
+        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    const int k = threadIdx.x < MCC_LOSS_WGS ? threadIdx.x : 0;
+    const float pl = __hip_atomic_load(&part[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int pc = __hip_atomic_load((int *)&part[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float lt = 0.f; int ct = 0;
+#pragma unroll
+    for (int j = 0; j < MCC_LOSS_WGS; ++j) { lt += __shfl(pl, j); ct += __shfl(pc, j); }
+    if (threadIdx.x == 0) {
+        loss2[0] += scale * lt; ((int *)loss2)[1] += ct;
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero again for the next launch)
     }
 }
 template <bool F32>
