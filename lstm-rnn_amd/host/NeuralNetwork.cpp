@@ -48,8 +48,15 @@ NeuralNetwork::NeuralNetwork(const json::Value &jsonDoc, int parallelSequences, 
                     if (i != j && m_layers[i]->name() == m_layers[j]->name())
                         throw std::runtime_error("Different layers have the same name '" + m_layers[i]->name() + "'");
 
-            // initial weights for layers that are not in the "weights" section: one generator shared by all
-            // layers in construction order (TrainableLayer.cu:108-124; std::mt19937 here, boost::mt19937 there)
+            // Initial weights for layers that are not in the "weights" section: one generator shared by all layers in construction
+            // order (TrainableLayer.cu:108-124: a function-local static boost::mt19937 seeded with --random_seed).  boost::mt19937
+            // and std::mt19937 are the same engine (MT19937, 32-bit outputs); what differs between the libraries is how a
+            // distribution turns engine outputs into floats, so the UNIFORM case (the default, Configuration.cpp:186-187) restates
+            // Boost's published algorithm for boost::random::uniform_real_distribution<float>(0, range) -- generate_uniform_real:
+            // result = float(engine()) / (float(engine.max()) + 1) * range + 0, drawn again while result >= range -- followed by
+            // the reference's `+ uniformMin`.  Boost is not in this image, so this cannot be checked against a reference run here:
+            // it is NOT part of any parity claim (every parity test passes explicit weights).  The normal case uses
+            // std::normal_distribution (Boost's algorithm for it changed between releases).
             std::mt19937 gen(weightsInit && weightsInit->seed ? weightsInit->seed : 5489u);
             for (size_t i = 0; i < m_layers.size(); ++i) {
                 layers::TrainableLayer *tl = dynamic_cast<layers::TrainableLayer *>(m_layers[i].get());
@@ -60,8 +67,13 @@ NeuralNetwork::NeuralNetwork(const json::Value &jsonDoc, int parallelSequences, 
                     for (size_t k = 0; k < w.size(); ++k) w[k] = dist(gen);
                 } else {
                     const real_t lo = weightsInit ? weightsInit->uniformMin : -0.1f, hi = weightsInit ? weightsInit->uniformMax : 0.1f;
-                    std::uniform_real_distribution<real_t> dist(0, hi - lo);
-                    for (size_t k = 0; k < w.size(); ++k) w[k] = dist(gen) + lo;
+                    const real_t range = hi - lo;
+                    const real_t divisor = static_cast<real_t>(gen.max() - gen.min()) + 1;          // 2^32
+                    for (size_t k = 0; k < w.size(); ++k) {
+                        real_t r;
+                        do { r = static_cast<real_t>(gen() - gen.min()) / divisor * range + 0; } while (range > 0 && !(r < range));
+                        w[k] = r + lo;
+                    }
                 }
                 tl->setWeights(w);
             }
