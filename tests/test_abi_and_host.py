@@ -121,7 +121,10 @@ def test_persistent_gemm_never_touches_its_bias_registers_before_a_counted_wait_
     """gemm_nt_big8_kernel fetches the next tile's bias with an asm load the compiler knows nothing about (a plain load would
     make hipcc drain vmcnt at every tile seam); that is only sound while the compiled code leaves the destination registers alone
     until one of the kernel's own counted waits has retired the load -- the first `s_waitcnt vmcnt(6)` behind it (third k-tile
-    of the tile, phase 1) or the `vmcnt(0)` in front of the last tile's stores.  Checked on the ISA hipcc produces here."""
+    of the tile, phase 1) or the `vmcnt(0)` in front of the last tile's stores.  Checked on the ISA hipcc produces here: in the
+    text between the load and that wait the register is not named, and the control flow stays inside that text -- every branch in
+    it goes FORWARD to a label in front of the wait (the skipped `if (ok)` stores of the seam), so no path leaves the region, or
+    re-enters it from elsewhere, without passing the wait."""
     import shutil, subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -135,9 +138,20 @@ def test_persistent_gemm_never_touches_its_bias_registers_before_a_counted_wait_
     assert len(loads) == 4                                   # two per instantiation (C or C2 / both)
     for i in loads:
         reg = re.match(r"\s*global_load_dword (v\d+),", lines[i]).group(1)
-        for l in lines[i + 1:]:
+        region = None
+        for k, l in enumerate(lines[i + 1:], i + 1):
             if re.search(r"s_waitcnt vmcnt\((6|0)\)", l):
+                region = (i + 1, k)
                 break
             assert not re.search(r"\b%s\b" % reg, l), (reg, l)
-        else:
-            raise AssertionError("no wait behind the bias load")
+        assert region, "no wait behind the bias load"
+        labels = {m.group(1): k for k in range(*region) for m in [re.match(r"^(\.?\w+):", lines[k])] if m}
+        for k in range(*region):
+            m = re.match(r"\s*s_c?branch\w*\s+(\.?\w+)", lines[k])
+            if m:
+                assert m.group(1) in labels and labels[m.group(1)] > k, ("a branch leaves the region between the bias load and its wait", lines[k])
+        # nothing outside jumps into the region either
+        for name in labels:
+            for k, l in enumerate(lines):
+                if not (region[0] <= k < region[1]) and re.match(r"\s*s_c?branch\w*\s+%s\b" % re.escape(name), l):
+                    raise AssertionError(("a branch enters the region between the bias load and its wait", l))
