@@ -37,7 +37,10 @@
 #define CN_TH_STORE 1
 #endif
 #ifndef CN_POLL2
-#define CN_POLL2 1
+#define CN_POLL2 0      // round 4: two polls in flight measured 3-5 % SLOWER per step than one (A.5: every extra sample costs more than it finds)
+#endif
+#ifndef CN_POLL_SLEEP
+#define CN_POLL_SLEEP 1
 #endif
 #ifndef CN_POLL2_STAGGER
 #define CN_POLL2_STAGGER 4
@@ -49,6 +52,22 @@
 #include <mutex>
 
 #define KEEP_TUPLE(tuple, after) asm volatile("" :: "v"(tuple), "v"(after))
+
+// In-kernel segment timing of the delta-exchange backward kernel (tools/stamps_cl.py; `make variantc NAME=clstamp DEFS=-DCN_CL_STAMP`;
+// never defined in the shipped build): wave w of cluster 0, member 0 sums s_memtime deltas per step segment
+#ifdef CN_CL_STAMP
+__device__ unsigned long long cn_cl_stamp_buf[8][8];
+extern "C" int cn_dbg_read_stamps_cl(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_cl_stamp_buf), sizeof(cn_cl_stamp_buf)); }
+#define CLS_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CLS(i) { unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
+#define CLS_FORCE(x) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
+#define CLS_STORE if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) cn_cl_stamp_buf[threadIdx.x >> 6][i_] = st_acc[i_]; }
+#else
+#define CLS_DECL
+#define CLS(i)
+#define CLS_FORCE(x)
+#define CLS_STORE
+#endif
 
 namespace cn {
 
@@ -113,9 +132,50 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
         for (int i = 0; i < K; ++i) { ok = ok && (unsigned)(x[i] >> 32) == epoch; val[i] = (unsigned)x[i]; }
         if (ok) break;
         if (++spins > (1 << 21)) { *fault = 1; gaveup = true; break; }
-        __builtin_amdgcn_s_sleep(1);
+        if (CN_POLL_SLEEP) __builtin_amdgcn_s_sleep(CN_POLL_SLEEP);
     }
     }
+}
+
+// Round 4: the poll's OWN round trip was the largest segment of a step (in-kernel stamps, tools/stamps_cl.py: ~1000 of the 3400
+// cycles of a 2-CU backward step, ~1850 of 4800 in the 8-CU shape, although the partners' values had reached L2 long before the
+// first sample came back): a poll issued behind the own part of the product only starts its trip then.  The samples are
+// therefore taken at the TOP of the step -- the partners published at the end of their previous step, one hop (~270-320 ns,
+// tools/probe/hop_probe.cpp) before -- and looked at behind the own part; a thread whose early samples missed falls back to
+// the polling loop above.  Measured (variants of CN_EARLY_MASK / CN_POLL2, reading B per fraction): no early sample + two polls
+// in flight (rounds 2-3) 2.928 ms; no early sample, one poll 2.836; ONE early sample behind the stage copies + one poll 2.796;
+// at the top 2.837; behind the own part 2.841; two early samples 2.89; three 2.96: every extra sample costs more in L2 traffic
+// than it finds.  Shipped: one early sample for threads that wait for at most two granules (2-CU bf16), none otherwise
+// (split-bf16 4-CU: 5.01 ms without against 5.06 with; 8-CU: 7 / 14 granules per thread).
+#ifndef CN_EARLY_MASK
+#define CN_EARLY_MASK 2          // which of the three sample points of a step are taken (bit 0: top, 1: behind the stage copies, 2: behind the own part)
+#endif
+#ifndef CN_EARLY_MAXK
+#define CN_EARLY_MAXK 2          // ... by threads that wait for at most this many granules (2-CU bf16 shapes)
+#endif
+template <int K> struct EarlyPoll { static constexpr bool ON = K <= CN_EARLY_MAXK; u64 s[ON ? 3 : 1][ON ? K : 1]; };
+template <int N, int K>
+__device__ __forceinline__ void poll_early(const u64 *const (&slot)[K], EarlyPoll<K> &e)
+{
+    if constexpr (EarlyPoll<K>::ON && ((CN_EARLY_MASK >> N) & 1)) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) e.s[N][i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int K>
+__device__ __forceinline__ void poll_finish(const u64 *const (&slot)[K], unsigned epoch, int *fault, unsigned (&val)[K], bool &gaveup, const EarlyPoll<K> &e)
+{
+    if constexpr (EarlyPoll<K>::ON) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+            if (!((CN_EARLY_MASK >> n) & 1)) continue;
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < K; ++i) { ok = ok && (unsigned)(e.s[n][i] >> 32) == epoch; val[i] = (unsigned)e.s[n][i]; }
+            if (ok) return;
+        }
+    }
+    consume_all<K>(slot, epoch, fault, val, gaveup);
 }
 
 // two granules at once: both loads are in flight together (one L2 round trip instead of two when the data is there)
@@ -258,19 +318,28 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
                 }
             }
         };
-        product(std::integral_constant<int, 0>(), std::integral_constant<int, KCO>());
-        // y[t-1] of the partners' units: published at the end of their previous step, so its trip through L2 has been
-        // running beside the products above (it used to be waited for at the end of the step, on the critical path)
-        if (it > 0) {
-            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * NT);
-            // partner j = member + 1 + j (mod CS) sits in column block j + 1 of the member-relative tile
-            const u64 *slots[(CS - 1) * RPL];
-            unsigned vals[(CS - 1) * RPL];
+        // y[t-1] of the partners' units: published at the end of their previous step.  The samples are taken NOW (their round trip
+        // runs beside the own part of the product) and looked at behind it
+        // partner j = member + 1 + j (mod CS) sits in column block j + 1 of the member-relative tile
+        const u64 *slots[(CS - 1) * RPL];
+        EarlyPoll<(CS - 1) * RPL> early;
+        {
+            u64 *xprev = xbase + (long)((it + 1) & 1) * CS * (RPL * NT);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
                 for (int r = 0; r < RPL; ++r) slots[j * RPL + r] = xprev + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
-            consume_all<(CS - 1) * RPL>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
+        }
+        if (it > 0) poll_early<0>(slots, early);
+        product(std::integral_constant<int, 0>(), std::integral_constant<int, KCO / 2>());
+        if (it > 0) poll_early<1>(slots, early);
+        product(std::integral_constant<int, KCO / 2>(), std::integral_constant<int, KCO>());
+        if (it > 0) poll_early<2>(slots, early);
+        // (the scheduler must not pull the first look at the samples -- and with it the wait for them -- up in front of the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        if (it > 0) {
+            unsigned vals[(CS - 1) * RPL];
+            poll_finish<(CS - 1) * RPL>(slots, p.xch_epoch + it, p.fault, vals, gaveup, early);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -424,6 +493,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 
     const int tfirst = d ? 0 : T - 1;
     ClBwdPre<RPL> preA, preB;
+    CLS_DECL
     auto prefetch = [&](int t, ClBwdPre<RPL> &pre) {
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
         const int tprev = d ? t + 1 : t - 1;
@@ -451,6 +521,21 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         char *deltaT = (char *)p.delta_op + t * stepA * MELT;
         u64 *xslot = xbase + (long)(it & 1) * CS * (RPL * G * NT);
 
+        // the partners' deltas of the previous step: sampled first thing (EarlyPoll), looked at behind the own part of the product
+        const u64 *slots[(CS - 1) * RPL * G];
+        EarlyPoll<(CS - 1) * RPL * G> early;
+        {
+            u64 *xprev = xbase + (long)((it + 1) & 1) * CS * (RPL * G * NT);
+#pragma unroll
+            for (int j = 0; j < CS - 1; ++j)
+#pragma unroll
+                for (int r = 0; r < RPL; ++r) {
+                    const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * G * NT) + (r * G) * NT + tid;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) slots[(j * RPL + r) * G + i] = theirs + i * NT;
+                }
+        }
+        if (it > 0) poll_early<0>(slots, early);
         f32x4 acc, a_[RPL];
         [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
         [[maybe_unused]] f32x4 accs, acch;           // SP: the row-pair accumulator (KHS: first half) and the second half's
@@ -517,20 +602,19 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 #pragma unroll
             for (int r = 0; r < RPL; ++r) accs[2 * r] = acc[r];
         }
+        if (it > 0) poll_early<1>(slots, early);
+        CLS(0)
         product(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
-        if (it > 0) {      // the partners' deltas of the previous step
-            u64 *xprev = xbase + (long)((it - 1) & 1) * CS * (RPL * G * NT);
-            const u64 *slots[(CS - 1) * RPL * G];
+        if (it > 0) poll_early<2>(slots, early);
+#ifdef CN_CL_STAMP
+        if constexpr (SP) { CLS_FORCE(accs[0]) } else { CLS_FORCE(acc[0]) }
+#endif
+        CLS(1)
+        __builtin_amdgcn_sched_barrier(0);     // (the first look at the samples, and the wait for them, stays behind the MFMAs above)
+        if (it > 0) {      // the partners' deltas of the previous step (sampled at the top of the step, see EarlyPoll)
             unsigned vals[(CS - 1) * RPL * G];
-#pragma unroll
-            for (int j = 0; j < CS - 1; ++j)
-#pragma unroll
-                for (int r = 0; r < RPL; ++r) {
-                    const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * G * NT) + (r * G) * NT + tid;
-#pragma unroll
-                    for (int i = 0; i < G; ++i) slots[(j * RPL + r) * G + i] = theirs + i * NT;
-                }
-            consume_all<(CS - 1) * RPL * G>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
+            poll_finish<(CS - 1) * RPL * G>(slots, p.xch_epoch + it, p.fault, vals, gaveup, early);
+            CLS_FORCE(vals[0]) CLS(2)
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -554,9 +638,14 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                     } else *(uint2 *)dst = make_uint2(vals[(j * RPL + r) * 2], vals[(j * RPL + r) * 2 + 1]);
                 }
             lds_barrier();
+            CLS(3)
         }
         prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt), see the forward kernel
         product(std::integral_constant<int, 1>(), std::integral_constant<int, CS>());
+#ifdef CN_CL_STAMP
+        if constexpr (SP) { CLS_FORCE(accs[0]) } else { CLS_FORCE(acc[0]) }
+#endif
+        CLS(4)
         if constexpr (KQS) acc[0] = (accq[0][0] + accq[1][1]) + (accq[2][2] + accq[3][3]);
         if constexpr (KHS) acc[0] = (accs[0] + accs[1]) + (acch[2] + acch[3]);
         else if constexpr (SP) {
@@ -615,7 +704,9 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                 *(bf16x4 *)((__bf16 *)deltaT + oA[r]) = dv;
             }
         }
+        CLS(5)
         lds_barrier();
+        CLS(6)
     };
 
 #pragma unroll
@@ -623,10 +714,14 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     prefetch(tfirst, preA);
     prefetch(d ? 1 : T - 2, preB);
     lds_barrier();
+#ifdef CN_CL_STAMP
+    st_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < T; it += 2) {
         step(it, preA);
         if (it + 1 < T) step(it + 1, preB);
     }
+    CLS_STORE
 
     float v[7] = {sb[0], sb[1], sb[2], sb[3], spi, spf, spo};
 #pragma unroll
