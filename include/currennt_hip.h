@@ -242,6 +242,9 @@ int  cn_ctx_arm_update(cn_ctx *ctx, float learning_rate, float momentum);
  * of weightUpdates per layer on RCCL over xGMI, then the identical UpdateWeightFn on every rank keeps the replicas
  * bit-identical without a broadcast.  librccl is opened at run time (dlopen "librccl.so.1"; a process that already
  * holds one, e.g. through PyTorch, shares it); the library has no link-time dependency on it. */
+/* (Tests on a box with fewer GPUs than ranks: with CN_COMM_BACKEND=ipc in the environment the four entry points below keep their
+ * contract on a host-blocking TEST backend for ranks that share a device -- a shared-memory rendezvous named by the id, hipIpc
+ * staging buffers, sums in rank order (csrc/cn_comm_ipc.cpp).  Never a measurement.) */
 #define CN_COMM_ID_BYTES 128
 /* rank 0: a fresh rendezvous id (ncclGetUniqueId); hand its 128 bytes to every rank out of band (pipe, file, MPI, ...) */
 int  cn_comm_unique_id(char *id /* [CN_COMM_ID_BYTES] */);
