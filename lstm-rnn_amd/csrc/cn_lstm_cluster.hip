@@ -39,6 +39,9 @@
 #ifndef CN_POLL2
 #define CN_POLL2 0      // round 4: two polls in flight measured 3-5 % SLOWER per step than one (A.5: every extra sample costs more than it finds)
 #endif
+#ifndef CN_KHS_READ_AHEAD
+#define CN_KHS_READ_AHEAD 1
+#endif
 #ifndef CN_POLL_SLEEP
 #define CN_POLL_SLEEP 1
 #endif
@@ -549,7 +552,22 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         // the product over member parts [p0, p1) of K
         auto product = [&](auto p0_, auto p1_) {      // (compile-time bounds: wreg must stay in registers)
             constexpr int p0 = decltype(p0_)::value, p1 = decltype(p1_)::value;
-            if constexpr (KHS) {
+            if constexpr (KHS && !X3 && CN_KHS_READ_AHEAD) {
+                // all operand reads of the parts first, then the MFMAs: left to hipcc each MFMA pair waited for its own read (second part
+                // of the product in the 8-CU shape: 1 290 cycles for 28 MFMAs; long utterances 36.6 -> 35.4 ms per fraction).  The same
+                // in the forward kernel and in the 2-CU backward kernel measured nothing and was not kept.
+                constexpr int KH = KCO / 2, NR = (p1 - p0) * KH;
+                u32x4 a[NR];
+#pragma unroll
+                for (int j = 0; j < NR; ++j) a[j] = *(const u32x4 *)(dcur + c * pitch + (p0 * KH + j) * 64 + q * 16);
+#pragma unroll
+                for (int pp = p0; pp < p1; ++pp)
+#pragma unroll
+                    for (int kq = 0; kq < KH; ++kq) {
+                        smma16(accs, a[(pp - p0) * KH + kq], wsp[pp * KCO + kq], spidx);
+                        smma16(acch, a[(pp - p0) * KH + kq], wsp[pp * KCO + KH + kq], spidx);
+                    }
+            } else if constexpr (KHS) {
                 constexpr int KH = KCO / 2;
 #pragma unroll
                 for (int pp = p0; pp < p1; ++pp)
