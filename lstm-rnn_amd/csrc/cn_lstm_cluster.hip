@@ -59,8 +59,10 @@
 // In-kernel segment timing of the delta-exchange backward kernel (tools/stamps_cl.py; `make variantc NAME=clstamp DEFS=-DCN_CL_STAMP`;
 // never defined in the shipped build): wave w of cluster 0, member 0 sums s_memtime deltas per step segment
 #ifdef CN_CL_STAMP
-__device__ unsigned long long cn_cl_stamp_buf[8][8];
+__device__ unsigned long long cn_cl_stamp_buf[8][8], cn_cl_stamp_buf_f[8][8];
 extern "C" int cn_dbg_read_stamps_cl(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_cl_stamp_buf), sizeof(cn_cl_stamp_buf)); }
+extern "C" int cn_dbg_read_stamps_cl_fwd(unsigned long long *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_cl_stamp_buf_f), sizeof(cn_cl_stamp_buf_f)); }
+#define CLS_STORE_F if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) cn_cl_stamp_buf_f[threadIdx.x >> 6][i_] = st_acc[i_]; }
 #define CLS_DECL unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define CLS(i) { unsigned long long st_now = __builtin_amdgcn_s_memtime(); st_acc[i] += st_now - st_prev; st_prev = st_now; }
 #define CLS_FORCE(x) asm volatile("v_mov_b32 %0, %0" : "+v"(x));
@@ -70,6 +72,7 @@ extern "C" int cn_dbg_read_stamps_cl(unsigned long long *host) { return (int)hip
 #define CLS(i)
 #define CLS_FORCE(x)
 #define CLS_STORE
+#define CLS_STORE_F
 #endif
 
 namespace cn {
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 
     f32x4 preA[RPL], preB[RPL];
     char ptA[RPL], ptB[RPL];
+    CLS_DECL
     auto prefetch = [&](int t, f32x4 (&pre)[RPL], char (&pt)[RPL]) {
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
         const float *actsT = p.acts + t * stepA;
@@ -334,15 +338,18 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
                 for (int r = 0; r < RPL; ++r) slots[j * RPL + r] = xprev + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
         }
         if (it > 0) poll_early<0>(slots, early);
+        CLS(0)
         product(std::integral_constant<int, 0>(), std::integral_constant<int, KCO / 2>());
         if (it > 0) poll_early<1>(slots, early);
         product(std::integral_constant<int, KCO / 2>(), std::integral_constant<int, KCO>());
         if (it > 0) poll_early<2>(slots, early);
+        CLS_FORCE(acc[3][0]) CLS(1)
         // (the scheduler must not pull the first look at the samples -- and with it the wait for them -- up in front of the MFMAs)
         __builtin_amdgcn_sched_barrier(0);
         if (it > 0) {
             unsigned vals[(CS - 1) * RPL];
             poll_finish<(CS - 1) * RPL>(slots, p.xch_epoch + it, p.fault, vals, gaveup, early);
+            CLS_FORCE(vals[0]) CLS(2)
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j)
 #pragma unroll
@@ -356,10 +363,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
                     } else *(unsigned short *)dst = (unsigned short)vals[j * RPL + r];
                 }
             lds_barrier();
+            CLS(3)
         }
         // (the poll above drains vmcnt: the prefetch is issued behind it so that it has a whole step to land)
         prefetch(d ? t - 2 : t + 2, pre, pt);
         product(std::integral_constant<int, KCO>(), std::integral_constant<int, KC>());
+        CLS_FORCE(acc[3][0]) CLS(4)
 
 #pragma unroll
         for (int r = 0; r < RPL; ++r) {
@@ -397,16 +406,22 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
             thT[oC[r]] = th;                                 // for the backward pass (cn_lstm.hip)
             if constexpr (X3) ((float *)yT)[oC[r]] = yo; else ((__bf16 *)yT)[oC[r]] = yb;
         }
+        CLS(5)
         lds_barrier();
+        CLS(6)
     };
 
     prefetch(d ? T - 1 : 0, preA, ptA);
     prefetch(d ? T - 2 : 1, preB, ptB);
     lds_barrier();
+#ifdef CN_CL_STAMP
+    st_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int it = 0; it < T; it += 2) {
         step(it, preA, ptA);
         if (it + 1 < T) step(it + 1, preB, ptB);
     }
+    CLS_STORE_F
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -34,4 +34,12 @@ print("ticks of s_memtime per step by segment (rows = waves of workgroup 0), tot
 for w in range(8):
     if a[w].sum() > 0:
         print("  wave %d  " % w + "  ".join("%7.1f" % v for v in a[w, :7]) + "   | %8.1f" % a[w, :7].sum())
+if hasattr(lib, "cn_dbg_read_stamps_cl_fwd"):
+    lib.cn_dbg_read_stamps_cl_fwd.argtypes = [C.c_void_p]
+    assert lib.cn_dbg_read_stamps_cl_fwd(buf) == 0
+    a = np.array(buf, np.float64).reshape(8, 8) / T
+    print("forward cluster kernel (segments: 0 top, 1 own part done, 2 polled, 3 LDS write + barrier, 4 partners' parts done, 5 cell update + publish + stores, 6 barrier):")
+    for w in range(8):
+        if a[w].sum() > 0:
+            print("  wave %d  " % w + "  ".join("%7.1f" % v for v in a[w, :7]) + "   | %8.1f" % a[w, :7].sum())
 net.close()
