@@ -176,3 +176,26 @@ def test_partial_sum_exchange_backward_clusters_in_bf16(pkg, orc, monkeypatch, s
     frac = pkg.make_fraction(xs, ts, PS)
     fwd = "lstm_fwd_cluster_kernel<0,256,128,1>" if size == 500 else "lstm_fwd_cluster_kernel<0,512,64,1>"
     check_pinned(pkg, orc, layers, weights, frac, PS, kernels=(fwd, kernel))
+
+
+@pytest.mark.parametrize("case", ["configs0_lstm128", "blstm128_Hp64", "blstm250_PS600_rpl", "blstm192_Hp96"])
+def test_other_bf16_kernel_families(pkg, orc, case):
+    """The bf16 kernels outside the headline shapes against the bf16-operand oracle: BASELINE configs[0] (39 -> lstm128 ->
+    softmax183, unidirectional, the hand-written loops with one direction), Hp = 64 (the compiled kernels of the two-sequences
+    cut), PS = 600 (more sequence pairs than CUs: the 4-sequence kernels with several sequences per lane), Hp = 96 (six-wave
+    register-resident kernels)."""
+    rng = np.random.RandomState(80 + len(case))
+    P, C = 39, 183
+    hidden, PS, T, kern = {
+        "configs0_lstm128": ([("lstm", 128)], 50, 60, ("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel")),
+        "blstm128_Hp64": ([("blstm", 128)] * 2, 50, 40, ("lstm_fwd_s2_kernel<0,64>", "lstm_bwd_s2_kernel<0,64>")),
+        "blstm250_PS600_rpl": ([("blstm", 250)], 600, 12, None),
+        "blstm192_Hp96": ([("blstm", 192)] * 2, 20, 30, None),
+    }[case]
+    layers = net_desc(P, hidden, C)
+    weights = random_weights(layers, rng, 0.1)
+    lengths = sorted([T] + rng.randint(max(1, T // 2), T + 1, PS - 2).tolist(), reverse=True)
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=kern)
+    print("bf16 pinned,", case, {k: float("%.3g" % v) for k, v in rep.items()})
