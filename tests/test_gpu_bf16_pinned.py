@@ -199,3 +199,23 @@ def test_other_bf16_kernel_families(pkg, orc, case):
     frac = pkg.make_fraction(xs, ts, PS)
     rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=kern)
     print("bf16 pinned,", case, {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+def test_peaked_posteriors(pkg, orc):
+    """With untrained weights every posterior is ~1/183 and the absolute bound above is easy; here the output layer's weights are
+    scaled up (+-5) until the largest posteriors pass 0.3.  A flipped bf16 output of the last LSTM layer (2^-9 |y|) then moves a
+    logit by ~1e-3, i.e. a posterior p by ~1e-3 p (1 - p): the bound for this case is 2e-3; bench.py's parity_vs_cpu reports the
+    same comparison at the weights 40 training updates reach (largest posterior 0.88: 5e-4).  Gradients as before."""
+    rng = np.random.RandomState(99)
+    P, C, PS = 39, 183, 50
+    layers = net_desc(P, [("blstm", 250)] * 2, C)
+    weights = random_weights(layers, rng, 0.1)
+    weights["output"]["input"] = (weights["output"]["input"] * 50.0).astype(np.float32)
+    xs, ts = random_sequences(rng, sorted(rng.randint(40, 61, PS).tolist(), reverse=True), P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel"), post_tol=2e-3)
+    print("bf16 pinned, peaked:", {k: float("%.3g" % v) for k, v in rep.items()})
+    with orc.operand_rounding("bf16"):
+        ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+        ref.load_sequences(frac); ref.compute_forward_pass()
+        assert ref.outputs().reshape(-1, C)[real_mask(frac)].max() > 0.3           # (the case is what it says)
