@@ -284,6 +284,7 @@ def main():
         raise SystemExit("bench.py: precision %s is not built into this library" % args.precision)
     use_comm = world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1"
     flat_exchange = os.environ.get("CN_BENCH_FLAT_ALLREDUCE") == "1"
+    prefetch = os.environ.get("CN_BENCH_NO_PREFETCH") != "1"   # A/B switch: the next fraction's re-layout on the main stream
     armed = os.environ.get("CN_BENCH_NO_ARM") != "1"       # A/B switch: the update of all layers behind the last backward kernel
     # The gradient exchange is the library's own RCCL communicator (cn_comm_init / cn_allreduce_grads); torch.distributed
     # carries the control plane only (rendezvous id, barrier, max-over-ranks timing).  CN_BENCH_BACKEND=gloo swaps in the
@@ -351,6 +352,8 @@ def main():
                 net.load_sequences_resident(f)
             net.compute_forward_pass()
             net.loss_accumulate()
+            if prefetch and not from_host:
+                net.prefetch_sequences_resident(dfr[(i + 1) % nfrac])   # the next step's re-layout, beside this backward pass
             # every layer's momentum-SGD step behind its own gradient (cn_ctx_arm_update; with the library's communicator: behind
             # its all-reduce); the torch test double reduces outside the library, so it keeps the update behind the whole pass
             if armed and (not use_comm or (native_comm and not flat_exchange)):

@@ -173,6 +173,16 @@ int  cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const
  * device-to-device on the ctx stream; nothing synchronises. */
 int  cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
 
+/* Announces the fraction the NEXT cn_fraction_load_resident will load (same descriptor, same layers).  The library
+ * re-lays it out into a second set of buffers on the side stream of the next gradient work -- beside the backward
+ * pass of the current fraction -- and that load then only exchanges the buffers (no kernel, nothing on the critical
+ * path).  Purely a hint: a load of any other fraction, a host-buffer load, or a backward pass that put nothing on
+ * the side stream simply discards it and loads the ordinary way.  The device buffers of `fraction` must stay
+ * unchanged until that load.  cn_layer_device_ptr(input, CN_BUF_OUTPUTS) changes with the exchange.  CN_ERR_STATE
+ * when a prefetch that is already in flight has not been consumed.  The reference has no counterpart (its loader
+ * thread prefetches HOST fractions, DataSet.cpp:546-552; Layer::loadSequences copies synchronously).   [async] */
+int  cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
+
 /* Layer::computeForwardPass / computeBackwardPass (Layer.hpp:165-170).  Backward of a trainable
  * layer consumes its outputErrors, writes the preceding trainable layer's outputErrors
  * (LstmLayer.cu:990-1009, FeedForwardLayer.cu:188-198) and its own weightUpdates. */

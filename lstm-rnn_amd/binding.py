@@ -30,7 +30,7 @@ BUF = {
 EXPORTS = [
     "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_ctx_join", "cn_layer_join", "cn_layer_join_stream", "cn_ctx_stream", "cn_last_error", "cn_device_arch", "cn_device_count", "cn_device_name",
     "cn_version", "cn_layer_create", "cn_layer_destroy", "cn_layer_size", "cn_layer_kind_of",
-    "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_layer_forward",
+    "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_fraction_prefetch_resident", "cn_layer_forward",
     "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_arm_update", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
@@ -107,6 +107,7 @@ def load_library():
     L.cn_layer_weight_count.argtypes = [vp]
     L.cn_fraction_load.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_fraction_load_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
+    L.cn_fraction_prefetch_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_loss_accumulate.argtypes = [vp]
     L.cn_loss_read.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_layer_forward.argtypes = [vp]

@@ -103,6 +103,15 @@ struct cn_ctx {
     bool stage_used[2] = {false, false};
     unsigned upload_idx = 0;
 
+    // cn_fraction_prefetch_resident: the announced fraction is re-laid out into the alternate buffers on the side stream of
+    // the next gradient work (beside the backward pass); the load that follows swaps the buffers instead of running the kernel
+    struct Prefetch {
+        bool valid = false, launched = false;
+        cn_fraction f{}; cn_layer *input = nullptr, *post = nullptr;
+        char *pat = nullptr, *pat_raw = nullptr; int *tcls = nullptr; void *in_op = nullptr; float *targets = nullptr;   // alternates
+        bool allocated = false;
+    } pf;
+
     // data-parallel training: RCCL communicator of this rank, its stream and the newest reduction's event
     ncclComm_t comm = nullptr;
     IpcComm *ipc = nullptr;                    // CN_COMM_BACKEND=ipc: the test backend (cn_comm_ipc.cpp) in place of RCCL
@@ -331,6 +340,20 @@ void require_comm(cn_ctx *c, const char *who)
 {
     if (!c->has_comm()) throw cn_error(CN_ERR_STATE, std::string(who) + ": no communicator bound to this context (call cn_comm_init first)");
 }
+// cn_fraction_prefetch_resident: the re-layout of the announced fraction, into the alternate buffers
+void launch_prefetch(cn_ctx *c, hipStream_t st)
+{
+    cn_ctx::Prefetch &p = c->pf;
+    const cn_fraction &f = p.f;
+    const bool cls = p.post && (p.post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || p.post->kind == CN_LAYER_BINARY_CLASSIFICATION);
+    launch_fraction_load(st, c->f32, f.max_seq_length, c->PS, c->PSp, (const char *)f.pat_types, p.pat,
+                         cls ? (const int *)f.target_classes : nullptr, p.tcls,
+                         (p.post && !cls) ? (const float *)f.targets : nullptr, p.post ? p.targets : nullptr,
+                         p.post ? p.post->size : 0, (const float *)f.inputs, p.input->size, p.in_op, p.input->Lp);
+    if (p.post && p.post->kind == CN_LAYER_BINARY_CLASSIFICATION)
+        launch_classes_to_targets(st, p.tcls, p.targets, f.max_seq_length * c->PSp);
+    p.launched = true;
+}
 // run `f(stream)` on the side stream after everything enqueued on the main stream so far
 // (fork_attached: ev_fork already completes with the last main-stream kernel, see fork_event)
 template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = false)
@@ -358,6 +381,7 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     }
     hipStream_t st = slow ? c->side_slow : c->side;
     HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
+    if (c->pf.valid && !c->pf.launched) launch_prefetch(c, st);      // covered by this layer's join event (same stream, in order)
     // the join event rides on the last kernel of the side work too (f returns true when it attached it)
     const bool join_attached = f(st, (c->attach_forks && !c->timing) ? l->ev_join : nullptr);
     if (!join_attached) HIP_CHECK(hipEventRecord(l->ev_join, st));
@@ -821,6 +845,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
+        hipFree(ctx->pf.pat_raw); hipFree(ctx->pf.tcls);
         hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -1166,27 +1191,38 @@ int cn_layer_weight_count(const cn_layer *layer) { return layer ? layer->nw : CN
 // ---------------------------------------------------------------------------------------------
 // fraction
 // ---------------------------------------------------------------------------------------------
+static void check_fraction(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    if (input->kind != CN_LAYER_INPUT) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `input` is not an input layer");
+    if (f->input_pattern_size != input->size)                                                     // InputLayer.cpp:52-55
+        throw cn_error(CN_ERR_SHAPE, "Input layer size of " + std::to_string(input->size) +
+                       " != data input pattern size of " + std::to_string(f->input_pattern_size));
+    if (post_output) {
+        if (!post_output->post) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `post_output` is not a post output layer");
+        if (f->output_pattern_size != post_output->size)                                          // PostOutputLayer.cpp:70-73
+            throw cn_error(CN_ERR_SHAPE, "Output layer size of " + std::to_string(post_output->size) +
+                           " != data target pattern size of " + std::to_string(f->output_pattern_size));
+    }
+    const int T = f->max_seq_length;
+    if (T <= 0 || T > ctx->maxT) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: max_seq_length " + std::to_string(T) +
+                                                " outside (0, " + std::to_string(ctx->maxT) + "]");
+    if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
+    if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
+}
+static bool same_fraction(const cn_fraction &a, const cn_fraction &b)
+{
+    return a.max_seq_length == b.max_seq_length && a.min_seq_length == b.min_seq_length && a.num_sequences == b.num_sequences &&
+           a.input_pattern_size == b.input_pattern_size && a.output_pattern_size == b.output_pattern_size &&
+           a.pat_types == b.pat_types && a.inputs == b.inputs && a.target_classes == b.target_classes && a.targets == b.targets;
+}
 static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f, bool resident)
 {
     if (!ctx || !input || !f) { g_last_error = "cn_fraction_load: NULL argument"; return CN_ERR_BAD_ARG; }
     const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     return guarded([&] {
         HIP_CHECK(hipSetDevice(ctx->device));
-        if (input->kind != CN_LAYER_INPUT) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `input` is not an input layer");
-        if (f->input_pattern_size != input->size)                                                     // InputLayer.cpp:52-55
-            throw cn_error(CN_ERR_SHAPE, "Input layer size of " + std::to_string(input->size) +
-                           " != data input pattern size of " + std::to_string(f->input_pattern_size));
-        if (post_output) {
-            if (!post_output->post) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: `post_output` is not a post output layer");
-            if (f->output_pattern_size != post_output->size)                                          // PostOutputLayer.cpp:70-73
-                throw cn_error(CN_ERR_SHAPE, "Output layer size of " + std::to_string(post_output->size) +
-                               " != data target pattern size of " + std::to_string(f->output_pattern_size));
-        }
+        check_fraction(ctx, input, post_output, f);
         const int T = f->max_seq_length;
-        if (T <= 0 || T > ctx->maxT) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: max_seq_length " + std::to_string(T) +
-                                                    " outside (0, " + std::to_string(ctx->maxT) + "]");
-        if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
-        if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
         finalize(ctx);
         join_side(ctx);                      // gradient GEMMs of the previous fraction still read the activations
         flush_loss(ctx);                     // (a deferred loss sum counts the rows of the fraction that is being replaced)
@@ -1197,16 +1233,28 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
             if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
             if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
+            cn_ctx::Prefetch &pf = ctx->pf;
+            const bool hit = pf.valid && pf.launched && pf.input == input && pf.post == post_output && same_fraction(pf.f, *f);
+            pf.valid = false;          // a prefetch serves the very next load or nothing
+            if (hit) {
+                // the side stream has re-laid this fraction out already (join_side above ordered this stream behind it): the
+                // alternate buffers become the current ones
+                std::swap(ctx->d_pat, pf.pat); std::swap(ctx->d_pat_raw, pf.pat_raw); std::swap(ctx->d_tcls, pf.tcls);
+                std::swap(input->out_op, pf.in_op);
+                if (post_output && post_output->targets) std::swap(post_output->targets, pf.targets);
+            } else {
             launch_fraction_load(ctx->stream, ctx->f32, T, (int)PS, (int)PSp, f->pat_types, ctx->d_pat,
                                  cls ? f->target_classes : nullptr, ctx->d_tcls,
                                  (post_output && !cls) ? f->targets : nullptr, post_output ? post_output->targets : nullptr,
                                  post_output ? post_output->size : 0, f->inputs, input->size, input->out_op, input->Lp);
             if (post_output && post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
                 launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
+            }
             ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
             ctx->loaded = true;
             return;
         }
+        ctx->pf.valid = false;
         if (ctx->overlap) {
             // Host buffers: pack [patTypes | classes or targets | inputs] into pinned memory, ONE contiguous upload
             // on the copy stream (it runs while the previous fraction still computes: the staging areas alternate),
@@ -1291,6 +1339,32 @@ int cn_fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const 
 int cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
 {
     return fraction_load(ctx, input, post_output, f, true);
+}
+int cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    if (!ctx || !input || !f) { g_last_error = "cn_fraction_prefetch_resident: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        check_fraction(ctx, input, post_output, f);
+        const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
+        if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_prefetch_resident: target_classes missing");
+        if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_prefetch_resident: targets missing");
+        cn_ctx::Prefetch &pf = ctx->pf;
+        if (pf.valid && pf.launched) throw cn_error(CN_ERR_STATE, "cn_fraction_prefetch_resident: the previous prefetch has not been consumed by a cn_fraction_load_resident yet");
+        if (!pf.allocated) {          // the alternates of the four buffers a fraction is re-laid out into (same initial contents)
+            const size_t maxN = input->maxN(), guard = (size_t)CN_GUARD_STEPS * ctx->PSp;
+            HIP_CHECK(hipMalloc((void **)&pf.pat_raw, maxN + 2 * guard));
+            HIP_CHECK(hipMemsetAsync(pf.pat_raw, 0, maxN + 2 * guard, ctx->stream));
+            pf.pat = pf.pat_raw + guard;
+            HIP_CHECK(hipMalloc((void **)&pf.tcls, maxN * sizeof(int)));
+            HIP_CHECK(hipMemsetAsync(pf.tcls, 0xFF, maxN * sizeof(int), ctx->stream));
+            pf.in_op = dalloc(input, maxN * input->Lp * ctx->esz());
+            if (post_output && post_output->targets) pf.targets = (float *)dalloc(post_output, maxN * post_output->size * sizeof(float));
+            pf.allocated = true;
+        }
+        if (post_output && post_output->targets && !pf.targets) pf.targets = (float *)dalloc(post_output, input->maxN() * post_output->size * sizeof(float));
+        pf.f = *f; pf.input = input; pf.post = post_output; pf.launched = false; pf.valid = true;
+    });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -210,9 +210,7 @@ class NeuralNetwork:
         self.T, self.Tmin = f.max_seq_length, f.min_seq_length
         self.N = self.T * self.PS
 
-    def load_sequences_resident(self, dfrac):
-        """Like load_sequences, but `dfrac` holds DEVICE pointers (ints) for inputs / patTypes /
-        targetClasses / targets: the fraction is already resident in HBM."""
+    def _resident_descriptor(self, dfrac):
         f = B.Fraction()
         f.max_seq_length, f.min_seq_length = int(dfrac["T"]), int(dfrac["Tmin"])
         f.num_sequences = int(dfrac.get("numSeqs", self.PS))
@@ -220,6 +218,19 @@ class NeuralNetwork:
         f.output_pattern_size = int(dfrac.get("outputPatternSize", self.layers[-1].size))
         f.pat_types, f.inputs = dfrac["patTypes"], dfrac["inputs"]
         f.target_classes, f.targets = dfrac.get("targetClasses"), dfrac.get("targets")
+        return f
+
+    def prefetch_sequences_resident(self, dfrac):
+        """cn_fraction_prefetch_resident: `dfrac` is what the next load_sequences_resident will load; it is re-laid out
+        beside the coming backward pass."""
+        f = self._resident_descriptor(dfrac)
+        B.check(self.lib.cn_fraction_prefetch_resident(self.ctx, self.layers[0].handle, self.layers[-1].handle,
+                                                       C.byref(f)), self.ctx)
+
+    def load_sequences_resident(self, dfrac):
+        """Like load_sequences, but `dfrac` holds DEVICE pointers (ints) for inputs / patTypes /
+        targetClasses / targets: the fraction is already resident in HBM."""
+        f = self._resident_descriptor(dfrac)
         B.check(self.lib.cn_fraction_load_resident(self.ctx, self.layers[0].handle, self.layers[-1].handle,
                                                    C.byref(f)), self.ctx)
         self.T, self.Tmin = f.max_seq_length, f.min_seq_length

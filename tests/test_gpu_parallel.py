@@ -331,3 +331,55 @@ def test_resident_fraction_load_matches_host_load(pkg, post):
     assert np.array_equal(res["host"][0], res["resident"][0]) and res["host"][1] == res["resident"][1] and res["host"][2] == res["resident"][2]
     for a, b in zip(res["host"][3], res["resident"][3]):
         assert np.abs(a - b).max() <= 1e-5 * max(1.0, np.abs(a).max())
+
+
+@pytest.mark.parametrize("post", ["multiclass_classification", "sse", "binary_classification"])
+def test_prefetched_resident_fraction_equals_plain_load(pkg, post):
+    """cn_fraction_prefetch_resident: the next fraction is re-laid out on the side stream beside the backward pass and the load
+    only exchanges buffers.  Six training steps over three fractions of different lengths (the alternates hold stale rows of other
+    fractions) must give the same outputs and errors per step and the same weights as loads without the hint; a load of ANOTHER
+    fraction than the announced one discards the hint; a second announcement while one is in flight is CN_ERR_STATE."""
+    import torch
+    rng = np.random.RandomState(31)
+    P, PS = 5, 6
+    C = 1 if post == "binary_classification" else 4
+    layers = net_desc(P, [("blstm", 12), ("lstm", 8)], C, post=post)
+    if post == "binary_classification":
+        layers[-2]["type"] = "feedforward_logistic"
+    weights = random_weights(layers, rng, 0.4)
+    fracs, keep = [], []
+    for lens in ([9, 7, 4, 6, 9], [5, 5, 3], [8, 8, 8, 8, 2, 1]):
+        if post == "sse":
+            xs, ts = random_sequences(rng, lens, P, L=C)
+            fr = pkg.make_fraction(xs, ts, PS, classification=False)
+        else:
+            xs, ts = random_sequences(rng, lens, P, C=max(C, 2))
+            fr = pkg.make_fraction(xs, ts, PS)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).cuda() for k in ("inputs", "patTypes", "targetClasses", "targets") if k in fr and fr[k] is not None}
+        keep.append(dev)
+        d = {"T": fr["T"], "Tmin": fr["Tmin"], "numSeqs": fr["numSeqs"], "inputPatternSize": P, "outputPatternSize": C}
+        d.update({k: v.data_ptr() for k, v in dev.items()})
+        fracs.append(d)
+    order = [0, 1, 2, 0, 2, 1]
+    res = {}
+    for mode in ("plain", "prefetch", "wrong_hint"):
+        with pkg.NeuralNetwork(layers, weights, PS, 9, precision=pkg.PREC_F32) as net:
+            trace = []
+            for i, k in enumerate(order):
+                net.load_sequences_resident(fracs[k])
+                net.compute_forward_pass()
+                e, c = net.error_and_correct()
+                trace.append((net.outputs().copy(), e, c))
+                if mode != "plain" and i + 1 < len(order):
+                    nxt = order[i + 1] if mode == "prefetch" else (order[i + 1] + 1) % 3
+                    net.prefetch_sequences_resident(fracs[nxt])
+                net.compute_backward_pass()
+                if mode == "prefetch" and i == 0:
+                    with pytest.raises(pkg.CurrenntHipError, match="has not been consumed"):
+                        net.prefetch_sequences_resident(fracs[0])
+                net.update_weights_fused(1e-2, 0.9)
+            res[mode] = (trace, np.concatenate([l.weights() for l in net.trainable_layers()]))
+    for mode in ("prefetch", "wrong_hint"):
+        for (o, e, c), (o0, e0, c0) in zip(res[mode][0], res["plain"][0]):
+            assert np.abs(o - o0).max() < 1e-5 and abs(e - e0) <= 1e-4 * max(1.0, abs(e0)) and c == c0, mode
+        assert np.abs(res[mode][1] - res["plain"][1]).max() < 1e-5, mode
