@@ -178,7 +178,7 @@ int  cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_outp
  * pass of the current fraction -- and that load then only exchanges the buffers (no kernel, nothing on the critical
  * path).  Purely a hint: a load of any other fraction, a host-buffer load, or a backward pass that put nothing on
  * the side stream simply discards it and loads the ordinary way.  The device buffers of `fraction` must stay
- * unchanged until that load.  cn_layer_device_ptr(input, CN_BUF_OUTPUTS) changes with the exchange.  CN_ERR_STATE
+ * unchanged until that load.  CN_ERR_STATE
  * when a prefetch that is already in flight has not been consumed.  The reference has no counterpart (its loader
  * thread prefetches HOST fractions, DataSet.cpp:546-552; Layer::loadSequences copies synchronously).   [async] */
 int  cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);

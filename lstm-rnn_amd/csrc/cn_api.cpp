@@ -152,6 +152,12 @@ struct cn_layer {
     int PS = 0, PSp = 0, maxT = 0;
     bool trainable = false, post = false, lstm = false, has_follower = false;
     bool mcc_pending = false;             // softmax layer: multiclass error injection deferred into the fused backward kernel
+    // wide softmax layer (softmax_fwd_can_be_lazy): the forward pass may leave the LOGITS in out_f32 and {offset, sum} per row in
+    // sm_stat; the fused backward kernel recomputes the posteriors from them, anybody else gets them through posteriors()
+    float *sm_stat = nullptr;
+    bool sm_lazy = false;                 // out_f32 holds logits right now
+    bool sm_lazy_next = true;             // the last forward pass's posteriors were only consumed by the fused backward kernel
+    bool sm_read = false;                 // somebody else looked at them since the forward pass
 
     int dirs = 1, H = 0, Hp = 0;          // lstm geometry
     int Lp = 0;                           // padded output width (row stride of out/err)
@@ -258,6 +264,24 @@ struct Timed {
         if (a) { hipEvent_t b = get_event(c); hipEventRecord(b, st); c->spans[cls].push_back({a, b}); }
     }
 };
+
+// wide softmax rows of the bf16 throughput mode: v_exp_f32 + one reciprocal per row (cn_elementwise.hip, softmax_exp<FAST>)
+bool softmax_fast(cn_ctx *c)
+{
+    static const bool exact = getenv("CN_SOFTMAX_EXACT") != nullptr;      // A/B switch
+    return c->prec == P_BF16 && !exact;
+}
+// fp32 outputs of a feed-forward / softmax layer for a reader other than the fused softmax backward kernel
+float *posteriors(cn_layer *o)
+{
+    cn_ctx *c = o->ctx;
+    o->sm_read = true;
+    if (o->sm_lazy) {
+        launch_softmax_normalise(c->stream, softmax_fast(c), o->out_f32, c->d_pat, c->N, o->size, o->Lp, o->sm_stat);
+        o->sm_lazy = false;
+    }
+    return o->out_f32;
+}
 
 // the main stream waits for everything the side stream still has in flight
 void join_side(cn_ctx *c)
@@ -678,7 +702,17 @@ void ff_forward(cn_layer *l)
         flush_loss(c);                         // (the row statistics are about to be overwritten)
         Timed tm(c, KC_OTHER);
         const bool stat = c->d_rowstat != nullptr;
-        launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp, stat ? c->d_tcls : nullptr, stat ? c->d_rowstat : nullptr);
+        // wide rows in training: the posteriors are only ever read by the fused backward kernel, which can recompute them from the
+        // logits -- 1.1 GB less to write per fraction of the 8000-class output layer.  A layer whose posteriors were asked for after
+        // its last forward pass (forward-only use, another loss than multiclass) runs the eager kernel.  Only where recomputing is
+        // cheap (softmax_fast): with expf and a division per element the two lazy passes take longer than the eager ones
+        // (probe/softmax_bench: 363 + 633 against 454 + 427 us).
+        const bool lazy_off = getenv("CN_NO_LAZY_SOFTMAX") != nullptr;           // (read per pass: tests switch them)
+        const bool lazy_force = getenv("CN_LAZY_SOFTMAX") != nullptr;            // the exact lazy kernels
+        l->sm_lazy = stat && l->sm_stat && l->sm_lazy_next && !l->has_follower && !lazy_off && (softmax_fast(c) || lazy_force);
+        l->sm_read = false;
+        launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp, stat ? c->d_tcls : nullptr, stat ? c->d_rowstat : nullptr,
+                           softmax_fast(c), l->sm_lazy ? l->sm_stat : nullptr);
         c->rowstat_of = stat ? l : nullptr;
         if (!c->f32 && l->has_follower) launch_pad_convert(c->stream, false, l->out_f32, c->N, l->Lp, l->out_op, l->Lp);
     }
@@ -695,14 +729,17 @@ void ff_backward(cn_layer *l)
             // bf16 mode: the fp32 outputErrors stay unwritten (read back from the bf16 operand copy if anyone asks)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
-                                   with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6);
+                                   with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6, l->sm_lazy ? l->sm_stat : nullptr,
+                                   softmax_fast(c));
+            l->sm_lazy_next = !l->sm_read;
             if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
         } else {
             l->err_in_delta = false;
-            if (l->mcc_pending) launch_mcc_backward(c->stream, l->out_f32, c->d_tcls, N, l->size, l->Lp, l->err);
-            if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, l->out_f32, l->err, c->d_pat, N, l->size, l->Lp);
-            launch_ff_delta(c->stream, c->f32, ff_act(l->kind), l->out_f32, l->err, l->delta_op, N, l->size, l->Lp);
+            const float *y = posteriors(l);
+            if (l->mcc_pending) launch_mcc_backward(c->stream, y, c->d_tcls, N, l->size, l->Lp, l->err);
+            if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, y, l->err, c->d_pat, N, l->size, l->Lp);
+            launch_ff_delta(c->stream, c->f32, ff_act(l->kind), y, l->err, l->delta_op, N, l->size, l->Lp);
             launch_colsum(c->stream, l->err, N, l->Lp, l->dbias);
         }
         l->mcc_pending = false;
@@ -1126,6 +1163,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->grad_block_floats = (size_t)l->Lp * l->Pp + l->Lp;
             l->grad_block = (float *)dalloc(l, l->grad_block_floats * sizeof(float));
             l->dWin = l->grad_block; l->dbias = l->dWin + (size_t)l->Lp * l->Pp;
+            if (kind == CN_LAYER_SOFTMAX && softmax_fwd_can_be_lazy(size)) l->sm_stat = (float *)dalloc(l, maxN * 2 * sizeof(float));
             break; }
         case CN_LAYER_SSE:
         case CN_LAYER_WEIGHTEDSSE:
@@ -1414,7 +1452,7 @@ int cn_layer_backward(cn_layer *layer)
             if (layer->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
                 o->mcc_pending = true;         // injected inside the output layer's backward pass (fused kernel)
             else
-                launch_post_backward(c->stream, post_kind(layer), o->out_f32, layer->targets, c->d_pat, c->N, o->size, o->Lp, o->err);
+                launch_post_backward(c->stream, post_kind(layer), posteriors(o), layer->targets, c->d_pat, c->N, o->size, o->Lp, o->err);
         }
     });
 }
@@ -1433,10 +1471,10 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
             if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
                 launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss, true);
             else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-                launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
+                launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
             else {
                 flush_loss(c);
-                launch_post_eval(c->stream, post_kind(post), o->out_f32, post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss, true);
+                launch_post_eval(c->stream, post_kind(post), posteriors(o), post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss, true);
                 c->rowstat_of = nullptr;       // the softmax row statistics were overwritten
             }
         }
@@ -1473,9 +1511,9 @@ int cn_loss_accumulate(cn_layer *post)
         if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
             launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
         else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-            launch_mcc_eval(c->stream, o->out_f32, c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
+            launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
         else {
-            launch_post_eval(c->stream, post_kind(post), o->out_f32, post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss_acc, false);
+            launch_post_eval(c->stream, post_kind(post), posteriors(o), post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss_acc, false);
             c->rowstat_of = nullptr;
         }
     });
@@ -1624,13 +1662,13 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
                 launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else if (layer->lstm)
                 for (int d = 0; d < layer->dirs; ++d) launch_unpad(c->stream, opbf, layer->out_op, layer->Lp, d * Hp, 1, N, H, tmp, layer->size, d * H, c->PS, c->PSp);
-            else if (layer->trainable) launch_unpad(c->stream, false, layer->out_f32, layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
+            else if (layer->trainable) launch_unpad(c->stream, false, posteriors(layer), layer->Lp, 0, 1, N, layer->size, tmp, layer->size, 0, c->PS, c->PSp);
             else throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputs");
             break;
         case CN_BUF_OUTPUT_ERRORS:
             if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_read: layer has no outputErrors");
             if (layer->mcc_pending) {     // the deferred multiclass error injection becomes visible here
-                launch_mcc_backward(c->stream, layer->out_f32, c->d_tcls, c->N, layer->size, layer->Lp, layer->err);
+                launch_mcc_backward(c->stream, posteriors(layer), c->d_tcls, c->N, layer->size, layer->Lp, layer->err);
                 layer->mcc_pending = false;
             }
             if (layer->lstm)

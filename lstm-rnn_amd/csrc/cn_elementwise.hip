@@ -434,6 +434,28 @@ __device__ __forceinline__ float safe_exp(float x)      // helpers/safeExp.cuh:3
     return expf(x);
 }
 
+// The wide-row kernels of the bf16 throughput mode (FAST): v_exp_f32 and one reciprocal per row instead of libm's expf and an
+// IEEE division per element -- at 8000 classes x 35 000 patterns those are 0.3 ms of VALU work per pass, more than the row's
+// memory time.  (The LSTM kernels of that mode evaluate their activations the same way.)  One definition of a posterior per mode:
+// every kernel that produces or re-produces one calls softmax_term with the same arguments.
+template <bool FAST> __device__ __forceinline__ float softmax_exp(float x)
+{
+    if constexpr (!FAST) return safe_exp(x);
+    return __builtin_amdgcn_exp2f(fminf(x, NL_EXPLIMIT) * 1.44269504088896341f);      // (v_exp_f32 underflows to 0 by itself)
+}
+// `norm` = sum (exact modes: SoftmaxLayer.cu:152 divides) or 1 / sum (FAST)
+template <bool FAST> __device__ __forceinline__ float softmax_norm(float sum) { return FAST ? 1.0f / sum : sum; }
+template <bool FAST> __device__ __forceinline__ float softmax_scale(float e, float norm) { return FAST ? e * norm : e / norm; }
+
+// pat[row] for a wave-uniform row through the scalar cache (gfx950 has no scalar byte load: a plain pat[row] is a vector
+// memory round trip in front of everything that depends on it)
+__device__ __forceinline__ int pat_at(const char *pat, long row)
+{
+    const uintptr_t a = (uintptr_t)(pat + row);
+    const unsigned w = *(const unsigned *)(a & ~(uintptr_t)3);
+    return (w >> (8 * (a & 3))) & 0xff;
+}
+
 // rowstat (optional): per pattern {log max(FLT_MIN, p_target), 1 if argmax == target} for the multiclass
 // post output layer, so that the loss evaluation is a fixed-order reduction of N pairs instead of a second
 // pass over the posteriors (MulticlassClassificationLayer.cu:55-68, :77-105)
@@ -522,12 +544,16 @@ __device__ __forceinline__ float block_reduce(float v, int op, float *sh)      /
     const float a = sh[0], b = sh[1], c = sh[2], d = sh[3];
     return op == 0 ? (a + b) + (c + d) : (op == 1 ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : fminf(fminf(a, b), fminf(c, d)));
 }
-__global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const char *pat, int N, int L, int Lp, const int *tcls, float2 *rowstat)
+// STORE = false (the lazy form): the posteriors stay unwritten -- the row keeps its logits and smstat[row] = {offset, sum} lets
+// softmax_mcc_bwd_wide_kernel<.., true> / softmax_normalise_wide_kernel recompute exactly the values this kernel would have
+// stored (same expression per element), while rowstat (log p_target, correct) is complete as always.
+template <bool STORE, bool FAST>
+__global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const char *pat, int N, int L, int Lp, const int *tcls, float2 *rowstat, float2 *smstat)
 {
     __shared__ float sh[4]; __shared__ float shb[4]; __shared__ int shi[4];
     const long row = blockIdx.x;
     const int tid = threadIdx.x;
-    if (pat[row] == 0) {                                 // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+    if (pat_at(pat, row) == 0) {                         // SKIP_MARKER path, SoftmaxLayer.cu:58-59
         if (rowstat && tid == 0) rowstat[row] = make_float2(0.f, 0.f);
         return;
     }
@@ -545,29 +571,44 @@ __global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const c
     }
     const int tc = rowstat ? tcls[row] : -1;
     float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
+    // columns >= L (padding up to Lp, and the groups beyond Lp) become -inf behind the min / max pass: exp gives them 0, they add
+    // nothing to the sum, never win the argmax and are written back as the 0 the GEMM left there
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) if (col(k) < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
+    for (int q = 0; q < SMW_VPT / 4; ++q) {
+        const int j0 = 4 * (tid + 256 * q);
+        if (j0 + 3 < L) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mx = fmaxf(mx, v[4 * q + e]); mn = fminf(mn, v[4 * q + e]); }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (j0 + e < L) { mx = fmaxf(mx, v[4 * q + e]); mn = fminf(mn, v[4 * q + e]); }
+                else v[4 * q + e] = -__builtin_inff();
+            }
+        }
+    }
     mx = block_reduce(mx, 1, sh); mn = block_reduce(mn, 2, sh);
     const float offset = 0.5f * (mn + mx);               // :74
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < SMW_VPT; ++k) if (col(k) < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
+    for (int k = 0; k < SMW_VPT; ++k) { v[k] = softmax_exp<FAST>(v[k] - offset); sum += v[k]; }
     sum = block_reduce(sum, 0, sh);
+    const float norm = softmax_norm<FAST>(sum);
     float best = 0.f, ptv = 0.f; int bi = 0;
 #pragma unroll
     for (int k = 0; k < SMW_VPT; ++k) {
         const int j = col(k);
-        if (j < L) {
-            const float w = v[k] / sum; v[k] = w;        // :152
-            if (w > best) { best = w; bi = j; }          // ascending j per thread: first maximum kept
-            if (j == tc) ptv = w;
-        }
+        const float w = softmax_scale<FAST>(v[k], norm); v[k] = w;            // :152
+        if (w > best) { best = w; bi = j; }              // ascending j per thread: first maximum kept
+        if (j == tc) ptv = w;
     }
+    if constexpr (STORE) {
 #pragma unroll
-    for (int q = 0; q < SMW_VPT / 4; ++q) {              // (columns L .. Lp - 1 get back what they held)
-        const int j0 = 4 * (tid + 256 * q);
-        if (j0 < Lp) *(f32x4 *)(r + j0) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-    }
+        for (int q = 0; q < SMW_VPT / 4; ++q) {          // (columns L .. Lp - 1 get back what they held)
+            const int j0 = 4 * (tid + 256 * q);
+            if (j0 < Lp) *(f32x4 *)(r + j0) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+    } else if (tid == 0) smstat[row] = make_float2(offset, norm);
     if (rowstat) {
         ptv = block_reduce(ptv, 0, sh);
 #pragma unroll
@@ -586,12 +627,39 @@ __global__ __launch_bounds__(256) void softmax_fwd_wide_kernel(float *y, const c
     }
 }
 
-void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat)
+// the posteriors of a lazily forwarded wide softmax layer, on demand: y = exp(z - offset) / sum per element
+template <bool FAST>
+__global__ __launch_bounds__(256) void softmax_normalise_wide_kernel(float *y, const char *pat, int N, int L, int Lp, const float2 *smstat)
+{
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const long row = blockIdx.x;
+    if (pat_at(pat, row) == 0) return;
+    const float2 st = smstat[row];
+    float *r = y + row * Lp;
+    for (int j0 = 4 * threadIdx.x; j0 < Lp; j0 += 1024) {
+        f32x4 x = *(const f32x4 *)(r + j0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (j0 + e < L) x[e] = softmax_scale<FAST>(softmax_exp<FAST>(x[e] - st.x), st.y);
+        *(f32x4 *)(r + j0) = x;
+    }
+}
+bool softmax_fwd_can_be_lazy(int L) { return L > 256 && L <= 256 * SMW_VPT; }
+void launch_softmax_normalise(hipStream_t s, bool fast, float *y, const char *pat, int N, int L, int Lp, const float *smstat)
 {
     if (N <= 0) return;
-    if (L > 256 && L <= 256 * SMW_VPT)
-        hipLaunchKernelGGL(softmax_fwd_wide_kernel, dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
-    else
+    if (fast) hipLaunchKernelGGL(softmax_normalise_wide_kernel<true>, dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, (const float2 *)smstat);
+    else      hipLaunchKernelGGL(softmax_normalise_wide_kernel<false>, dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, (const float2 *)smstat);
+}
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat, bool fast, float *smstat)
+{
+    if (N <= 0) return;
+    if (L > 256 && L <= 256 * SMW_VPT) {
+        float2 *rs = (float2 *)rowstat, *sm = (float2 *)smstat;
+        if (fast) { if (sm) hipLaunchKernelGGL((softmax_fwd_wide_kernel<false, true>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm);
+                    else    hipLaunchKernelGGL((softmax_fwd_wide_kernel<true, true>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm); }
+        else      { if (sm) hipLaunchKernelGGL((softmax_fwd_wide_kernel<false, false>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm);
+                    else    hipLaunchKernelGGL((softmax_fwd_wide_kernel<true, false>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm); }
+    } else
         hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
 }
 
@@ -762,10 +830,14 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
 }
 // The same fusion for wide rows (256 < Lp <= 8192): one workgroup walks rows blockIdx.x, blockIdx.x + grid, ...; a thread
 // owns the four columns 4 (tid + 256 k) .. + 3 of every k (16-byte loads and stores, 8-byte bf16 stores) and keeps their
-// sums in registers; one atomic per column and workgroup at the end.
-template <bool F32>
-__global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                                                                   float *err, void *delta_op, float *colsum)
+// sums in registers; one atomic per column and workgroup at the end.  The loads of a row are issued together, and those of
+// the next row before the current one is worked on (the row and its per-row scalars are a chain of three dependent round
+// trips otherwise).  LAZY (1 exact, 2 FAST): y holds the logits of softmax_fwd_wide_kernel<false, ..>, the posteriors are
+// recomputed from smstat.
+template <bool F32, int LAZY>
+__global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *__restrict__ y, const int *__restrict__ tcls, const char *__restrict__ pat,
+                                                                   int N, int L, int Lp, float *__restrict__ err, void *__restrict__ delta_op,
+                                                                   float *colsum, const float2 *__restrict__ smstat)
 {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -774,26 +846,61 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
     f32x4 cs[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) cs[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long row = blockIdx.x; row < N; row += gridDim.x) {
-        const int tc = tcls[row];
-        const bool real = pat[row] != 0;
+    struct Row { f32x4 v[NV]; float pt; int tc; bool real; float2 st; };
+    auto fetch = [&](long row, Row &r) {
+        r.tc = -1; r.real = false; r.pt = 0.f; r.st = make_float2(0.f, 1.f);
+        if (row >= N) return;
+        r.tc = tcls[row]; r.real = pat_at(pat, row) != 0;
+        if (!r.real) return;
         const float *yr = y + row * Lp;
+        if constexpr (LAZY != 0) r.st = smstat[row];
+        if (r.tc >= 0) r.pt = yr[r.tc];
+        // columns >= L hold what makes their posterior 0: -inf as a logit (LAZY), 0 as a posterior
+        const float none = LAZY != 0 ? -__builtin_inff() : 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = 4 * (tid + 256 * k);
+            r.v[k] = j < Lp ? *(const f32x4 *)(yr + j) : f32x4{none, none, none, none};
+            if (j + 3 >= L) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (j + e >= L) r.v[k][e] = none;
+            }
+        }
+    };
+    Row cur, nxt;
+    fetch(blockIdx.x, cur);
+    for (long row = blockIdx.x; row < N; row += gridDim.x) {
+        fetch(row + gridDim.x, nxt);
         float et = 0.f, off = 0.f;
-        if (real && tc >= 0) { const float pt_ = yr[tc]; et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
+        if (cur.real && cur.tc >= 0) {
+            float pt_ = cur.pt;
+            if constexpr (LAZY != 0) pt_ = softmax_scale<LAZY == 2>(softmax_exp<LAZY == 2>(pt_ - cur.st.x), cur.st.y);
+            et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et;
+        }
+        const float m0 = 0.f - off, mt = et - off;        // factor of every column but the target's / of the target's
+        const int tgroup = cur.tc & ~3;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int j = 4 * (tid + 256 * k);
             if (j >= Lp) break;
             f32x4 dl = {0.f, 0.f, 0.f, 0.f};
-            if (real) {
-                const f32x4 yv = *(const f32x4 *)(yr + j);
+            if (cur.real) {
+                f32x4 p = cur.v[k];
+                if constexpr (LAZY != 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (j + e < L) dl[e] = yv[e] * ((j + e == tc ? et : 0.f) - off);
+                    for (int e = 0; e < 4; ++e) p[e] = softmax_scale<LAZY == 2>(softmax_exp<LAZY == 2>(p[e] - cur.st.x), cur.st.y);
+                }
+                dl = p * m0;
+                if (j == tgroup) {                       // (one lane of the workgroup per row)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (j + e == cur.tc) dl[e] = p[e] * mt;
+                }
             }
             if (err) *(f32x4 *)(err + row * Lp + j) = dl;
             if constexpr (!F32) *(bf16x4 *)((__bf16 *)delta_op + row * Lp + j) = bf16x4{(__bf16)dl[0], (__bf16)dl[1], (__bf16)dl[2], (__bf16)dl[3]};
             cs[k] += dl;
         }
+        cur = nxt;
     }
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -807,13 +914,16 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
 
 bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part)
+                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part, const float *smstat, bool fast)
 {
     if (N <= 0) return;
     if (Lp > 256) {
-        int blocks = N < 1024 ? N : 1024;
-        if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_wide_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
-        else     hipLaunchKernelGGL(softmax_mcc_bwd_wide_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum);
+        int blocks = N < 1536 ? N : 1536;      // (two to three workgroups per CU are resident, 170 VGPRs: 512 ... 2048 measured)
+        const float2 *sm = (const float2 *)smstat;
+#define CN_BWD_WIDE(F, Z) hipLaunchKernelGGL((softmax_mcc_bwd_wide_kernel<F, Z>), dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, sm)
+        if (f32) { if (!sm) CN_BWD_WIDE(true, 0); else if (fast) CN_BWD_WIDE(true, 2); else CN_BWD_WIDE(true, 1); }
+        else     { if (!sm) CN_BWD_WIDE(false, 0); else if (fast) CN_BWD_WIDE(false, 2); else CN_BWD_WIDE(false, 1); }
+#undef CN_BWD_WIDE
         return;
     }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;

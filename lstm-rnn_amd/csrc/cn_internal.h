@@ -158,7 +158,12 @@ void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *er
 void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum);
 // softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
 // optional: tcls + rowstat[N][2] = {log p_target, argmax == target} for the multiclass loss
-void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat);
+// smstat (nullable, wide rows only: softmax_fwd_can_be_lazy): the LAZY form -- y keeps the logits, smstat[N][2] = {offset, sum};
+// launch_softmax_mcc_bwd(.., smstat) and launch_softmax_normalise recompute the very same posteriors from them
+// fast (wide rows only; the bf16 throughput mode): v_exp_f32 and one reciprocal per row in place of expf and a division per element
+void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, int Lp, const int *tcls, float *rowstat, bool fast = false, float *smstat = nullptr);
+bool softmax_fwd_can_be_lazy(int L);
+void launch_softmax_normalise(hipStream_t s, bool fast, float *y, const char *pat, int N, int L, int Lp, const float *smstat);
 void launch_rowstat_reduce(hipStream_t s, const float *rowstat, int N, float *loss2, bool reset, float scale = -1.0f);
 // remaining post output layers (row f4): per-pattern terms -> rowstat -> fixed-order sum
 enum { POST_SSE = 0, POST_WEIGHTEDSSE, POST_SSE_MASK, POST_CE, POST_RMSE, POST_BINARY };
@@ -171,7 +176,8 @@ void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N
 // statistics into loss2 like launch_rowstat_reduce(..., reset = false) would (the same sums in the same order), in sixteen extra workgroups
 // `loss_part`: 16 x {float sum, int count} + one arrival counter (zero between launches) for the sixteen reduction workgroups
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr);
+                            float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr,
+                            const float *smstat = nullptr, bool fast = false);
 bool softmax_mcc_bwd_takes_loss(int Lp);
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);

@@ -545,6 +545,56 @@ def test_wide_softmax_layer(pkg, orc):
     net.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_lazy_wide_softmax_equals_the_eager_kernels(pkg, precision, monkeypatch):
+    """Wide softmax rows in training: the forward pass leaves the logits in place (softmax_fwd_wide_kernel<false> writes only
+    {offset, sum} and the loss statistics per row) and the fused backward kernel recomputes the posteriors (SoftmaxLayer.cu:61-152
+    element by element, the same expressions).  Three orders of calls must agree BIT FOR BIT on posteriors and output errors:
+    A forward, backward, then read the posteriors (normalised on demand after the lazy backward kernel);
+    B forward, read the posteriors (normalised on demand), backward (the eager backward kernel on them);
+    C as B, then a second forward pass -- a layer whose posteriors were read runs the eager forward kernel -- and backward.
+    Error, #correct (row statistics of either forward kernel) and the gradients (atomic column sums: 1e-6) agree too.
+    The library is lazy by itself only in the bf16 mode (v_exp_f32 and one reciprocal per row: recomputing is cheap there);
+    CN_LAZY_SOFTMAX=1 puts the fp32 mode's exact kernels (expf, a division per element) through the same three orders."""
+    if precision == 0:
+        monkeypatch.setenv("CN_LAZY_SOFTMAX", "1")
+    rng = np.random.RandomState(35 + precision)
+    P, C, PS = 6, 700, 5
+    layers = net_desc(P, [("lstm", 24)], C)
+    weights = random_weights(layers, rng, 0.3)
+    xs, ts = random_sequences(rng, [9, 7, 7, 4], P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    got = {}
+    for mode in "ABC":
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=precision) as net:
+            out = net.layer("output")
+            net.load_sequences(frac); net.compute_forward_pass()
+            if mode == "A":
+                ec = net.error_and_correct()
+                net.compute_backward_pass()
+                oe = out.output_errors().copy(); y = net.outputs().copy()
+            else:
+                y = net.outputs().copy()
+                ec = net.error_and_correct()
+                net.compute_backward_pass()
+                oe = out.output_errors().copy()
+                if mode == "C":
+                    net.compute_forward_pass()
+                    y2 = net.outputs().copy(); ec2 = net.error_and_correct()
+                    net.compute_backward_pass()
+                    assert np.array_equal(y2, y) and ec2 == ec and np.array_equal(out.output_errors(), oe)
+            got[mode] = (y, oe, ec, [l.weight_updates() for l in net.trainable_layers()])
+    real = real_mask(frac)
+    yA = got["A"][0].reshape(-1, C)
+    assert np.allclose(yA[real].sum(1), 1.0, atol=1e-5) and np.abs(got["A"][1]).max() > 0
+    for mode in "BC":
+        assert np.array_equal(got[mode][0], got["A"][0]), mode
+        assert np.array_equal(got[mode][1], got["A"][1]), mode
+        assert got[mode][2] == got["A"][2], mode
+        for a, b in zip(got[mode][3], got["A"][3]):
+            assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max()), mode
+
+
 def test_two_contexts_interleaved(pkg):
     """Two networks alive in one process, trained alternately (they share the device's CU-masked gradient stream):
     each ends with the weights it reaches when trained alone."""
