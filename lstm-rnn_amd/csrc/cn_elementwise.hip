@@ -447,6 +447,13 @@ template <bool FAST> __device__ __forceinline__ float softmax_exp(float x)
 template <bool FAST> __device__ __forceinline__ float softmax_norm(float sum) { return FAST ? 1.0f / sum : sum; }
 template <bool FAST> __device__ __forceinline__ float softmax_scale(float e, float norm) { return FAST ? e * norm : e / norm; }
 
+// the wave's index within its workgroup as a scalar: what is indexed with it (target class, pattern type, the target's
+// posterior) then comes through the scalar cache instead of a vector memory round trip per link of the chain
+#ifndef CN_EW_NO_UNIFORM
+#define CN_WAVE_ID() __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+#else
+#define CN_WAVE_ID() ((int)(threadIdx.x >> 6))
+#endif
 // pat[row] for a wave-uniform row through the scalar cache (gfx950 has no scalar byte load: a plain pat[row] is a vector
 // memory round trip in front of everything that depends on it)
 __device__ __forceinline__ int pat_at(const char *pat, long row)
@@ -462,9 +469,9 @@ __device__ __forceinline__ int pat_at(const char *pat, long row)
 __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int Lp, const int *tcls, float2 *rowstat)
 {
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + CN_WAVE_ID();
     if (row >= N) return;
-    if (pat[row] == 0) {                                 // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+    if (pat_at(pat, row) == 0) {                         // SKIP_MARKER path, SoftmaxLayer.cu:58-59
         if (rowstat && lane == 0) rowstat[row] = make_float2(0.f, 0.f);
         return;
     }
@@ -784,14 +791,14 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     // they are same-address atomics, so the grid stays at one workgroup per CU (2048 workgroups: 50 us).
     constexpr int RB = 4;
     __shared__ float part[4][256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = CN_WAVE_ID();
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
     for (long row0 = ((long)blockIdx.x * 4 + wv) * RB; row0 < N; row0 += (long)nwg * 4 * RB) {
         int tc[RB]; bool real[RB]; float et[RB], off[RB], pt_[RB];
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
             const long row = row0 + b < N ? row0 + b : N - 1;
-            tc[b] = tcls[row]; real[b] = pat[row] != 0 && row0 + b < N;
+            tc[b] = tcls[row]; real[b] = pat_at(pat, row) != 0 && row0 + b < N;
         }
 #pragma unroll
         for (int b = 0; b < RB; ++b) {
