@@ -476,43 +476,6 @@ __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int 
         return;
     }
     float *r = y + row * Lp;
-    if (L <= 256) {
-        // the whole row in registers: one read and one write of the posteriors (same arithmetic and order)
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; v[k] = j < L ? r[j] : 0.f; }
-        const int tc = rowstat ? tcls[row] : -1;
-        float mx = NL_MIN, mn = NL_MAX;                  // :61-62 (max starts at FLT_MIN, quirk Q3)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (lane + 64 * k < L) { mx = fmaxf(mx, v[k]); mn = fminf(mn, v[k]); }
-        mx = wave_max(mx); mn = wave_min(mn);
-        const float offset = 0.5f * (mn + mx);           // :74
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (lane + 64 * k < L) { v[k] = safe_exp(v[k] - offset); sum += v[k]; }
-        sum = wave_sum(sum);
-        float best = 0.f, ptv = 0.f; int bi = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int j = lane + 64 * k;
-            if (j < L) {
-                const float w = v[k] / sum; r[j] = w;    // :152
-                if (w > best) { best = w; bi = j; }
-                if (j == tc) ptv = w;
-            }
-        }
-        if (rowstat) {
-            ptv = wave_sum(ptv);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
-                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (best <= 0.f) bi = 0;
-            if (lane == 0) rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
-        }
-        return;
-    }
     float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
     for (int j = lane; j < L; j += 64) { float v = r[j]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
     mx = wave_max(mx); mn = wave_min(mn);
@@ -537,6 +500,76 @@ __global__ void softmax_fwd_kernel(float *y, const char *pat, int N, int L, int 
         }
         if (best <= 0.f) bi = 0;
         if (lane == 0) rowstat[row] = tc < 0 ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
+    }
+}
+// Narrow rows (Lp <= 256, the headline's 183 classes), round 4: SIXTEEN lanes per pattern, four patterns per wave.  Lane c of
+// a pattern's group owns the 16-byte column groups c, c + 16, c + 32, c + 48 (v[4g + e] = column 4 (c + 16 g) + e, ascending):
+// 16-byte loads and stores instead of dwords, four-step reductions instead of six, a quarter of the waves.  The loads of the row
+// are issued beside the pattern's type and target class, not behind them (a padding pattern's row is read and dropped).
+// Same expressions per element as softmax_fwd_kernel; the sums associate differently (per lane, then a 16-lane tree).
+__device__ __forceinline__ float g16_sum(float v) { v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1); return v; }
+__device__ __forceinline__ float g16_max(float v) { v = fmaxf(v, __shfl_xor(v, 8)); v = fmaxf(v, __shfl_xor(v, 4)); v = fmaxf(v, __shfl_xor(v, 2)); return fmaxf(v, __shfl_xor(v, 1)); }
+__device__ __forceinline__ float g16_min(float v) { v = fminf(v, __shfl_xor(v, 8)); v = fminf(v, __shfl_xor(v, 4)); v = fminf(v, __shfl_xor(v, 2)); return fminf(v, __shfl_xor(v, 1)); }
+template <bool FAST>
+__global__ __launch_bounds__(256) void softmax_fwd_rows16_kernel(float *__restrict__ y, const char *__restrict__ pat, int N, int L, int Lp,
+                                                                 const int *__restrict__ tcls, float2 *__restrict__ rowstat)
+{
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    const int c = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool in = row < N;
+    const long rr = in ? row : N - 1;
+    float *r = y + rr * Lp;
+    float v[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int j0 = 4 * (c + 16 * g);
+        const f32x4 x = j0 < Lp ? *(const f32x4 *)(r + j0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[4 * g] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
+    }
+    const bool real = in && pat[rr] != 0;                // SKIP_MARKER path, SoftmaxLayer.cu:58-59
+    const int tc = rowstat ? tcls[rr] : -1;
+    float mx = NL_MIN, mn = NL_MAX;                      // :61-62 (max starts at FLT_MIN, quirk Q3)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int j0 = 4 * (c + 16 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (j0 + e < L) { mx = fmaxf(mx, v[4 * g + e]); mn = fminf(mn, v[4 * g + e]); }
+            else v[4 * g + e] = -__builtin_inff();       // (exp gives 0: nothing in the sum, never the argmax, written back as 0)
+        }
+    }
+    mx = g16_max(mx); mn = g16_min(mn);
+    const float offset = 0.5f * (mn + mx);               // :74
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k] = softmax_exp<FAST>(v[k] - offset); sum += v[k]; }
+    sum = g16_sum(sum);
+    const float norm = softmax_norm<FAST>(sum);
+    float best = 0.f, ptv = 0.f; int bi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = 4 * (c + 16 * (k >> 2)) + (k & 3);
+        const float w = softmax_scale<FAST>(v[k], norm); v[k] = w;            // :152
+        if (w > best) { best = w; bi = j; }              // ascending j per lane: first maximum kept
+        if (j == tc) ptv = w;
+    }
+    if (real) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = 4 * (c + 16 * g);
+            if (j0 < Lp) *(f32x4 *)(r + j0) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        }
+    }
+    if (rowstat) {
+        ptv = g16_sum(ptv);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o); int oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (best <= 0.f) bi = 0;
+        if (in && c == 0) rowstat[row] = (!real || tc < 0) ? make_float2(0.f, 0.f) : make_float2(logf(fmaxf(NL_MIN, ptv)), bi == tc ? 1.f : 0.f);
     }
 }
 // Wide rows (256 < L <= 8192, e.g. 8000 tied states): one workgroup per pattern, the row in registers (VPT values per
@@ -666,7 +699,11 @@ void launch_softmax_fwd(hipStream_t s, float *y, const char *pat, int N, int L, 
                     else    hipLaunchKernelGGL((softmax_fwd_wide_kernel<true, true>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm); }
         else      { if (sm) hipLaunchKernelGGL((softmax_fwd_wide_kernel<false, false>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm);
                     else    hipLaunchKernelGGL((softmax_fwd_wide_kernel<true, false>), dim3(N), dim3(256), 0, s, y, pat, N, L, Lp, tcls, rs, sm); }
-    } else
+    } else if (Lp <= 256) {
+        if (fast) hipLaunchKernelGGL(softmax_fwd_rows16_kernel<true>, dim3((N + 15) / 16), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
+        else      hipLaunchKernelGGL(softmax_fwd_rows16_kernel<false>, dim3((N + 15) / 16), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
+    }
+    else
         hipLaunchKernelGGL(softmax_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, s, y, pat, N, L, Lp, tcls, (float2 *)rowstat);
 }
 
@@ -786,52 +823,87 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
 {
     const unsigned nwg = gridDim.x - (loss2 ? (unsigned)MCC_LOSS_WGS : 0u);
     if (loss2 && blockIdx.x >= nwg) { rowstat_reduce_wave(rowstat, N, loss2, -1.0f, (int)(blockIdx.x - nwg), loss_part); return; }
-    // One row is a chain of dependent loads (target class -> its posterior -> the row), so a wave works on RB
-    // rows at a time to keep RB chains in flight.  The column sums end in one atomic per column and WORKGROUP:
-    // they are same-address atomics, so the grid stays at one workgroup per CU (2048 workgroups: 50 us).
-    constexpr int RB = 4;
+    // SIXTEEN lanes per pattern, four patterns per wave, sixteen per workgroup and pass (round 4; before: a wave per pattern,
+    // dword accesses, four patterns in flight per wave).  Lane c of a pattern's group owns the 16-byte column groups c, c + 16,
+    // c + 32, c + 48.  A row used to be a chain of dependent loads (target class -> its posterior -> the row): the row is
+    // loaded beside its class, the target's posterior is picked out of the registers (one select per element + one shuffle
+    // from its owner lane), and the next sixteen patterns are fetched before the current ones are worked on.  The column
+    // sums end in one atomic per column and WORKGROUP: they are same-address atomics, so the grid stays at one workgroup per
+    // CU (2048 workgroups: 50 us).
+    typedef __attribute__((ext_vector_type(4))) float f32x4;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
     __shared__ float part[4][256];
-    const int lane = threadIdx.x & 63, wv = CN_WAVE_ID();
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-    for (long row0 = ((long)blockIdx.x * 4 + wv) * RB; row0 < N; row0 += (long)nwg * 4 * RB) {
-        int tc[RB]; bool real[RB]; float et[RB], off[RB], pt_[RB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15;
+    f32x4 cs[4];
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const long row = row0 + b < N ? row0 + b : N - 1;
-            tc[b] = tcls[row]; real[b] = pat_at(pat, row) != 0 && row0 + b < N;
+    for (int g = 0; g < 4; ++g) cs[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    struct Rows { f32x4 v[4]; int tc; bool in, real; };
+    auto fetch = [&](long batch, Rows &r) {
+        const long row = batch * 16 + (threadIdx.x >> 4);
+        r.in = row < N;
+        const long rr = r.in ? row : N - 1;
+        r.tc = tcls[rr]; r.real = r.in && pat[rr] != 0;
+        const float *yr = y + rr * Lp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = 4 * (c + 16 * g);
+            r.v[g] = j0 < Lp ? *(const f32x4 *)(yr + j0) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+    };
+    const long nb = ((long)N + 15) / 16;
+    Rows cur, nxt, nx2;                                  // two passes ahead: a workgroup makes four to five passes, each a memory round trip
+    if ((long)blockIdx.x < nb) fetch(blockIdx.x, cur);
+    if ((long)blockIdx.x + nwg < nb) fetch(blockIdx.x + nwg, nxt);
+    for (long bt = blockIdx.x; bt < nb; bt += nwg) {
+        const bool more = bt + nwg < nb;
+        if (bt + 2 * (long)nwg < nb) fetch(bt + 2 * (long)nwg, nx2);
+        const long row = bt * 16 + (threadIdx.x >> 4);
+        // the target's posterior: v[og][oe] of lane ol of this pattern's group
+        const int idx = cur.tc >= 0 ? cur.tc : 0, og = idx >> 6, oe = idx & 3, ol = (idx >> 2) & 15;
+        float cand = 0.f;
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const long row = row0 + b < N ? row0 + b : N - 1;
-            pt_[b] = y[row * Lp + (tc[b] >= 0 ? tc[b] : 0)];
-        }
-        float yv[RB][4];
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            const long row = row0 + b < N ? row0 + b : N - 1;
+            for (int e = 0; e < 4; ++e) if (g == og && e == oe) cand = cur.v[g][e];
+        const float pt_ = __shfl(cand, (lane & 48) | ol);
+        float et = 0.f, off = 0.f;
+        if (cur.real && cur.tc >= 0) { et = -(1.0f / fmaxf(NL_MIN, pt_)); off = pt_ * et; }
+        const float m0 = 0.f - off, mt = et - off;        // factor of every column but the target's / of the target's
+        const int tgroup = cur.tc & ~3;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int j = lane + 64 * k; yv[b][k] = j < Lp ? y[row * Lp + j] : 0.f; }
-        }
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = 4 * (c + 16 * g);
+            if (j0 < Lp) {
+                f32x4 dl = {0.f, 0.f, 0.f, 0.f};
+                if (cur.real) {
+                    dl = cur.v[g] * m0;
+                    if (j0 == tgroup) {
 #pragma unroll
-        for (int b = 0; b < RB; ++b) {
-            et[b] = 0.f; off[b] = 0.f;
-            if (real[b] && tc[b] >= 0) { et[b] = -(1.0f / fmaxf(NL_MIN, pt_[b])); off[b] = pt_[b] * et[b]; }
-            if (row0 + b >= N) continue;
-            const long row = row0 + b;
+                        for (int e = 0; e < 4; ++e) if (j0 + e == cur.tc) dl[e] = cur.v[g][e] * mt;
+                    }
+                    if (j0 + 3 >= L) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int j = lane + 64 * k;
-                if (j >= Lp) break;
-                float dl = 0.f;
-                if (real[b] && j < L) dl = yv[b][k] * ((j == tc[b] ? et[b] : 0.f) - off[b]);
-                if (err) err[row * Lp + j] = dl;         // (bf16 mode: only the operand copy is written; cn_layer_read converts it)
-                if constexpr (!F32) ((__bf16 *)delta_op)[row * Lp + j] = (__bf16)dl;
-                cs[k] += dl;
+                        for (int e = 0; e < 4; ++e) if (j0 + e >= L) dl[e] = 0.f;
+                    }
+                }
+                if (cur.in) {
+                    if (err) *(f32x4 *)(err + row * Lp + j0) = dl;    // (bf16 mode: only the operand copy is written; cn_layer_read converts it)
+                    if constexpr (!F32) *(bf16x4 *)((__bf16 *)delta_op + row * Lp + j0) = bf16x4{(__bf16)dl[0], (__bf16)dl[1], (__bf16)dl[2], (__bf16)dl[3]};
+                }
+                cs[g] += dl;
             }
         }
+        if (more) { cur = nxt; nxt = nx2; }
     }
+    // the four patterns of a wave -> lanes 0..15, the four waves through LDS, one atomic per column
 #pragma unroll
-    for (int k = 0; k < 4; ++k) part[wv][lane + 64 * k] = cs[k];
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = cs[g][e];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            if (lane < 16) part[wv][4 * (c + 16 * g) + e] = v;
+        }
     __syncthreads();
     for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
 }
