@@ -89,6 +89,7 @@ struct cn_ctx {
     unsigned long long *d_xch = nullptr; size_t xch_bytes = 0;   // cluster kernels' exchange granules
     unsigned xch_epoch = 0;       // granule tags handed out so far (LstmRec::xch_epoch)
     int *d_fault = nullptr;       // device fault word (bounded spins)
+    float *d_colpart = nullptr;   // softmax_mcc_bwd_colpart_floats(): replicas of the output layer's column sums (zero between launches)
     float *d_rowstat = nullptr;   // [maxN][2] per-pattern {log p_target, correct} of the last softmax forward pass
     cn_layer *rowstat_of = nullptr;
     bool loss_deferred = false;   // cn_loss_accumulate of the current fraction has not been enqueued yet: it rides on the output
@@ -730,7 +731,7 @@ void ff_backward(cn_layer *l)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
                                    with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6, l->sm_lazy ? l->sm_stat : nullptr,
-                                   softmax_fast(c));
+                                   softmax_fast(c), c->d_colpart);
             l->sm_lazy_next = !l->sm_read;
             if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
@@ -844,6 +845,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
         HIP_CHECK(hipMalloc((void **)&c->d_loss, (6 + 2 * 16 + 2) * sizeof(float)));
         HIP_CHECK(hipMemsetAsync(c->d_loss, 0, (6 + 2 * 16 + 2) * sizeof(float), c->stream));
         c->d_loss_acc = c->d_loss + 2;
+        HIP_CHECK(hipMalloc((void **)&c->d_colpart, softmax_mcc_bwd_colpart_floats() * sizeof(float)));
+        HIP_CHECK(hipMemsetAsync(c->d_colpart, 0, softmax_mcc_bwd_colpart_floats() * sizeof(float), c->stream));
         HIP_CHECK(hipMalloc((void **)&c->d_fault, sizeof(int)));
         HIP_CHECK(hipMemsetAsync(c->d_fault, 0, sizeof(int), c->stream));
     });
@@ -882,7 +885,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         }
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
-        hipFree(ctx->pf.pat_raw); hipFree(ctx->pf.tcls);
+        hipFree(ctx->pf.pat_raw); hipFree(ctx->pf.tcls); hipFree(ctx->d_colpart);
         hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;

@@ -779,6 +779,7 @@ void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *p
 // of "virtual wave" w of rowstat_reduce_body -- the same loads, the same adds, the same shuffles --, the last one to arrive adds
 // the sixteen sums in wave order: bit-identical to the one-workgroup kernel, a sixteenth of its time.
 constexpr int MCC_LOSS_WGS = 16;
+constexpr int MCC_COL_REPL = 8;           // replicas of the column sums (softmax_mcc_bwd_colpart_floats)
 __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N, float *loss2, float scale, int w, float *part)
 {
     if (threadIdx.x >= 64) return;
@@ -802,7 +803,9 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
     if (threadIdx.x == 0) {
         __hip_atomic_store(&part[2 * w], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store((int *)&part[2 * w + 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
+        // (the partials are device-scope atomic stores: acknowledged -- a workgroup-scope release waits for that -- is visible)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
     }
     last = __shfl(last, 0);
     if (!last) return;
@@ -819,7 +822,7 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
 }
 template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2, float *loss_part)
+                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2, float *loss_part, float *colpart)
 {
     const unsigned nwg = gridDim.x - (loss2 ? (unsigned)MCC_LOSS_WGS : 0u);
     if (loss2 && blockIdx.x >= nwg) { rowstat_reduce_wave(rowstat, N, loss2, -1.0f, (int)(blockIdx.x - nwg), loss_part); return; }
@@ -905,7 +908,34 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
             if (lane < 16) part[wv][4 * (c + 16 * g) + e] = v;
         }
     __syncthreads();
-    for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
+    if (!colpart) {
+        for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
+        return;
+    }
+    // 256 workgroups adding to the same 192 words at the same moment are a queue at six L2 lines (4.5 of the launch's 17 us):
+    // the adds go to MCC_COL_REPL replicas instead, and the last workgroup to arrive folds the replicas into colsum
+    float *rep = colpart + (blockIdx.x % MCC_COL_REPL) * 256;
+    for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&rep[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
+    // The adds are device-scope atomics, performed where all CUs meet: it is enough that they have been ACKNOWLEDGED before this
+    // workgroup is counted (a workgroup-scope release = wait for the thread's outstanding memory operations; an agent-scope fence
+    // in every thread writes the L2 back 65 000 times and doubled the launch)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __shared__ int last;
+    unsigned *cnt = (unsigned *)(colpart + MCC_COL_REPL * 256);
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+    __syncthreads();
+    if (!last) return;
+    for (int j = threadIdx.x; j < Lp; j += 256) {
+        float v[MCC_COL_REPL];
+#pragma unroll
+        for (int r = 0; r < MCC_COL_REPL; ++r) v[r] = __hip_atomic_load(&colpart[r * 256 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < MCC_COL_REPL; ++r) { t += v[r]; __hip_atomic_store(&colpart[r * 256 + j], 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        colsum[j] += t;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (zero again for the next launch)
 }
 // The same fusion for wide rows (256 < Lp <= 8192): one workgroup walks rows blockIdx.x, blockIdx.x + grid, ...; a thread
 // owns the four columns 4 (tid + 256 k) .. + 3 of every k (16-byte loads and stores, 8-byte bf16 stores) and keeps their
@@ -992,8 +1022,10 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
 }
 
 bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
+size_t softmax_mcc_bwd_colpart_floats() { return MCC_COL_REPL * 256 + 1; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part, const float *smstat, bool fast)
+                            float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part, const float *smstat, bool fast,
+                            float *colpart)
 {
     if (N <= 0) return;
     if (Lp > 256) {
@@ -1008,8 +1040,8 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
     if (loss2 && !loss_part) loss2 = nullptr;
     if (loss2) blocks += MCC_LOSS_WGS;
-    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part);
-    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part);
+    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart);
+    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -177,8 +177,11 @@ void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N
 // `loss_part`: 16 x {float sum, int count} + one arrival counter (zero between launches) for the sixteen reduction workgroups
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr,
-                            const float *smstat = nullptr, bool fast = false);
+                            const float *smstat = nullptr, bool fast = false, float *colpart = nullptr);
 bool softmax_mcc_bwd_takes_loss(int Lp);
+// `colpart` (nullable; narrow rows): softmax_mcc_bwd_colpart_floats() zeroed floats the launch spreads its column-sum atomics over
+// (replicas folded into colsum by the last workgroup; zero again when the launch ends)
+size_t softmax_mcc_bwd_colpart_floats();
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
 // multiclass_classification: loss/#correct reduction and error injection

@@ -63,6 +63,7 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(dpat, pat.data(), N, hipMemcpyHostToDevice)); CK(hipMemcpy(dtc, tc.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemset(colsum, 0, Lp * 4));
+    float *colpart; CK(hipMalloc(&colpart, softmax_mcc_bwd_colpart_floats() * 4)); CK(hipMemset(colpart, 0, softmax_mcc_bwd_colpart_floats() * 4));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const double gb_row = real * (double)Lp * 4 / 1e9, gb_half = N * (double)Lp * 2 / 1e9;
@@ -86,7 +87,7 @@ int main(int argc, char **argv)
         timeit(("stream read + bf16 write, " + std::to_string(blocks) + " workgroups").c_str(), gb_row + gb_half, [&] { hipLaunchKernelGGL(stream_rw_kernel, dim3(blocks), dim3(256), 0, s, y, dpat, N, Lp, (unsigned short *)delta); }, false);
     for (int fast = 0; fast < 2; ++fast) {
         timeit(fast ? "softmax fwd eager fast" : "softmax fwd eager exact", 2 * gb_row, [&] { launch_softmax_fwd(s, y, dpat, N, L, Lp, dtc, rowstat, fast, nullptr); }, true);
-        timeit(fast ? "softmax bwd eager (on posteriors)" : "softmax bwd eager (on posteriors) ", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, nullptr, nullptr, nullptr, nullptr, false); }, false);
+        timeit(fast ? "softmax bwd eager, column sums in replicas" : "softmax bwd eager (on posteriors)", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, nullptr, nullptr, nullptr, nullptr, false, fast ? colpart : nullptr); }, false);
         if (narrow) continue;
         timeit(fast ? "softmax fwd lazy fast" : "softmax fwd lazy exact", gb_row, [&] { launch_softmax_fwd(s, y, dpat, N, L, Lp, dtc, rowstat, fast, smstat); }, true);
         timeit(fast ? "softmax bwd lazy fast" : "softmax bwd lazy exact", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, nullptr, nullptr, nullptr, smstat, fast); }, false);
