@@ -63,6 +63,7 @@ int main(int argc, char **argv)
     }
     CK(hipMemcpy(dpat, pat.data(), N, hipMemcpyHostToDevice)); CK(hipMemcpy(dtc, tc.data(), N * 4, hipMemcpyHostToDevice));
     CK(hipMemset(colsum, 0, Lp * 4));
+    float *loss2; CK(hipMalloc(&loss2, 64 * 4)); CK(hipMemset(loss2, 0, 64 * 4));
     float *colpart; CK(hipMalloc(&colpart, softmax_mcc_bwd_colpart_floats() * 4)); CK(hipMemset(colpart, 0, softmax_mcc_bwd_colpart_floats() * 4));
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -88,7 +89,10 @@ int main(int argc, char **argv)
     for (int fast = 0; fast < 2; ++fast) {
         timeit(fast ? "softmax fwd eager fast" : "softmax fwd eager exact", 2 * gb_row, [&] { launch_softmax_fwd(s, y, dpat, N, L, Lp, dtc, rowstat, fast, nullptr); }, true);
         timeit(fast ? "softmax bwd eager, column sums in replicas" : "softmax bwd eager (on posteriors)", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, nullptr, nullptr, nullptr, nullptr, false, fast ? colpart : nullptr); }, false);
-        if (narrow) continue;
+        if (narrow) {
+            if (fast) timeit("softmax bwd eager, replicas + loss sum (16 workgroups)", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, rowstat, loss2, loss2 + 2, nullptr, false, colpart); }, false);
+            continue;
+        }
         timeit(fast ? "softmax fwd lazy fast" : "softmax fwd lazy exact", gb_row, [&] { launch_softmax_fwd(s, y, dpat, N, L, Lp, dtc, rowstat, fast, smstat); }, true);
         timeit(fast ? "softmax bwd lazy fast" : "softmax bwd lazy exact", gb_row + gb_half, [&] { launch_softmax_mcc_bwd(s, false, y, dtc, dpat, N, L, Lp, nullptr, delta, colsum, nullptr, nullptr, nullptr, smstat, fast); }, false);
     }
