@@ -383,3 +383,37 @@ def test_prefetched_resident_fraction_equals_plain_load(pkg, post):
         for (o, e, c), (o0, e0, c0) in zip(res[mode][0], res["plain"][0]):
             assert np.abs(o - o0).max() < 1e-5 and abs(e - e0) <= 1e-4 * max(1.0, abs(e0)) and c == c0, mode
         assert np.abs(res[mode][1] - res["plain"][1]).max() < 1e-5, mode
+
+
+def test_prefetch_hint_without_side_stream_work_is_dropped(pkg):
+    """A network whose only trainable layer computes its gradient on the main stream (nothing runs beside the backward pass): the
+    announced fraction is never re-laid out ahead, the load that follows takes the ordinary path, results equal the unhinted run."""
+    import torch
+    rng = np.random.RandomState(32)
+    P, C, PS = 7, 5, 4
+    layers = [{"name": "input", "type": "input", "size": P},
+              {"name": "output", "type": "softmax", "size": C, "bias": 1.0},
+              {"name": "postoutput", "type": "multiclass_classification", "size": C}]
+    weights = random_weights(layers, rng, 0.4)
+    fracs, keep = [], []
+    for lens in ([6, 5, 3], [4, 4, 4, 2]):
+        xs, ts = random_sequences(rng, lens, P, C=C)
+        fr = pkg.make_fraction(xs, ts, PS)
+        dev = {k: torch.from_numpy(np.ascontiguousarray(fr[k])).cuda() for k in ("inputs", "patTypes", "targetClasses")}
+        keep.append(dev)
+        d = {"T": fr["T"], "Tmin": fr["Tmin"], "numSeqs": fr["numSeqs"], "inputPatternSize": P, "outputPatternSize": C}
+        d.update({k: v.data_ptr() for k, v in dev.items()})
+        fracs.append(d)
+    res = {}
+    for mode in ("plain", "hint"):
+        with pkg.NeuralNetwork(layers, weights, PS, 6, precision=pkg.PREC_F32) as net:
+            errs = []
+            for i in range(4):
+                net.load_sequences_resident(fracs[i % 2]); net.compute_forward_pass()
+                errs.append(net.error_and_correct())
+                if mode == "hint":
+                    net.prefetch_sequences_resident(fracs[(i + 1) % 2])
+                net.compute_backward_pass(); net.update_weights_fused(1e-2, 0.9)
+            res[mode] = (errs, np.concatenate([l.weights() for l in net.trainable_layers()]))
+    assert res["hint"][0] == res["plain"][0]
+    assert np.abs(res["hint"][1] - res["plain"][1]).max() < 1e-6
