@@ -737,6 +737,7 @@ void ff_backward(cn_layer *l)
             l->err_in_delta = !c->f32;
         } else {
             l->err_in_delta = false;
+            if (l->kind == CN_LAYER_SOFTMAX) l->sm_lazy_next = false;   // no fused consumer: lazy rows would be normalised on demand every pass
             const float *y = posteriors(l);
             if (l->mcc_pending) launch_mcc_backward(c->stream, y, c->d_tcls, N, l->size, l->Lp, l->err);
             if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, y, l->err, c->d_pat, N, l->size, l->Lp);

@@ -16,6 +16,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,10 +98,31 @@ bool ipc_backend_selected()
     return b && !strcmp(b, "ipc");
 }
 
+// Segments this process created and nobody has unlinked yet (rank 0 unlinks inside ipc_comm_create): if the caller throws
+// between cn_comm_unique_id and cn_comm_init, or exits without ever calling it, the name would stay in /dev/shm.
+static std::mutex g_pending_mu;
+static std::vector<std::string> g_pending;
+static pid_t g_pending_pid = 0;               // (a forked child inherits the list but owns none of it)
+static void ipc_unlink_pending()
+{
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    if (g_pending_pid == getpid())
+        for (const std::string &n : g_pending) shm_unlink(n.c_str());
+    g_pending.clear();
+}
+static void ipc_forget_pending(const char *id)
+{
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    for (size_t i = 0; i < g_pending.size(); ++i)
+        if (g_pending[i] == id) { g_pending.erase(g_pending.begin() + i); break; }
+}
+
 // rank 0: create the segment; its name is the id
 void ipc_unique_id(char *id, size_t bytes)
 {
     static std::atomic<unsigned> serial{0};
+    static std::once_flag once;
+    std::call_once(once, [] { atexit(ipc_unlink_pending); });
     memset(id, 0, bytes);
     snprintf(id, bytes, "/cn_ipc_%d_%u_%lx", (int)getpid(), serial.fetch_add(1), (unsigned long)(now_s() * 1e6));
     int fd = shm_open(id, O_CREAT | O_EXCL | O_RDWR, 0600);
@@ -111,6 +134,9 @@ void ipc_unique_id(char *id, size_t bytes)
     memset(p, 0, sizeof(Shared));
     ((Shared *)p)->magic.store(IPC_MAGIC);
     munmap(p, sizeof(Shared));
+    std::lock_guard<std::mutex> lk(g_pending_mu);
+    if (g_pending_pid != getpid()) { g_pending.clear(); g_pending_pid = getpid(); }
+    g_pending.push_back(id);
 }
 
 IpcComm *ipc_comm_create(const char *id, int rank, int world)
@@ -119,7 +145,10 @@ IpcComm *ipc_comm_create(const char *id, int rank, int world)
     if (id[0] != '/' || strncmp(id, "/cn_ipc_", 8)) throw std::runtime_error("ipc communicator: the id does not come from cn_comm_unique_id with CN_COMM_BACKEND=ipc");
     IpcComm *c = new IpcComm;
     c->name = id; c->rank = rank; c->world = world;
-    if (const char *t = getenv("CN_COMM_IPC_TIMEOUT")) c->timeout_s = atof(t);
+    if (const char *t = getenv("CN_COMM_IPC_TIMEOUT")) {
+        const double v = atof(t);              // garbage or 0 would time every barrier out at once: keep the default then
+        if (v >= 1.0) c->timeout_s = v;
+    }
     int fd = shm_open(id, O_RDWR, 0600);
     if (fd < 0) { delete c; throw std::runtime_error(std::string("ipc communicator: rank ") + std::to_string(rank) + " cannot open " + id); }
     void *p = mmap(nullptr, sizeof(Shared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
@@ -130,11 +159,11 @@ IpcComm *ipc_comm_create(const char *id, int rank, int world)
     try {
         c->barrier("cn_comm_init");
     } catch (...) {
-        if (rank == 0) shm_unlink(id);
+        if (rank == 0) { shm_unlink(id); ipc_forget_pending(id); }
         munmap(p, sizeof(Shared)); delete c;
         throw;
     }
-    if (rank == 0) shm_unlink(id);           // every rank holds a mapping now: nothing stays behind in /dev/shm
+    if (rank == 0) { shm_unlink(id); ipc_forget_pending(id); }           // every rank holds a mapping now: nothing stays behind in /dev/shm
     return c;
 }
 

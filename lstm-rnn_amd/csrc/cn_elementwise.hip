@@ -803,12 +803,16 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
     if (threadIdx.x == 0) {
         __hip_atomic_store(&part[2 * w], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store((int *)&part[2 * w + 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (the partials are device-scope atomic stores: acknowledged -- a workgroup-scope release waits for that -- is visible)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
+        // The partials must have ARRIVED before this workgroup is counted.  A workgroup-scope release fence does not do that
+        // (it compiles to no wait at all on gfx950: the stores and the counter add left unordered, other L2 channels): the one
+        // counting thread drains its stores explicitly and bumps the counter as an agent-scope release; the last arriver
+        // acquires before it reads (tests/test_abi_and_host.py checks the wait in the ISA).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
     }
     last = __shfl(last, 0);
     if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int k = threadIdx.x < MCC_LOSS_WGS ? threadIdx.x : 0;
     const float pl = __hip_atomic_load(&part[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int pc = __hip_atomic_load((int *)&part[2 * k + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -916,16 +920,19 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     // the adds go to MCC_COL_REPL replicas instead, and the last workgroup to arrive folds the replicas into colsum
     float *rep = colpart + (blockIdx.x % MCC_COL_REPL) * 256;
     for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&rep[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
-    // The adds are device-scope atomics, performed where all CUs meet: it is enough that they have been ACKNOWLEDGED before this
-    // workgroup is counted (a workgroup-scope release = wait for the thread's outstanding memory operations; an agent-scope fence
-    // in every thread writes the L2 back 65 000 times and doubled the launch)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // The adds are device-scope atomics, performed where all CUs meet: they must have been ACKNOWLEDGED before this workgroup
+    // is counted.  Every wave drains its own (`s_waitcnt vmcnt(0)`; a workgroup-scope release fence compiles to no wait on
+    // gfx950 and left a late add free to land behind the counter, or in a replica already folded and zeroed), the barrier
+    // collects the waves, and thread 0 alone counts with an agent-scope release (one L2 write-back per workgroup; the same
+    // fence in every thread wrote the L2 back 65 000 times and doubled the launch).  The last arriver acquires before it reads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int last;
     unsigned *cnt = (unsigned *)(colpart + MCC_COL_REPL * 256);
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
     __syncthreads();
     if (!last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     for (int j = threadIdx.x; j < Lp; j += 256) {
         float v[MCC_COL_REPL];
 #pragma unroll

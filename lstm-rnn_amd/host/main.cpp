@@ -26,6 +26,14 @@ namespace {
 
 enum data_set_type { DATA_SET_TRAINING, DATA_SET_VALIDATION, DATA_SET_TEST, DATA_SET_FEEDFORWARD };
 
+// The driver's test hooks (CN_DP_FORCE, CN_DP_SAME_DEVICE, CN_DP_TEST_FAIL_RANK) only exist under the master switch
+// CN_TEST_HOOKS=1: a compute job that inherits one of those variables by accident is not affected.
+const char *testHook(const char *name)
+{
+    static const bool enabled = [] { const char *e = getenv("CN_TEST_HOOKS"); return e && atoi(e) != 0; }();
+    return enabled ? getenv(name) : nullptr;
+}
+
 // This process' place in a data-parallel run (--gpus N: one process per GPU, forked by main() before any GPU call).
 // idPipe: rank 0 writes the RCCL rendezvous id to every other rank's pipe, rank r > 0 reads its own.
 struct DataParallel {
@@ -238,7 +246,7 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
                                           config.weightsDistributionNormalMean(), config.randomSeed() };
         // one rank per GPU: device --device + rank.  CN_DP_SAME_DEVICE=1 (tests on a one-GPU box, together with the library's
         // CN_COMM_BACKEND=ipc): every rank on --device
-        const bool sameDevice = dp.active && getenv("CN_DP_SAME_DEVICE") != 0;
+        const bool sameDevice = dp.active && testHook("CN_DP_SAME_DEVICE") != 0;
         NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device() + (sameDevice ? 0 : dp.rank), &wi);
         if (dp.active) {
             // rendezvous: rank 0 draws the id and hands it to the other ranks through their pipes, then every rank joins
@@ -257,7 +265,7 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
             }
             neuralNetwork.initDataParallel(id, dp.rank, dp.world);
             // test hook (tests/test_host_driver.py): this rank gives up after the rendezvous, the others are in their first exchange
-            if (getenv("CN_DP_TEST_FAIL_RANK") && atoi(getenv("CN_DP_TEST_FAIL_RANK")) == dp.rank)
+            if (testHook("CN_DP_TEST_FAIL_RANK") && atoi(testHook("CN_DP_TEST_FAIL_RANK")) == dp.rank)
                 throw std::runtime_error("test hook CN_DP_TEST_FAIL_RANK: this rank fails on purpose");
         }
         if (!trainingSet->empty() && trainingSet->outputPatternSize() != neuralNetwork.postOutputLayer().size())
@@ -367,7 +375,7 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
 // exit code = the first failing rank's (the others are terminated, they would wait in a collective for ever).
 int runDataParallel(const Configuration &config, int world)
 {
-    if (getenv("CN_DP_SAME_DEVICE"))
+    if (testHook("CN_DP_SAME_DEVICE"))
         printf("Data-parallel training with %d ranks on device %d (CN_DP_SAME_DEVICE: a test mode), %d parallel sequences per rank.\n", world, config.device(), config.parallelSequences());
     else
     printf("Data-parallel training on %d GPU%s (devices %d..%d), %d parallel sequences per GPU.\n", world, world == 1 ? "" : "s",
@@ -443,7 +451,7 @@ int main(int argc, const char *argv[])
         printf("Started in %s training mode.\n", config.hybridOnlineBatch() ? "hybrid online/batch" : "batch");   // Configuration.cpp:316
         printf("Computations run on the MI355X (libcurrennt_hip: %s, %s operands).\n", cn_version(),
                config.precision() == CN_PREC_BF16 ? "bf16" : (config.precision() == CN_PREC_BF16X3 ? "fp32 (split-bf16 x3 products)" : "fp32"));
-        const bool forceDp = getenv("CN_DP_FORCE") != 0;       // test hook: --gpus 1 through the whole data-parallel path
+        const bool forceDp = testHook("CN_DP_FORCE") != 0;       // test hook: --gpus 1 through the whole data-parallel path
         if (config.gpus() == 1 && !forceDp) return trainerMain(config);
         if (!config.trainingMode()) throw std::runtime_error("--gpus > 1 is a training option");
         return runDataParallel(config, config.gpus());

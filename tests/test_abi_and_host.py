@@ -155,3 +155,45 @@ def test_persistent_gemm_never_touches_its_bias_registers_before_a_counted_wait_
             for k, l in enumerate(lines):
                 if not (region[0] <= k < region[1]) and re.match(r"\s*s_c?branch\w*\s+%s\b" % re.escape(name), l):
                     raise AssertionError(("a branch enters the region between the bias load and its wait", l))
+
+
+def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_counted(tmp_path):
+    """softmax_mcc_bwd_kernel hands its column-sum replicas (float atomics) and, through rowstat_reduce_wave, its loss partials
+    (stores) to the last workgroup to arrive at a counter.  That is only sound when the adds / stores have been acknowledged before
+    the counter is bumped: in the ISA an `s_waitcnt vmcnt(0)` must sit between the last replica add (partial store) and the counter
+    atomic, the counter atomic must be preceded by an L2 write-back (agent-scope release, one thread per workgroup) and the reader
+    must invalidate (`buffer_inv sc1`) before its loads.  (A workgroup-scope release fence compiled to nothing here in round 4.)"""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "ew.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(root, "lstm-rnn_amd", "csrc", "cn_elementwise.hip")], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w*softmax_mcc_bwd_kernel\w*:", l)]
+    assert len(starts) == 2                                  # F32 = false / true
+    for st in starts:
+        end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        body = [l.strip() for l in lines[st:end]]
+        counters = [k for k, l in enumerate(body) if re.match(r"global_atomic_add v\d+, v\d+, v\d+, s\[", l)]   # returning u32 adds
+        assert len(counters) == 2, counters                  # the loss partials' counter, the replicas' counter
+        for k in counters:
+            # the release of the counting thread: write-back + drain directly in front of the counter
+            head = body[max(0, k - 4):k]
+            assert any(l.startswith("buffer_wbl2") for l in head) and any("s_waitcnt vmcnt(0)" in l for l in head), head
+            # the acquire of the last arriver behind it
+            tail = body[k:k + 40]
+            assert any(l.startswith("buffer_inv sc1") for l in tail), tail
+        # loss partials: two dword stores, then a drain, then the counter -- in straight-line code
+        k0 = counters[0]
+        stores = [k for k in range(max(0, k0 - 24), k0) if body[k].startswith("global_store_dword")]
+        assert len(stores) == 2
+        assert any("s_waitcnt vmcnt(0)" in body[k] for k in range(stores[-1], k0))
+        # replicas: float adds, then every wave's own drain IN FRONT of the barrier that precedes the counter
+        k1 = counters[1]
+        adds = [k for k in range(k1) if body[k].startswith("global_atomic_add_f32")]
+        assert adds
+        barrier = max(k for k in range(adds[-1], k1) if body[k] == "s_barrier")
+        assert any("s_waitcnt vmcnt(0)" in body[k] for k in range(adds[-1], barrier)), body[adds[-1]:barrier + 1]

@@ -256,7 +256,7 @@ def test_driver_data_parallel_path_one_rank(pkg, tmp_path, stochastic):
     a = subprocess.run(common + ["--save_network", plain], capture_output=True, text=True, timeout=300)
     assert a.returncode == 0, a.stdout + a.stderr
     b = subprocess.run(common + ["--gpus", "1", "--save_network", dp], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, CN_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+                       env=dict(os.environ, CN_TEST_HOOKS="1", CN_DP_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert b.returncode == 0, b.stdout + b.stderr
     assert "Data-parallel training on 1 GPU" in b.stdout
     rows = lambda out: [l.split("|")[2:5] for l in out.splitlines() if l.strip()[:1].isdigit() and "|" in l]
@@ -329,7 +329,7 @@ def _error_rows(out):
     return rows
 
 
-TWO_RANK_ENV = dict(CN_COMM_BACKEND="ipc", CN_DP_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CN_COMM_IPC_TIMEOUT="60")
+TWO_RANK_ENV = dict(CN_TEST_HOOKS="1", CN_COMM_BACKEND="ipc", CN_DP_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", CN_COMM_IPC_TIMEOUT="60")
 
 
 @pytest.mark.gpu
