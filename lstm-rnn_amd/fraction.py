@@ -71,3 +71,33 @@ def make_fractions(inputs, targets, parallel_sequences, sort_by_length=False, **
 
 def real_frames(frac):
     return int((np.asarray(frac["patTypes"]) != PATTYPE_NONE).sum())
+
+
+def truncated_pieces(length, trunc):
+    """--truncate_seq (DataSet.cpp:527-542): pieces of `trunc` steps while MORE than 1.5 * trunc steps remain, the remainder
+    (0.5 .. 1.5 * trunc steps) as the last piece; trunc <= 0 keeps the sequence whole."""
+    out = []
+    length = int(length)
+    while length > 0:
+        n = min(trunc, length) if (trunc > 0 and length > 1.5 * trunc) else length
+        out.append(n)
+        length -= n
+    return out
+
+
+def load_sequences(files, fraction=1.0, truncate_seq=0):
+    """The sequence list data_sets::DataSet builds from its files (DataSet.cpp:443-606), before the length sort.
+    files: list of (inputs, targets) pairs, one per NetCDF file, each a list of per-sequence arrays in file order.
+    fraction: --train_fraction etc.: the first max(int(float32(numSeqs) * float32(fraction)), 1) sequences of EVERY file
+    (:518-520).  Returns (inputs, targets, info) with info[i] = (file index, sequence index in the file, piece number)."""
+    if not (0 < fraction <= 1):
+        raise ValueError("Invalid fraction")                                         # :457-458
+    xs, ts, info = [], [], []
+    for fi, (fx, ft) in enumerate(files):
+        n_seq = max(int(np.float32(len(fx)) * np.float32(fraction)), 1)
+        for si in range(n_seq):
+            pos = 0
+            for k, n in enumerate(truncated_pieces(len(fx[si]), truncate_seq)):
+                xs.append(np.asarray(fx[si])[pos:pos + n]); ts.append(np.asarray(ft[si])[pos:pos + n]); info.append((fi, si, k))
+                pos += n
+    return xs, ts, info

@@ -1,5 +1,6 @@
 #include "Configuration.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 #include <sstream>
@@ -106,6 +107,7 @@ void Configuration::apply(const std::string &key, const std::string &v)
     else if (key == "dp_rank") m_dpRank = atoi(v.c_str());
     else if (key == "dp_world") m_dpWorld = atoi(v.c_str());
     else if (key == "dump_fractions") m_dumpFractions = toBool(key, v);
+    else if (key == "dump_epochs") m_dumpEpochs = std::max(1, atoi(v.c_str()));
     else if (key == "input_noise_sigma") m_inputNoiseSigma = (real_t)atof(v.c_str());
     else if (key == "weight_noise_sigma") m_weightNoiseSigma = (real_t)atof(v.c_str());
     else if (key == "input_left_context") m_inputLeftContext = atoi(v.c_str());

@@ -60,6 +60,7 @@ public:
     int dpWorld() const { return m_dpWorld; }
     bool help() const { return m_help; }
     bool dumpFractions() const { return m_dumpFractions; }
+    int dumpEpochs() const { return m_dumpEpochs; }
     // data/noise options of Configuration.cpp:139-146,171-176
     real_t inputNoiseSigma() const { return m_inputNoiseSigma; }
     real_t weightNoiseSigma() const { return m_weightNoiseSigma; }
@@ -76,6 +77,7 @@ public:
     static const char *usage();
 
 private:
+    int m_dumpEpochs = 1;
     bool m_dumpFractions = false, m_autosave = false, m_autosaveBest = false;
     real_t m_inputNoiseSigma = 0, m_weightNoiseSigma = 0;
     int m_inputLeftContext = 0, m_inputRightContext = 0, m_outputTimeLag = 0;

@@ -11,6 +11,17 @@ namespace data_sets {
 
 DataSet::DataSet() {}
 
+// --truncate_seq (DataSet.cpp:527-542): a sequence is cut into pieces of `trunc` steps for as long as MORE than 1.5 x trunc
+// steps remain; what remains then (0.5 .. 1.5 x trunc steps) is the last piece.  trunc <= 0: one piece.
+std::vector<int> DataSet::truncatedPieces(int length, int trunc)
+{
+    std::vector<int> pieces;
+    if (trunc > 0)
+        for (; length > 1.5 * trunc; length -= trunc) pieces.push_back(trunc);
+    if (length > 0) pieces.push_back(length);
+    return pieces;
+}
+
 DataSet::~DataSet()
 {
     if (m_prefetch.valid()) m_prefetch.wait();
@@ -47,19 +58,14 @@ DataSet::DataSet(const std::vector<std::string> &ncfiles, int parSeq, real_t fra
         std::vector<int> lengths = nc.readInts("seqLengths", 0, nSeq);
         std::vector<sequence_t> sequences;
         for (int i = 0; i < nSeq; ++i) {
-            int seqLength = lengths[i];
-            m_totalTimesteps += seqLength;
+            m_totalTimesteps += lengths[i];
             std::string seqTag = nc.readString("seqTags", i, maxSeqTagLength);
-            int k = 0;
-            while (seqLength > 0) {                                                            // truncation, :530-546
+            const std::vector<int> pieces = truncatedPieces(lengths[i], truncSeqLength);
+            for (size_t k = 0; k < pieces.size(); ++k) {
                 sequence_t seq;
-                seq.originalSeqIdx = k;
-                if (truncSeqLength > 0 && seqLength > 1.5 * truncSeqLength) seq.length = std::min(truncSeqLength, seqLength);
-                else seq.length = seqLength;
-                seq.seqTag = seqTag; seq.inputsBegin = 0; seq.targetsBegin = 0;
+                seq.originalSeqIdx = (int)k; seq.length = pieces[k]; seq.seqTag = seqTag;
+                seq.inputsBegin = 0; seq.targetsBegin = 0;
                 sequences.push_back(seq);
-                seqLength -= seq.length;
-                ++k;
             }
         }
         size_t frames = 0;

@@ -93,6 +93,7 @@ private:
     DataSetFraction m_next;
     bool produceNext(DataSetFraction *frac);
 
+    static std::vector<int> truncatedPieces(int length, int trunc);   // --truncate_seq, DataSet.cpp:527-542
     void makeFraction(int firstSeqIdx, DataSetFraction *frac);        // _makeFractionTask, DataSet.cpp:300-414
     void shuffleSequences();                                          // :226-230
     void shuffleFractions();                                          // :232-250

@@ -217,20 +217,31 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
         if (config.dumpFractions()) {     // host-only check of reader + packer (no GPU needed)
             data_sets::DataSet &ds = config.trainingMode() ? *trainingSet : *feedForwardSet;
             data_sets::DataSetFraction frac;
-            int idx = 0;
-            while (ds.getNextFraction(&frac)) {
-                double sx = 0; long st = 0; int none = 0;
-                for (size_t i = 0; i < frac.inputs().size(); ++i) sx += frac.inputs()[i];
-                for (size_t i = 0; i < frac.targetClasses().size(); ++i) if (frac.targetClasses()[i] >= 0) st += frac.targetClasses()[i];
-                for (size_t i = 0; i < frac.outputs().size(); ++i) sx += 1000.0 * frac.outputs()[i];
-                for (size_t i = 0; i < frac.patTypes().size(); ++i) none += frac.patTypes()[i] == PATTYPE_NONE;
-                // tags = the sequences of the fraction, slot by slot (the length sort is std::sort like the reference's,
-                // DataSet.cpp:603-605: ties land in an implementation-defined order, which a checker has to be told)
-                std::string order;
-                for (int i = 0; i < frac.numSequences(); ++i) order += (i ? "," : "") + frac.seqInfo(i).seqTag;
-                printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s tags=%s\n", idx++, frac.maxSeqLength(),
-                       frac.minSeqLength(), frac.numSequences(), none, sx, st, frac.numSequences() ? frac.seqInfo(0).seqTag.c_str() : "-",
-                       frac.numSequences() ? order.c_str() : "-");
+            // --dump_epochs N: N passes over the set (the shuffles of --shuffle_sequences / --shuffle_fractions run at the start
+            // of every pass, DataSet.cpp:416-427)
+            for (int epoch = 0; epoch < config.dumpEpochs(); ++epoch) {
+                if (config.dumpEpochs() > 1) printf("EPOCH %d\n", epoch);
+                int idx = 0;
+                while (ds.getNextFraction(&frac)) {
+                    double sx = 0; long st = 0; int none = 0;
+                    for (size_t i = 0; i < frac.inputs().size(); ++i) sx += frac.inputs()[i];
+                    for (size_t i = 0; i < frac.targetClasses().size(); ++i) if (frac.targetClasses()[i] >= 0) st += frac.targetClasses()[i];
+                    for (size_t i = 0; i < frac.outputs().size(); ++i) sx += 1000.0 * frac.outputs()[i];
+                    for (size_t i = 0; i < frac.patTypes().size(); ++i) none += frac.patTypes()[i] == PATTYPE_NONE;
+                    // tags / lens / pieces = the sequences of the fraction, slot by slot: tag, length and piece number under
+                    // --truncate_seq (the length sort is std::sort like the reference's, DataSet.cpp:603-605: ties land in an
+                    // implementation-defined order, which a checker has to be told)
+                    std::string order, lens, pieces;
+                    for (int i = 0; i < frac.numSequences(); ++i) {
+                        order += (i ? "," : "") + frac.seqInfo(i).seqTag;
+                        lens += (i ? "," : "") + std::to_string(frac.seqInfo(i).length);
+                        pieces += (i ? "," : "") + std::to_string(frac.seqInfo(i).originalSeqIdx);
+                    }
+                    const bool any = frac.numSequences() > 0;
+                    printf("FRACTION %d T=%d Tmin=%d seqs=%d none=%d sum_inputs=%.6f sum_targets=%ld first_tag=%s tags=%s lens=%s pieces=%s\n", idx++,
+                           frac.maxSeqLength(), frac.minSeqLength(), frac.numSequences(), none, sx, st, any ? frac.seqInfo(0).seqTag.c_str() : "-",
+                           any ? order.c_str() : "-", any ? lens.c_str() : "-", any ? pieces.c_str() : "-");
+                }
             }
             return 0;
         }
