@@ -244,6 +244,16 @@ int  cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum);
  * backward pass before it.  Not for batch learning (the epoch sum is formed first) nor with weight noise.        [async] */
 int  cn_ctx_arm_update(cn_ctx *ctx, float learning_rate, float momentum);
 
+/* Batch learning (`--stochastic false`): Optimizer.cu:72-85 sums the fractions' weightUpdates of an epoch on the DEVICE
+ * (thrust::copy for the first fraction, thrust::transform(plus) for the others) and updates once per epoch (:95-97).
+ * cn_ctx_accumulate_updates adds the weightUpdates of ALL layers, as the backward pass of the current fraction left them, to
+ * the context's epoch accumulator in one launch (first != 0: copies instead, the reference's `firstFraction` branch);
+ * cn_ctx_take_accumulated makes the epoch sum the weightUpdates of every layer again -- what SteepestDescentOptimizer.cu:83-85
+ * reads through `_curWeightUpdates()` -- in front of cn_allreduce_grads(ctx, NULL, 0) / cn_sgd_update*.  Nothing leaves the
+ * device and nothing synchronises.                                                                               [async] */
+int  cn_ctx_accumulate_updates(cn_ctx *ctx, int first);
+int  cn_ctx_take_accumulated(cn_ctx *ctx);
+
 /* ---- data-parallel training over the GPUs of one node (no counterpart in the reference, which
  *      drives a single device: main.cpp:526-541) ------------------------------------------------------------
  * One process (or thread) per GPU, one cn_ctx each.  The parallel sequences of a fraction are independent, so

@@ -33,7 +33,7 @@ EXPORTS = [
     "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_fraction_prefetch_resident", "cn_layer_forward",
     "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
-    "cn_sgd_update_all", "cn_ctx_arm_update", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
+    "cn_sgd_update_all", "cn_ctx_arm_update", "cn_ctx_accumulate_updates", "cn_ctx_take_accumulated", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
     "cn_layer_recurrent_kernel",
     "cn_comm_unique_id", "cn_comm_init", "cn_comm_destroy", "cn_comm_info", "cn_allreduce_grads", "cn_loss_read_global",
     # include/currennt_hip_debug.h
@@ -124,6 +124,8 @@ def load_library():
     L.cn_sgd_update.argtypes = [vp, cf, cf]
     L.cn_sgd_update_all.argtypes = [vp, cf, cf]
     L.cn_ctx_arm_update.argtypes = [vp, cf, cf]
+    L.cn_ctx_accumulate_updates.argtypes = [vp, ci]
+    L.cn_ctx_take_accumulated.argtypes = [vp]
     L.cn_ctx_timing_enable.argtypes = [vp, ci]
     L.cn_ctx_timing_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.cn_ctx_timing_reset.argtypes = [vp]

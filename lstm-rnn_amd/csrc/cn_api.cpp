@@ -130,6 +130,8 @@ struct cn_ctx {
     // parameter arena [weights | weightUpdates | weightDeltas]
     bool finalized = false;
     float *arena = nullptr;
+    float *acc = nullptr;                 // epoch sum of weightUpdates (batch learning, cn_ctx_accumulate_updates); [total]
+    bool acc_valid = false;
     size_t total = 0;
 
     // timing
@@ -887,7 +889,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         for (int k = 0; k < KC_COUNT; ++k) for (auto &sp : ctx->spans[k]) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
         for (hipEvent_t e : ctx->free_events) hipEventDestroy(e);
         hipFree(ctx->pf.pat_raw); hipFree(ctx->pf.tcls); hipFree(ctx->d_colpart);
-        hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
+        hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->acc); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
     });
@@ -1764,6 +1766,35 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
         Timed tm(c, KC_OTHER);
         launch_sgd(c->stream, layer->w, layer->wu, layer->wd, (size_t)layer->nw, learning_rate, momentum);
         layer->dirty = true;
+    });
+}
+
+int cn_ctx_accumulate_updates(cn_ctx *ctx, int first)
+{
+    if (!ctx) { g_last_error = "cn_ctx_accumulate_updates: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        finalize(ctx);
+        if (ctx->armed) throw cn_error(CN_ERR_STATE, "cn_ctx_accumulate_updates: an armed per-fraction update is pending (batch learning sums first, cn_ctx_arm_update is not for it)");
+        if (!first && !ctx->acc_valid) throw cn_error(CN_ERR_STATE, "cn_ctx_accumulate_updates: nothing accumulated yet (the first fraction of an epoch passes first != 0)");
+        join_side(ctx);                     // the gradient GEMMs / unpack launches of the side streams write weightUpdates
+        if (!ctx->acc) HIP_CHECK(hipMalloc((void **)&ctx->acc, ctx->total * sizeof(float)));
+        Timed tm(ctx, KC_OTHER);
+        launch_accumulate(ctx->stream, ctx->acc, ctx->arena + ctx->total, ctx->total, first != 0);
+        ctx->acc_valid = true;
+    });
+}
+
+int cn_ctx_take_accumulated(cn_ctx *ctx)
+{
+    if (!ctx) { g_last_error = "cn_ctx_take_accumulated: ctx is NULL"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        HIP_CHECK(hipSetDevice(ctx->device));
+        finalize(ctx);
+        if (!ctx->acc_valid) throw cn_error(CN_ERR_STATE, "cn_ctx_take_accumulated: nothing accumulated (cn_ctx_accumulate_updates)");
+        join_side(ctx);
+        HIP_CHECK(hipMemcpyAsync(ctx->arena + ctx->total, ctx->acc, ctx->total * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->acc_valid = false;
     });
 }
 

@@ -1239,6 +1239,20 @@ void launch_sum_ranks(hipStream_t s, float *dst, const SumRanks &sr, size_t n)
     if (n) hipLaunchKernelGGL(sum_ranks_kernel, dim3((unsigned)((n + 1023) / 1024 > 512 ? 512 : (n + 1023) / 1024)), dim3(256), 0, s, dst, sr, n);
 }
 
+// Batch learning: the epoch sum of the fractions' weightUpdates (Optimizer.cu:72-85: thrust::copy for the first fraction,
+// thrust::transform(plus) for the others -- one launch over the whole arena instead of one per layer).
+__global__ void accumulate_kernel(float *acc, const float *wu, size_t n, int first)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        acc[i] = first ? wu[i] : __fadd_rn(acc[i], wu[i]);
+}
+void launch_accumulate(hipStream_t s, float *acc, const float *wu, size_t n, bool first)
+{
+    if (n == 0) return;
+    int blocks = (int)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(accumulate_kernel, dim3(blocks), dim3(256), 0, s, acc, wu, n, first ? 1 : 0);
+}
+
 __global__ void sgd_kernel(float *w, const float *wu, float *wd, size_t n, float lr, float mom)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

@@ -204,6 +204,7 @@ void ipc_comm_mark_failed(IpcComm *c);
 void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st);
 void ipc_allreduce_loss(IpcComm *c, float *err, int *correct);
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);
+void launch_accumulate(hipStream_t s, float *acc, const float *wu, size_t n, bool first);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]
 // (host row n = t*PS + s maps to device row t*PSp + s)
 void launch_unpad(hipStream_t s, bool src_is_bf16, const void *src, long ld, int col0, int cstride, int N, int L, float *dst, long ldd, int dcol0, int PS, int PSp);

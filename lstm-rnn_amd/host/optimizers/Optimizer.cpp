@@ -19,7 +19,6 @@ Optimizer::Optimizer(NeuralNetwork &neuralNetwork, data_sets::DataSet &trainingS
 {
     m_neuralNetwork.setExchangePerFraction(hybridOnlineBatch);
     m_bestWeights.resize(m_neuralNetwork.layers().size());
-    m_curWeightUpdates.resize(m_neuralNetwork.layers().size());
     _storeWeights();
 }
 
@@ -88,14 +87,9 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
             if (m_hybridOnlineBatch) {
                 _updateWeights();                                           // Optimizer.cu:88-89
             } else {
-                // batch learning: sum the fractions' weightUpdates, one update per epoch (:72-85, :95-97)
-                for (size_t i = 1; i + 1 < ls.size(); ++i) {
-                    layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
-                    if (!layer) continue;
-                    Hip::real_vector wu = layer->weightUpdates();
-                    if (firstFraction) m_curWeightUpdates[i] = wu;
-                    else for (size_t k = 0; k < wu.size(); ++k) m_curWeightUpdates[i][k] += wu[k];
-                }
+                // batch learning: sum the fractions' weightUpdates, one update per epoch (:72-85, :95-97) -- on the device,
+                // one launch over all layers, like the reference's thrust::copy / thrust::transform(plus)
+                hipCheck(cn_ctx_accumulate_updates(m_neuralNetwork.context(), firstFraction ? 1 : 0), m_neuralNetwork.context());
             }
         }
         firstFraction = false;
@@ -285,13 +279,9 @@ void SteepestDescentOptimizer::_updateWeights()
     NeuralNetwork &nn = _neuralNetwork();
     const std::vector<std::shared_ptr<layers::Layer> > &ls = nn.layers();
     if (!hybridOnlineBatch()) {
-        // batch mode: the epoch sum replaces the device weightUpdates before the update; data-parallel ranks then add
-        // their epoch sums up in one exchange over the whole arena
-        for (size_t i = 1; i + 1 < ls.size(); ++i) {
-            layers::TrainableLayer *layer = dynamic_cast<layers::TrainableLayer *>(ls[i].get());
-            if (!layer) continue;
-            hipCheck(cn_layer_upload(layer->handle(), CN_BUF_WEIGHT_UPDATES, _curWeightUpdates()[i].data(), _curWeightUpdates()[i].size()), nn.context());
-        }
+        // batch mode: the epoch sum becomes the weightUpdates again before the update (device to device); data-parallel ranks
+        // then add their epoch sums up in one exchange over the whole arena
+        hipCheck(cn_ctx_take_accumulated(nn.context()), nn.context());
         if (nn.dataParallel()) hipCheck(cn_allreduce_grads(nn.context(), 0, 0), nn.context());
     }
     for (size_t i = 1; i + 1 < ls.size(); ++i) {

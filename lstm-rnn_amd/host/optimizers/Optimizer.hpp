@@ -52,8 +52,8 @@ protected:
     void _storeWeights();                                               // :151-158
     void _restoreWeights();                                             // :160-168
     NeuralNetwork &_neuralNetwork() { return m_neuralNetwork; }
-    // accumulated weightUpdates of the epoch (batch mode); per layer, reference layout
-    std::vector<Hip::real_vector> &_curWeightUpdates() { return m_curWeightUpdates; }
+    // (the reference's `_curWeightUpdates()`, the epoch sum of batch learning, lives on the device: cn_ctx_accumulate_updates /
+    // cn_ctx_take_accumulated)
 
 private:
     NeuralNetwork &m_neuralNetwork;
@@ -64,7 +64,7 @@ private:
     int m_curEpoch, m_epochsSinceLowestError;
     real_t m_lowestValidationError, m_curTrainingError, m_curValidationError, m_curTestError,
            m_curValidationClassError, m_curTrainingClassError, m_curTestClassError;
-    std::vector<Hip::real_vector> m_curWeightUpdates, m_bestWeights;
+    std::vector<Hip::real_vector> m_bestWeights;
     real_t m_weightNoiseSigma = 0;
     std::mt19937 m_noiseGen;
 protected:

@@ -350,6 +350,15 @@ class NeuralNetwork:
         """One launch for all layers; layers with a JSON learningRate of their own keep it (cn_layer_set_learning_rate)."""
         B.check(self.lib.cn_sgd_update_all(self.ctx, learning_rate, momentum), self.ctx)
 
+    def accumulate_updates(self, first):
+        """Batch learning (Optimizer.cu:72-85): add this fraction's weightUpdates of all layers to the epoch sum on the device
+        (`first`: copy instead of add)."""
+        B.check(self.lib.cn_ctx_accumulate_updates(self.ctx, 1 if first else 0), self.ctx)
+
+    def take_accumulated(self):
+        """The epoch sum becomes every layer's weightUpdates again (in front of the one update of the epoch, :95-97)."""
+        B.check(self.lib.cn_ctx_take_accumulated(self.ctx), self.ctx)
+
     def outputs(self):
         """Output layer activations [T][PS][C] (NeuralNetwork.cpp:237-262 de-interleaves per sequence)."""
         return self.output_layer().outputs()

@@ -214,6 +214,93 @@ def test_sgd_momentum_steps(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
 
 
+def test_weight_noise_perturbs_the_backward_pass_only(pkg, orc):
+    """Q9 (Optimizer.cu:47-50,59-70,83-84): forward pass and error on the CLEAN weights, `injectWeightNoise`, backward pass on
+    the NOISY weights (every product with a weight in it: the BPTT products, the error to the preceding layer; the gradients
+    themselves are activations x deltas), clean weights restored BEFORE the update, update applied to the clean weights.
+    Through the C ABI (cn_layer_set_weights between the passes) against the oracle doing the same with the same noise vectors.
+    Three stochastic steps; the counter-example (noise injected BEFORE the forward pass) must differ visibly."""
+    rng = np.random.RandomState(77)
+    P, C, PS, sigma = 5, 4, 3, 0.1
+    layers = net_desc(P, [("blstm", 12), ("lstm", 7)], C)
+    weights = random_weights(layers, rng, 0.3)
+    ref = orc.OracleNetwork(layers, weights, PS, 12)
+    wrong = orc.OracleNetwork(layers, weights, PS, 12)
+    with pkg.NeuralNetwork(layers, weights, PS, 12) as net:
+        for step in range(3):
+            xs, ts = random_sequences(rng, [12, 8, 5], P, C=C)
+            frac = pkg.make_fraction(xs, ts, PS)
+            noise = {l.name: rng.normal(0.0, sigma, l.weights.size).astype(np.float32) for l in ref.trainable_layers()}
+            # reference protocol on the oracle
+            ref.load_sequences(frac); ref.compute_forward_pass(); e_ref = ref.calculate_error()
+            clean = {l.name: l.weights.copy() for l in ref.trainable_layers()}
+            for l in ref.trainable_layers():
+                l.weights += noise[l.name]                                   # TrainableLayer.cu:188-209
+            ref.compute_backward_pass()
+            for l in ref.trainable_layers():
+                l.weights[:] = clean[l.name]
+            ref.update_weights(1e-2, 0.9)
+            # the same calls through the C ABI
+            net.load_sequences(frac); net.compute_forward_pass(); e, _ = net.error_and_correct()
+            assert abs(e - e_ref) < 1e-4 * max(1.0, abs(e_ref))                # the forward pass saw the clean weights
+            for lay in net.trainable_layers():
+                assert np.array_equal(lay.weights(), clean[lay.name]) or np.abs(lay.weights() - clean[lay.name]).max() < 5e-6
+                lay.set_weights(lay.weights() + noise[lay.name])
+            net.compute_backward_pass()
+            for lay in net.trainable_layers():
+                assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 2e-4, (step, lay.name)
+            net.join()                                                         # the gradient products still read the noisy operands
+            for lay in net.trainable_layers():
+                lay.set_weights(clean[lay.name])
+            net.update_weights(1e-2, 0.9)
+            for lay in net.trainable_layers():
+                assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (step, lay.name)
+            # counter-example: noise in front of the forward pass
+            wrong.load_sequences(frac)
+            for l in wrong.trainable_layers():
+                l.weights[:] = clean[l.name] + noise[l.name]
+            wrong.compute_forward_pass(); e_wrong = wrong.calculate_error(); wrong.compute_backward_pass()
+            assert abs(e_wrong - e_ref) > 1e-3 * abs(e_ref)
+            assert max(rel_err(l.weightUpdates, ref.layer(l.name).weightUpdates) for l in wrong.trainable_layers()) > 1e-2
+            for l in wrong.trainable_layers():
+                l.weights[:] = ref.layer(l.name).weights
+
+
+def test_batch_accumulation_on_the_device(pkg, orc):
+    """Batch learning (Optimizer.cu:72-85,95-97): cn_ctx_accumulate_updates sums the fractions' weightUpdates on the device
+    (first fraction: copy), cn_ctx_take_accumulated hands the sum to the one update of the epoch.  Two epochs of three
+    fractions against the oracle summing in the same order; call-order errors are reported, not ignored."""
+    rng = np.random.RandomState(78)
+    P, C, PS = 5, 4, 3
+    layers = net_desc(P, [("blstm", 12), ("feedforward_tanh", 6)], C)
+    weights = random_weights(layers, rng, 0.3)
+    fracs = [pkg.make_fraction(*random_sequences(rng, lens, P, C=C), PS) for lens in ([12, 8, 5], [9, 9], [4, 11, 7])]
+    ref = orc.OracleNetwork(layers, weights, PS, 12)
+    with pkg.NeuralNetwork(layers, weights, PS, 12) as net:
+        with pytest.raises(pkg.CurrenntHipError):
+            net.take_accumulated()                                             # nothing accumulated
+        with pytest.raises(pkg.CurrenntHipError):
+            net.accumulate_updates(False)                                      # an epoch starts with first = True
+        for epoch in range(2):
+            acc = None
+            for k, f in enumerate(fracs):
+                for n in (ref, net):
+                    n.load_sequences(f); n.compute_forward_pass(); n.compute_backward_pass()
+                g = [l.weightUpdates.copy() for l in ref.trainable_layers()]
+                acc = g if acc is None else [a + b for a, b in zip(acc, g)]
+                net.accumulate_updates(k == 0)
+            for l, a in zip(ref.trainable_layers(), acc):
+                l.weightUpdates[:] = a
+            net.take_accumulated()
+            for lay in net.trainable_layers():
+                assert rel_err(lay.weight_updates(), ref.layer(lay.name).weightUpdates) < 2e-4, (epoch, lay.name)
+            ref.update_weights(1e-2, 0.9); net.update_weights_fused(1e-2, 0.9)
+            for lay in net.trainable_layers():
+                assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 1e-5, (epoch, lay.name)
+        with pytest.raises(pkg.CurrenntHipError):
+            net.take_accumulated()                                             # the sum was taken
+
+
 @pytest.mark.parametrize("hidden", [[64, 64], [300], [384, 320], [440], [600]])
 def test_bf16_mode_close(pkg, orc, hidden):
     """Throughput mode (bf16 MFMA operands, fp32 accumulate/state): not a parity mode; posteriors

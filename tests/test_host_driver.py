@@ -379,3 +379,163 @@ def test_driver_two_ranks_one_fails(pkg, tmp_path):
     assert "rank 1: FAILED: test hook" in out.stderr and "rank 1 exited with code 2" in out.stderr
     assert not os.path.exists(str(tmp_path / "x.jsn"))
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("cn_ipc_")]          # the rendezvous segment is gone
+
+
+def _learnable(rng, n, P, C, flip, lo=4, hi=15):
+    """sequences whose class is the argmax of the first C inputs, a share `flip` of the labels drawn at random"""
+    xs = [rng.randn(k, P).astype(np.float32) for k in rng.randint(lo, hi, n)]
+    ts = []
+    for x in xs:
+        t = np.argmax(x[:, :C], 1).astype(np.int32)
+        m = rng.rand(len(t)) < flip
+        t[m] = rng.randint(0, C, m.sum())
+        ts.append(t)
+    return xs, ts
+
+
+def _oracle_set_error(ref, fracs, n_seqs):
+    """Optimizer::_processDataSet without updates (Optimizer.cu:46-55,99-101): float sum of the fractions' errors / #sequences,
+    class error = 1 - correct / timesteps"""
+    e, correct, steps = np.float32(0), 0, 0
+    for f in fracs:
+        ref.load_sequences(f); ref.compute_forward_pass()
+        e = np.float32(e + np.float32(ref.calculate_error()))
+        correct += ref.count_correct_classifications()
+        steps += int((f["patTypes"] != 0).sum())
+    return float(e / np.float32(n_seqs)), 1.0 - correct / steps
+
+
+def _table_rows(out):
+    """the cells of every epoch row: (epoch, training, validation, test, new best) as stripped strings"""
+    rows = []
+    for l in out.splitlines():
+        if l.strip()[:1].isdigit() and l.count("|") >= 5:
+            c = [x.strip() for x in l.split("|")]
+            rows.append((int(c[0]), c[2], c[3], c[4], c[5]))
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("validate_every", [1, 2])
+def test_driver_early_stopping_restores_the_best_weights(pkg, orc, tmp_path, validate_every):
+    """Optimizer::train (Optimizer.cu:283-324) with a validation set that gets WORSE: the epochs' validation errors decide
+    "New best" (yes / no), the weights of the best epoch are stored (`_storeWeights`, :152-160), training stops once
+    `max_epochs_no_best` epochs brought no new lowest error, the stored weights are restored (`_restoreWeights`, :162-170)
+    BEFORE the network is saved, and the driver says so (main.cpp:282-291).  The oracle is driven through the same protocol;
+    the saved network must be the oracle's BEST-epoch weights, not its last ones.  Also: `--test_file` + `--test_every 2`
+    (the test column, :305-307) and `--validate_every 2` (the counter moves by validate_every, :299)."""
+    rng = np.random.RandomState(2)
+    P, C, PS = 6, 4, 3
+    layers = net_desc(P, [("blstm", 8), ("feedforward_tanh", 5)], C)
+    weights = random_weights(layers, rng, 0.3)
+    xtr, ttr = _learnable(rng, 6, P, C, 0.0)
+    xv, tv = _learnable(rng, 5, P, C, 0.3)
+    xte, tte = _learnable(rng, 4, P, C, 0.3)
+    files = {}
+    for name, (xs, ts) in (("train", (xtr, ttr)), ("val", (xv, tv)), ("test", (xte, tte))):
+        files[name] = str(tmp_path / (name + ".nc")); write_nc(files[name], xs, ts, C)
+    net = str(tmp_path / "network.jsn")
+    json.dump({"layers": layers, "weights": {k: {a: np.asarray(b).tolist() for a, b in w.items()} for k, w in weights.items()}}, open(net, "w"))
+    lr, mom, no_best, max_epochs = 0.1, 0.9, 3, 40
+    trained = str(tmp_path / "trained.jsn")
+    out = subprocess.run([BIN, "--train", "true", "--stochastic", "true", "--train_file", files["train"], "--val_file", files["val"],
+                          "--test_file", files["test"], "--network", net, "--parallel_sequences", str(PS), "--max_epochs", str(max_epochs),
+                          "--max_epochs_no_best", str(no_best), "--validate_every", str(validate_every), "--test_every", "2",
+                          "--learning_rate", str(lr), "--momentum", str(mom), "--precision", "f32", "--save_network", trained],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    # the oracle through the same protocol
+    ftr = pkg.make_fractions(xtr, ttr, PS, sort_by_length=True)
+    fv = pkg.make_fractions(xv, tv, PS, sort_by_length=True)
+    fte = pkg.make_fractions(xte, tte, PS, sort_by_length=True)
+    ref = orc.OracleNetwork(layers, weights, PS, 20)
+    best = [l.weights.copy() for l in ref.trainable_layers()]
+    lowest, since, expect = np.inf, 0, []
+    for epoch in range(1, max_epochs + 1):
+        for f in ftr:
+            ref.load_sequences(f); ref.compute_forward_pass(); ref.compute_backward_pass(); ref.update_weights(lr, mom)
+        val = test = None
+        if epoch % validate_every == 0:
+            val = _oracle_set_error(ref, fv, len(xv))
+            if val[0] < lowest:
+                lowest, since = val[0], 0
+                best = [l.weights.copy() for l in ref.trainable_layers()]
+            else:
+                since += validate_every
+        if epoch % 2 == 0:
+            test = _oracle_set_error(ref, fte, len(xte))
+        expect.append((epoch, val, test, since == 0))
+        if since >= no_best:
+            break
+    last = [l.weights.copy() for l in ref.trainable_layers()]
+    assert 3 < len(expect) < max_epochs and not expect[-1][3]                      # the scenario: it stops early, not on a best epoch
+    assert max(np.abs(a - b).max() for a, b in zip(best, last)) > 1e-2              # ... and restoring matters
+    rows = _table_rows(out.stdout)
+    assert [r[0] for r in rows] == [e[0] for e in expect], out.stdout
+    for (ep, tr_c, val_c, test_c, best_c), (_, val, test, is_best) in zip(rows, expect):
+        if val is None:
+            assert val_c == "" and best_c == ""
+        else:
+            cls, err = (float(v.rstrip("%")) for v in val_c.split())
+            assert abs(err - val[0]) < 2e-3 * max(1.0, val[0]) + 6e-4 and abs(cls - 100 * val[1]) < 0.011, (ep, val_c, val)
+            assert best_c == ("yes" if is_best else "no"), (ep, out.stdout)
+        if test is None:
+            assert test_c == ""
+        else:
+            cls, err = (float(v.rstrip("%")) for v in test_c.split())
+            assert abs(err - test[0]) < 2e-3 * max(1.0, test[0]) + 6e-4 and abs(cls - 100 * test[1]) < 0.011, (ep, test_c, test)
+    # the counter moves in steps of validate_every: it may pass max_epochs_no_best without ever being equal to it, and the
+    # reference's message tests for equality (main.cpp:282-285)
+    msg = "No new lowest error since %d epochs. Training stopped." % no_best if since == no_best else "Maximum number of training epochs reached. Training stopped."
+    assert msg in out.stdout
+    assert "Lowest validation error: " in out.stdout
+    printed = float(out.stdout.split("Lowest validation error: ")[1].split()[0])
+    assert abs(printed - lowest) < 2e-4 * max(1.0, lowest)
+    got = _weights_of(trained)
+    for lay, b, l in zip(ref.trainable_layers(), best, last):
+        d_best, d_last = np.abs(got[lay.name] - b).max(), np.abs(got[lay.name] - l).max()
+        assert d_best < 2e-4, (lay.name, d_best)                                   # (lr 0.1 over a dozen updates amplifies fp32 order effects)
+        assert d_last > 10 * d_best or np.abs(b - l).max() < 1e-3, lay.name
+
+
+@pytest.mark.gpu
+def test_driver_without_a_validation_set_every_epoch_is_the_best(pkg, tmp_path):
+    """No validation set: every epoch stores its weights and resets the counter (Optimizer.cu:302-305), so training runs to
+    --max_epochs, ends on the LAST weights and reports the final training error (main.cpp:286-291)."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    trained = str(tmp_path / "t.jsn")
+    out = subprocess.run([BIN, "--train", "true", "--stochastic", "true", "--train_file", nc, "--network", net, "--parallel_sequences", "3",
+                          "--max_epochs", "4", "--max_epochs_no_best", "1", "--learning_rate", "1e-2", "--momentum", "0.9", "--save_network", trained],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = _table_rows(out.stdout)
+    assert [r[0] for r in rows] == [1, 2, 3, 4] and all(r[2] == "" and r[4] == "" for r in rows)
+    assert "Maximum number of training epochs reached. Training stopped." in out.stdout and "Final training set error: " in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stochastic", ["true", "false"])
+def test_driver_weight_noise_never_reaches_the_forward_pass_or_the_stored_weights(pkg, tmp_path, stochastic):
+    """Q9 at the driver (Optimizer.cu:47-84): with a learning rate of 0 the weights never move, so every epoch's training error is
+    a pure forward-pass quantity of the CLEAN weights -- a huge --weight_noise_sigma must not change a digit of the table, and the
+    saved network must be the initial one (the clean weights come back after every backward pass).  With a learning rate > 0 the
+    same noise does change the result (the backward pass saw it).  Stochastic and batch."""
+    layers, weights, xs, ts, nc, net = problem(tmp_path)
+    common = [BIN, "--train", "true", "--stochastic", stochastic, "--train_file", nc, "--network", net, "--parallel_sequences", "3",
+              "--max_epochs", "3", "--momentum", "0.9", "--random_seed", "3", "--precision", "f32"]
+    runs = {}
+    for name, extra in (("clean0", ["--learning_rate", "0"]), ("noisy0", ["--learning_rate", "0", "--weight_noise_sigma", "0.5"]),
+                        ("clean", ["--learning_rate", "1e-2"]), ("noisy", ["--learning_rate", "1e-2", "--weight_noise_sigma", "0.5"])):
+        path = str(tmp_path / (name + ".jsn"))
+        out = subprocess.run(common + extra + ["--save_network", path], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        runs[name] = ([r[1] for r in _table_rows(out.stdout)], _weights_of(path))
+    assert len(runs["clean0"][0]) == 3 and runs["noisy0"][0] == runs["clean0"][0], (runs["noisy0"][0], runs["clean0"][0])
+    assert len(set(runs["clean0"][0])) == 1                                # lr 0: the same error every epoch
+    for n in runs["clean0"][1]:
+        w0 = np.concatenate([np.asarray(weights[n][k], np.float64).reshape(-1) for k in ("input", "bias", "internal")])
+        assert np.abs(runs["noisy0"][1][n] - w0).max() < 1e-6, n           # (the JSON text carries ~7 digits)
+    if stochastic == "false":                                              # batch learning: the first update follows the first epoch's errors
+        assert runs["noisy"][0][0] == runs["clean"][0][0]
+    moved = max(np.abs(runs["noisy"][1][n] - runs["clean"][1][n]).max() for n in runs["clean"][1])
+    assert moved > 1e-4                                                    # the noisy backward passes led somewhere else
