@@ -805,10 +805,12 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
         __hip_atomic_store((int *)&part[2 * w + 1], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // The partials must have ARRIVED before this workgroup is counted.  A workgroup-scope release fence does not do that
         // (it compiles to no wait at all on gfx950: the stores and the counter add left unordered, other L2 channels): the one
-        // counting thread drains its stores explicitly and bumps the counter as an agent-scope release; the last arriver
+        // counting thread drains its stores explicitly.  They are agent-scope (sc1, write-through) stores -- acknowledged is
+        // visible to every CU --, so the wait is all a release has to add here: an agent-scope release RMW would also write the
+        // XCD's whole dirty L2 back (buffer_wbl2: the rows this launch has stored; +1.6 us on the launch).  The last arriver
         // acquires before it reads (tests/test_abi_and_host.py checks the wait in the ISA).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
+        last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MCC_LOSS_WGS - 1;
     }
     last = __shfl(last, 0);
     if (!last) return;
@@ -923,13 +925,15 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
     // The adds are device-scope atomics, performed where all CUs meet: they must have been ACKNOWLEDGED before this workgroup
     // is counted.  Every wave drains its own (`s_waitcnt vmcnt(0)`; a workgroup-scope release fence compiles to no wait on
     // gfx950 and left a late add free to land behind the counter, or in a replica already folded and zeroed), the barrier
-    // collects the waves, and thread 0 alone counts with an agent-scope release (one L2 write-back per workgroup; the same
-    // fence in every thread wrote the L2 back 65 000 times and doubled the launch).  The last arriver acquires before it reads.
+    // collects the waves, and thread 0 counts.  The wait is the whole release: what is handed over are atomics, performed where
+    // the CUs meet, not plain stores in a write-back L2 -- an agent-scope release RMW by thread 0 measured +1.6 us per launch
+    // (its buffer_wbl2 writes back the rows this launch stored; the same fence in every thread doubled the launch in round 4).
+    // The last arriver acquires before it reads.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int last;
     unsigned *cnt = (unsigned *)(colpart + MCC_COL_REPL * 256);
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
     __syncthreads();
     if (!last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

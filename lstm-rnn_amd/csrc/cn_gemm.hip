@@ -561,18 +561,24 @@ static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n)
 void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g)
 {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
+    if (gemm_tn_big_applies(prec, g)) { launch_gemm_tn_big_group(s, &g, 1); return; }
     launch_tn_any(s, prec, &g, 1);
 }
 
 void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n)
 {
-    GemmTN grp[TN_GROUP]; int ng = 0;
+    GemmTN grp[TN_GROUP], big[TN_GROUP]; int ng = 0, nb = 0;
+    bool any_big = false;
+    for (int i = 0; i < n; ++i) any_big = any_big || (gs[i].M > 0 && gs[i].N > 0 && gs[i].K > 0 && gemm_tn_big_applies(prec, gs[i]));
     for (int i = 0; i < n; ++i) {
         if (gs[i].M <= 0 || gs[i].N <= 0 || gs[i].K <= 0) continue;
+        // one grouped launch of 256 x 256 tiles for the products large enough to want them and those that can ride along
+        if (any_big && nb < TN_GROUP && gemm_tn_big_can(prec, gs[i])) { big[nb++] = gs[i]; continue; }
         const bool huge = (long)((gs[i].M + 63) / 64) * ((gs[i].N + 63) / 64) >= 2048;
         if (huge || ng == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
         else grp[ng++] = gs[i];
     }
+    if (nb) launch_gemm_tn_big_group(s, big, nb);
     if (ng) launch_tn_any(s, prec, grp, ng);
 }
 

@@ -65,6 +65,11 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = 
 bool gemm_nt_big_applies(int prec, const GemmNT &g);
 void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
 void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g);
+// 256 x 256 LDS-DMA variant for the products whose operands do not fit the caches (cn_gemm_tn_big.hip); launch_gemm_tn /
+// launch_gemm_tn_group dispatch to it
+bool gemm_tn_big_applies(int prec, const GemmTN &g);    // on its own
+bool gemm_tn_big_can(int prec, const GemmTN &g);        // beside a product that applies (one grouped launch)
+void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n);   // n <= 3
 void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n);      // up to 3 small products in one launch
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------

@@ -161,8 +161,8 @@ def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_co
     """softmax_mcc_bwd_kernel hands its column-sum replicas (float atomics) and, through rowstat_reduce_wave, its loss partials
     (stores) to the last workgroup to arrive at a counter.  That is only sound when the adds / stores have been acknowledged before
     the counter is bumped: in the ISA an `s_waitcnt vmcnt(0)` must sit between the last replica add (partial store) and the counter
-    atomic, the counter atomic must be preceded by an L2 write-back (agent-scope release, one thread per workgroup) and the reader
-    must invalidate (`buffer_inv sc1`) before its loads.  (A workgroup-scope release fence compiled to nothing here in round 4.)"""
+    atomic -- for the replicas in EVERY wave, in front of the barrier that precedes the count -- and the reader must invalidate
+    (`buffer_inv sc1`) before its loads.  (A workgroup-scope release fence compiled to nothing here in round 4.)"""
     import shutil, subprocess
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -180,9 +180,8 @@ def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_co
         counters = [k for k, l in enumerate(body) if re.match(r"global_atomic_add v\d+, v\d+, v\d+, s\[", l)]   # returning u32 adds
         assert len(counters) == 2, counters                  # the loss partials' counter, the replicas' counter
         for k in counters:
-            # the release of the counting thread: write-back + drain directly in front of the counter
-            head = body[max(0, k - 4):k]
-            assert any(l.startswith("buffer_wbl2") for l in head) and any("s_waitcnt vmcnt(0)" in l for l in head), head
+            # no L2 write-back in front of the counter (what is handed over are atomics and sc1 stores; buffer_wbl2 there cost 1.6 us)
+            assert not any(l.startswith("buffer_wbl2") for l in body[max(0, k - 6):k])
             # the acquire of the last arriver behind it
             tail = body[k:k + 40]
             assert any(l.startswith("buffer_inv sc1") for l in tail), tail

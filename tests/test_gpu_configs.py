@@ -372,3 +372,39 @@ def test_config1_drift_through_training_stays_inside_the_measured_bound(pkg, orc
         wmax = max(float(np.abs(l.weights() - ref.layer(l.name).weights).max()) for l in net.trainable_layers())
         assert abs(e[-1] - eref[-1]) < 2e-3 * eref[-1], (e[-1], eref[-1])
         assert post < post_bound and wmax < w_bound, (mode, post, wmax)
+
+
+def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
+    """BASELINE configs[2] as a TRAINING run on real data: the literal CHiME example network
+    (examples/speech_recognition_chime/no_subsampling/network.jsn: 39 -> blstm156 -> blstm300 -> blstm102 -> softmax51) on the
+    reference's one real data file (tests/golden/val_1_speaker.nc: 102 sequences, 13 878 frames), first 90 sequences to train on,
+    last 12 to validate on, identical initial weights (normal, sigma 0.1 as in the example's config.cfg), stochastic momentum
+    SGD through the C++ driver in f32, bf16x3 and bf16 (tools/chime_convergence.py).  What the benchmarked bf16 arithmetic
+    does to TRAINING (the single-pass distance is pinned elsewhere):
+      (i)  lr 1e-5 (the example's), 30 epochs -- the smooth part of training, validation class error 96 % -> ~70 %: bf16 follows
+           f32 epoch by epoch (measured: <= 0.07 % absolute on the class error, 3e-4 relative on the error);
+      (ii) lr 3e-5, 60 epochs -- training to ~40 %: the three runs decorrelate like any three SGD runs (from epoch ~12 on the
+           class error of ONE mode moves by +-3 % from epoch to epoch), so what is compared is the best epoch (what early stopping
+           keeps) and the mean of the last ten: bf16 within 2 % absolute of f32 -- the fp32-tolerance mode bf16x3 itself ends 1.5 %
+           away from f32 (measured: best 38.8 / 37.5 / 39.1, last ten 41.8 / 40.3 / 40.9 for f32 / bf16x3 / bf16)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import chime_convergence as cc
+    smooth = cc.run(str(tmp_path), epochs=30, ps=10, lr=1e-5)
+    f32, b16, x3 = smooth["modes"]["f32"], smooth["modes"]["bf16"], smooth["modes"]["bf16x3"]
+    assert len(f32) == len(b16) == len(x3) == 30
+    assert f32[-1]["val_class_err"] < f32[0]["val_class_err"] - 15.0                 # it trains
+    for a, b, c in zip(f32, b16, x3):
+        assert abs(a["val_class_err"] - b["val_class_err"]) <= 0.5, (a, b)
+        assert abs(a["val_err"] - b["val_err"]) <= 1e-2 * a["val_err"], (a, b)
+        assert abs(a["train_err"] - b["train_err"]) <= 1e-2 * a["train_err"], (a, b)
+        assert abs(a["val_class_err"] - c["val_class_err"]) <= 0.5 and abs(a["val_err"] - c["val_err"]) <= 1e-2 * a["val_err"], (a, c)
+    far = cc.run(str(tmp_path), epochs=60, ps=10, lr=3e-5)
+    stat = {}
+    for mode, rows in far["modes"].items():
+        ce = [r["val_class_err"] for r in rows]
+        stat[mode] = (min(ce), float(np.mean(ce[-10:])))
+        assert stat[mode][0] < 45.0, (mode, stat[mode])                               # from 91 % at epoch 1
+    for mode in ("bf16", "bf16x3"):
+        assert abs(stat[mode][0] - stat["f32"][0]) <= 2.0 and abs(stat[mode][1] - stat["f32"][1]) <= 2.0, stat

@@ -143,3 +143,54 @@ def test_gemm_tn(lib, prec, shape):
     if prec == 2:
         ref64 = A.astype(np.float64).T @ Bm.astype(np.float64)
         assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()
+
+
+BIG_TN_SHAPES = [(512, 256, 4096),        # two whole tiles, whole k-tiles
+                 (800, 448, 5003),        # M = 3 tiles + 32 rows, N = 256 + 192 (the narrowest last tile column that still goes big), K tail of 11 frames
+                 (2048, 512, 9000),       # the LVCSR / reading-B layer product's shape (dW_in)
+                 (1024, 256, 4111),       # ... and its dW_rec
+                 (8000, 512, 6000)]       # LVCSR output layer: 31.25 tile rows
+
+
+@pytest.mark.parametrize("shape", BIG_TN_SHAPES)
+def test_gemm_tn_big(lib, shape, monkeypatch):
+    """The 256 x 256 LDS-DMA gradient kernel (cn_gemm_tn_big.hip; bf16, M >= 512, N >= 192, K >= 4096): partial tile rows and
+    columns, a K tail (frames past the end must come back from the fill as ZEROS -- buffer range check), several splits; against
+    float64 numpy products of the rounded operands, and repeatable up to the order of its split-K atomics."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(K, M).astype(np.float32); Bm = rng.randn(K, N).astype(np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        outs = []
+        for rep in range(3):
+            out = np.zeros((M, N), np.float32)
+            B.check(L.cn_dbg_gemm_tn(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K), ctx)
+            outs.append(out)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    ref = bf16_round(A).astype(np.float64).T @ bf16_round(Bm).astype(np.float64)
+    tol = 2e-5 * np.sqrt(K) + 1e-6 * np.abs(ref).max()          # fp32 accumulation of exact bf16 products
+    for out in outs:
+        bad = np.abs(out - ref)
+        assert bad.max() < tol, (bad.max(), tol, np.unravel_index(bad.argmax(), bad.shape))
+    # launches differ only in the order of the split-K atomics
+    assert np.abs(outs[0] - outs[1]).max() < 1e-3 * tol + 2e-6 * np.abs(ref).max()
+
+
+def test_gemm_tn_big_sees_every_frame_once(lib):
+    """Unit impulses: A[k][m] = 1 only at m = k % M, B[k][n] = k-dependent small integers (exact in bf16): C[m][n] = the sum of
+    B over the frames k = m (mod M) -- any frame read twice, skipped, or taken from a neighbouring split shows up exactly."""
+    L, B = lib
+    M, N, K = 512, 256, 4096 + 37
+    A = np.zeros((K, M), np.float32); A[np.arange(K), np.arange(K) % M] = 1.0
+    Bm = ((np.arange(K)[:, None] * 7 + np.arange(N)[None, :] * 3) % 13 - 6).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_tn(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    ref = A.T.astype(np.float64) @ Bm.astype(np.float64)
+    assert np.array_equal(out, ref.astype(np.float32))

@@ -1,6 +1,6 @@
 // Times launch_gemm_nt / launch_gemm_tn on the shapes of the headline workload (bf16 operands, random data).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -c tools/probe/gemm_bench.cpp -o /tmp/gb.o &&
-//        hipcc --offload-arch=gfx950 /tmp/gb.o lstm-rnn_amd/csrc/cn_gemm.o lstm-rnn_amd/csrc/cn_gemm_big.o -o tools/probe/gemm_bench
+//        hipcc --offload-arch=gfx950 /tmp/gb.o lstm-rnn_amd/csrc/cn_gemm.o lstm-rnn_amd/csrc/cn_gemm_big.o lstm-rnn_amd/csrc/cn_gemm_tn_big.o -o tools/probe/gemm_bench
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -73,8 +73,13 @@ int main()
 #endif
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(bias));
     }
-    struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"}};
+    struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"},
+                   {2048, 512, 35200, "LVCSR dW_in of layers 2-4 (blstm512), T = 550"}, {1024, 256, 35136, "LVCSR dW_rec per direction"}, {8000, 512, 35200, "LVCSR softmax dW as run by bench.py"},
+                   {2048, 512, 15600, "reading B dW_in (Hp = 256)"}, {1024, 256, 15548, "reading B dW_rec per direction"}, {4096, 1024, 32000, "long-utterance dW_in (Hp = 512)"}};
+    const int tn_first = getenv("GEMM_BENCH_TN_FIRST") ? atoi(getenv("GEMM_BENCH_TN_FIRST")) : 0;      // skip the first n tn shapes
+    int itn = 0;
     for (auto &c : tn) {
+        if (itn++ < tn_first) continue;
         c.K /= mdiv;
         void *A = rnd((size_t)c.K * c.M), *B = rnd((size_t)c.K * c.N);
         float *C; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMemset(C, 0, (size_t)c.M * c.N * 4));
@@ -90,9 +95,11 @@ int main()
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C));
     }
     // the grouped launch of an LSTM layer's backward pass: dW_in + dW_rec per direction in ONE launch (cn_api.cpp: lstm_backward)
-    struct Grp { int P; const char *what; } grps[] = {{256, "layer 2/3 group (dW_in 1024x256 + 2 x dW_rec 512x128)"}, {64, "layer 1 group (dW_in 1024x64 + 2 x dW_rec 512x128)"}};
+    struct Grp { int P, K, Hp, PS; const char *what; } grps[] = {{256, 15600, 128, 52, "layer 2/3 group (dW_in 1024x256 + 2 x dW_rec 512x128)"}, {64, 15600, 128, 52, "layer 1 group (dW_in 1024x64 + 2 x dW_rec 512x128)"},
+        {512, 35200, 256, 64, "LVCSR layer 2-4 group (dW_in 2048x512 + 2 x dW_rec 1024x256), T = 550"}, {64, 35200, 256, 64, "LVCSR layer 1 group (dW_in 2048x64 + 2 x dW_rec 1024x256)"},
+        {512, 15600, 256, 52, "reading B layer 2/3 group"}, {1024, 32000, 512, 16, "long-utterance layer 2-5 group (dW_in 4096x1024 + 2 x dW_rec 2048x512)"}};
     for (auto &gr : grps) {
-        const int K = 15600, R = 1024, Hp = 128, PS = 52;
+        const int K = gr.K / mdiv, Hp = gr.Hp, R = 8 * Hp, PS = gr.PS;
         void *delta = rnd((size_t)K * R), *x = rnd((size_t)K * gr.P), *y = rnd((size_t)K * 2 * Hp);
         float *C; const size_t cfl = (size_t)R * gr.P + (size_t)R * Hp; CK(hipMalloc((void **)&C, cfl * 4)); CK(hipMemset(C, 0, cfl * 4));
         GemmTN gs[3] = {};
