@@ -64,6 +64,7 @@ struct cn_ctx {
     // to finish, and at full speed their memory traffic stalls the latency-bound recurrent kernel (291 vs 229 us
     // per backward launch); on a subset of the CUs they run longer but draw less bandwidth
     hipStream_t side_slow = nullptr; int side_cus = 0;    // CU-masked side stream and its CU count
+    int tn_cus = 0;                       // CUs the gradient products of the current on_side() call may fill (0 = the chip)
     hipEvent_t ev_sgd = nullptr, ev_ext = nullptr;
     hipEvent_t ev_pack_last = nullptr;         // = ev_pack of the last layer whose operand copies cn_sgd_update_all rebuilt (not owned)
     std::vector<hipEvent_t> pending_joins;     // side-stream work the main stream has not waited for yet ...
@@ -386,6 +387,7 @@ void launch_prefetch(cn_ctx *c, hipStream_t st)
 template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = false)
 {
     cn_ctx *c = l->ctx;
+    c->tn_cus = 0;
     if (!c->overlap) { f(c->stream, nullptr); return; }
     // The first trainable layer's gradient work has nothing to run beside: only the weight update follows.  On the main
     // stream it saves the two cross-stream hand-offs (fork, join) in front of the update.
@@ -402,11 +404,18 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     static const bool side_rule = getenv("CN_NO_SIDE_RULE") == nullptr;
     if (slow && side_rule) {
         const double flops = 2.0 * c->N * (l->lstm ? (double)l->dirs * 4 * l->Hp * (l->Pp + l->Hp) : (double)l->Lp * l->Pp);
-        const double t_side = flops / (c->side_cus * 1.5e12);                                        // ~1.5 TFLOP/s per CU
+        // ~1.5 TFLOP/s per CU on the 64 x 64 tiles; the 256 x 256 kernel of the wide layers (cn_gemm_tn_big.hip) runs at ~3
+        const bool big = c->prec == P_BF16 && c->N >= 4096 && (l->lstm ? l->Hp >= 256 && l->Pp >= 192 : l->Lp >= 512 && l->Pp >= 192);
+        const double t_side = flops / (c->side_cus * (big ? 3.0e12 : 1.5e12));
         const double t_rec = c->T * (l->prev->Hp > 192 ? 1.4e-6 : 0.5e-6);                           // cluster / single-CU step
         if (t_side > 0.8 * t_rec) slow = false;
     }
     hipStream_t st = slow ? c->side_slow : c->side;
+    // The 256 x 256 gradient kernel puts ONE long-lived workgroup on a CU (128 KB of LDS): beside a recurrent kernel it must leave
+    // that kernel's CUs alone -- a cluster grid starts when ALL its workgroups are resident, and the recurrent workgroups claim a
+    // whole CU's LDS.  Masked stream: its CUs; unmasked beside a recurrent kernel: the chip less 64 CUs (52 - 64 workgroups at
+    // PS = 50 / 64).  (reading B with the kernel filling the chip: 2.79 -> 2.83 ms per fraction, the recurrent kernel waited.)
+    c->tn_cus = slow ? c->side_cus : (l->prev && l->prev->lstm && c->num_cus > 128 ? c->num_cus - 64 : 0);
     HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
     if (c->pf.valid && !c->pf.launched) launch_prefetch(c, st);      // covered by this layer's join event (same stream, in order)
     // the join event rides on the last kernel of the side work too (f returns true when it attached it)
@@ -675,7 +684,7 @@ void lstm_backward(cn_layer *l)
                     gs[ng++] = r;
                 }
             }
-            launch_gemm_tn_group(st, c->prec, gs, ng);      // the three products side by side in one launch
+            launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus);      // the three products side by side in one launch
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -765,7 +774,7 @@ void ff_backward(cn_layer *l)
             GemmTN g{};
             g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
-            launch_gemm_tn(st, c->prec, g);
+            launch_gemm_tn(st, c->prec, g, c->tn_cus);
         }
         {
             Timed tm(c, KC_OTHER, st);

@@ -558,14 +558,14 @@ static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n)
 #undef CN_TN_DISPATCH
 }
 
-void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g)
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget)
 {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    if (gemm_tn_big_applies(prec, g)) { launch_gemm_tn_big_group(s, &g, 1); return; }
+    if (gemm_tn_big_applies(prec, g)) { launch_gemm_tn_big_group(s, &g, 1, cu_budget); return; }
     launch_tn_any(s, prec, &g, 1);
 }
 
-void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n)
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget)
 {
     GemmTN grp[TN_GROUP], big[TN_GROUP]; int ng = 0, nb = 0;
     bool any_big = false;
@@ -578,7 +578,7 @@ void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n)
         if (huge || ng == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
         else grp[ng++] = gs[i];
     }
-    if (nb) launch_gemm_tn_big_group(s, big, nb);
+    if (nb) launch_gemm_tn_big_group(s, big, nb, cu_budget);
     if (ng) launch_tn_any(s, prec, grp, ng);
 }
 

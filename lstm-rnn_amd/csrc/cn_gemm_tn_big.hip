@@ -233,7 +233,7 @@ bool gemm_tn_big_applies(int prec, const GemmTN &g)
     return gemm_tn_big_can(prec, g) && (long)g.M * g.N >= (1L << 20);
 }
 
-void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n)
+void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget)
 {
     if (n <= 0) return;
     static DeviceOnce attr_once;
@@ -255,7 +255,7 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n)
         // one workgroup per CU (128 KB of LDS): splits so that the group fills the chip once; every split ends in M*N fp32
         // atomics (~1.3 TB/s chip-wide): at most 64 MB of them per product, and at least 16 k-tiles per split
         static const int target_env = getenv("CN_TNBIG_BLOCKS") ? atoi(getenv("CN_TNBIG_BLOCKS")) : 0;
-        const int target = target_env ? target_env : cus;
+        const int target = target_env ? target_env : (cu_budget > 0 ? std::min(cu_budget, cus) : cus);
         int splits = (int)std::max(1L, target / all_tiles);
         const long cap_atomic = std::max(1L, (64L << 20) / ((long)g.M * g.N * 4));
         splits = (int)std::min<long>(splits, cap_atomic);

@@ -64,13 +64,14 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = 
 // 256 x 256 LDS-DMA variant for the MFMA-bound shapes (cn_gemm_big.hip); launch_gemm_nt dispatches to it
 bool gemm_nt_big_applies(int prec, const GemmNT &g);
 void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
-void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g);
+// cu_budget: CUs the launch may fill with its one-per-CU workgroups when it goes to the 256 x 256 kernel (0 = the chip)
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget = 0);
 // 256 x 256 LDS-DMA variant for the products whose operands do not fit the caches (cn_gemm_tn_big.hip); launch_gemm_tn /
 // launch_gemm_tn_group dispatch to it
 bool gemm_tn_big_applies(int prec, const GemmTN &g);    // on its own
 bool gemm_tn_big_can(int prec, const GemmTN &g);        // beside a product that applies (one grouped launch)
-void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n);   // n <= 3
-void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n);      // up to 3 small products in one launch
+void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget = 0);   // n <= 3
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget = 0);      // up to 3 small products in one launch
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------
 struct LstmRec {
