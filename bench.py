@@ -509,6 +509,9 @@ def main():
                      for k, v in also.items() if k in names}
             if other:
                 out["config"]["other_readings"] = other
+                # ... and once more as flat scalars (round 4's driver record kept only the scalar entries of `config`)
+                for k, v in other.items():
+                    out["config"]["frames_per_s_" + k] = round(v["value"])
         if world == 1 and not args.no_driver_leg:
             out["driver_leg"] = driver_leg(wl, args)
         if world == 1 and not args.no_cpu_baseline:

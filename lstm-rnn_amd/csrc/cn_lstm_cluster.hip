@@ -425,6 +425,71 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward: helper workgroups that keep the L2 ahead of a cluster (round 5)
+// ---------------------------------------------------------------------------------------------
+// What a backward step reads -- gate activations, cell states, tanh(c), outputErrors: 28 bytes per unit-frame -- was written a
+// whole forward pass ago and comes from HBM (LVCSR: 400 MB per layer, more than the Infinity Cache).  The cluster kernels poll
+// with vector loads, vmcnt retires in order, so every prefetch a wave has in flight must land before its next poll does: however
+// far ahead it is issued, a prefetch has ONE step (1.1 us) to arrive, and with the loads served from cache-hot lines instead
+// (timing-only build CN_CL_DIAG_HOT) the 2-CU backward kernel is 17-19 % faster (reading B 2.76 -> 2.52 ms, LVCSR 9.89 -> 9.10 ms
+// per fraction -- an upper bound: those lines sit in the CU's own L1).  A ninth wave per CU cannot do the fetching (226 registers
+// per wave: two waves per SIMD is all that fits), so extra WORKGROUPS do: helper h, on a free CU of the XCD that runs cluster h (block ids congruent mod 8: placement is speed only),
+// reads the cluster's progress off its exchange granules (tag = epoch + step + 1) and touches one dword of every 128-byte line the
+// cluster will read 3 ... 10 steps later; the members' own prefetches then find their lines in that XCD's L2.  A helper never
+// writes, never makes anybody wait, and gives up by itself (bounded) -- results cannot depend on it.
+template <int CS, int RPL, int GNT>
+__device__ __forceinline__ void bwd_cluster_touch_ahead(const LstmRec &p, int cluster, int nclusters, int HP)
+{
+    if (cluster >= nclusters) return;
+    const int T = p.T, PS = p.PS, dirs = p.dirs, SEQ = 4 * RPL;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * SEQ;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP, stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * GNT);          // member 0, granule 0, thread 0 of either parity
+    const u64 *tag0 = xbase, *tag1 = xbase + (long)CS * (RPL * GNT);
+    // lines of one (step, sequence): acts HP * 16 bytes, err / cell / th HP * 4 bytes each
+    const int la = HP * 16 / 128, lc = HP * 4 / 128, per_seq = la + 3 * lc, per_step = SEQ * per_seq;
+    constexpr int AHEAD = 3, WINDOW = 8;
+    int done = -1;                       // every step up to `done` has been touched
+    for (int spin = 0; spin < 64 * 1024; ++spin) {
+        const u64 a = __hip_atomic_load(tag0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(tag1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int pa = (int)((unsigned)(a >> 32) - p.xch_epoch) - 1, pb = (int)((unsigned)(b >> 32) - p.xch_epoch) - 1;
+        int prog = -1;                   // last step member 0 has published (tags of earlier launches are <= xch_epoch)
+        if (pa >= 0 && pa < T) prog = pa;
+        if (pb >= 0 && pb < T && pb > prog) prog = pb;
+        if (prog >= T - 1 - AHEAD) return;
+        const int first = max(done + 1, prog + AHEAD), last = min(T - 1, prog + AHEAD + WINDOW - 1);
+        // up to four lines per thread and round, issued together and awaited INSIDE the statement: an asm load's destination counts
+        // as written when its statement ends, and a sink that is reused while its load is still in flight would be overwritten
+        // by it (lanes without a line re-read the tag)
+        const int count = (last - first + 1) * per_step;
+        for (int i0 = threadIdx.x; i0 < count; i0 += 4 * blockDim.x) {
+            const char *line[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + k * blockDim.x;
+                line[k] = (const char *)tag0;
+                if (i < count) {
+                    const int it = first + i / per_step, r = i % per_step, sv = s0 + r / per_seq, l = r % per_seq;
+                    const int t = d ? it : T - 1 - it;
+                    if (l < la) line[k] = (const char *)(p.acts + t * stepA + sv * arow + (long)d * HP * 4) + l * 128;
+                    else {
+                        const int kk = (l - la) / lc, ll = (l - la) % lc;
+                        const float *base = kk == 0 ? p.err : (kk == 1 ? p.cell : p.th);
+                        line[k] = (const char *)(base + t * stepC + sv * crow + (long)d * HP) + ll * 128;
+                    }
+                }
+            }
+            unsigned k0, k1, k2, k3;
+            asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %5, off\n\tglobal_load_dword %2, %6, off\n\t"
+                         "global_load_dword %3, %7, off\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(k0), "=&v"(k1), "=&v"(k2), "=&v"(k3) : "v"(line[0]), "v"(line[1]), "v"(line[2]), "v"(line[3]) : "memory");
+        }
+        if (last > done) done = last;
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 template <int RPL> struct ClBwdPre { f32x4 a[RPL]; float e[RPL], cp[RPL], th[RPL]; char pt[RPL]; };
@@ -457,7 +522,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     int cluster, member;
     cluster_of<CS>(cluster, member);
     const int PS = p.PS, T = p.T, dirs = p.dirs;
-    if (cluster >= dirs * (PS / (4 * RPL))) return;
+    const int nclusters = dirs * (PS / (4 * RPL)), ncblocks = (nclusters + 7) / 8 * 8 * CS;
+    if ((int)blockIdx.x >= ncblocks) {       // a helper workgroup (launch_cluster appends them): warms the L2 ahead of cluster blockIdx - ncblocks
+        bwd_cluster_touch_ahead<CS, RPL, G * UPC * 4>(p, (int)blockIdx.x - ncblocks, nclusters, HP);
+        return;
+    }
+    if (cluster >= nclusters) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int d = cluster % dirs, s0 = (cluster / dirs) * (4 * RPL);
@@ -514,6 +584,9 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     CLS_DECL
     auto prefetch = [&](int t, ClBwdPre<RPL> &pre) {
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+#ifdef CN_CL_DIAG_HOT
+        t = tfirst;                  // timing-only build (results wrong): every prefetch from the same, cache-hot lines
+#endif
         const int tprev = d ? t + 1 : t - 1;
         const bool hasprev = tprev >= 0 && tprev < T;
         const float *actsT = p.acts + t * stepA, *errT = p.err + t * stepC;
@@ -956,6 +1029,188 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_psum_kernel(LstmRec 
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, bf16, Hp = 256: TWO sequences per cluster of two CUs, one wave per SIMD ("s2c"; round 5)
+// ---------------------------------------------------------------------------------------------
+// The cut of cn_lstm_s2.hip (a wave owns 32 units x 2 sequences; both unit groups accumulate through two zero-padded views of the
+// operand tile; row-pair sparse MFMAs) on the two-CU split of the kernel above: member m owns output units 128 m .. 128 m + 127
+// and keeps their rows of W_rec^T -- all K = 1024 of them, 256 registers per lane -- resident.  Why: the step of the 4-sequence
+// cluster kernel is a chain (deltas published -> hop through L2 -> partner's deltas into LDS -> barrier -> their half of the
+// product -> block errors -> deltas) that eight waves per CU walk with two waves per SIMD and four sequences' cell arithmetic
+// each; this cut halves the vector work per CU (a lane owns ONE (unit, sequence)), doubles the CUs in use (PS = 64: 128 of 256)
+// and is the layout the hand-written loop below schedules.
+// Tile: a sequence's quad of rows = (K half, parity) as in lstm_bwd_s2_kernel, K half 0 = the member's OWN 128 units (written by
+// the member itself at the end of a step), K half 1 = the partner's (written behind the poll of the next step); e = accA[0] +
+// accA[1] (own half, own rows of W) + accB[2] + accB[3] (partner half).  The own half is multiplied while the partner's
+// deltas are on their way.  Exchange: two 8-byte {tag, value} granules per lane and step (cn_lstm_cluster.hip protocol: tags
+// count on across launches, slots alternate with the step parity, bounded spins).
+__global__ __launch_bounds__(256) void lstm_bwd_s2c_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 256, UPC = 128, CS = 2, NT = 256, G = 2;
+    constexpr int KCS = 4 * HP / 64, KCH = KCS / 2;          // 16 chunks of K in all, 8 per tile row (= per member)
+    constexpr int pitch = lds_pitch(KCH * 64);
+    constexpr int DROWS = 9, plane = DROWS * pitch;
+    int cluster, member;
+    cluster_of<CS>(cluster, member);
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    if (cluster >= dirs * (PS / 2)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * 2;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = tid * 4; i < 2 * plane; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+    // dummy-slot table: dtab[t][s] = (t >= Tmin && patTypes[t][s0 + s] == NONE) (LstmLayer.cu:224-234 with :949,983)
+    unsigned char *dtab = (unsigned char *)smem + 2 * plane;
+    for (int i = tid; i < 2 * T; i += NT) {
+        const int tt = i >> 1;
+        dtab[i] = tt >= p.Tmin && p.pat[(long)tt * PS + s0 + (i & 1)] == 0;
+    }
+
+    // W_rec^T rows of this lane's two output units (unit group j), K chunks in member-relative order: own units first
+    u32x8 wsp[2][KCS];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kc = 0; kc < KCS; ++kc) {
+            const int kch = ((member + kc / KCH) % CS) * KCH + kc % KCH;
+            wsp[j][kc] = sp_load_bf16(Wd + ((long)(member * UPC + 32 * wave + 16 * j + c) * 4 * HP + kch * 64 + q * 16) * 2);
+        }
+    const int spidx = sp_index(c);
+    const int av0 = (c < 8 ? c : 8) * pitch + q * 16, av1 = (c >= 8 ? c - 8 : 8) * pitch + q * 16;
+
+    const int lunit = 32 * wave + 16 * ug + c, unit = member * UPC + lunit;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const unsigned oA = (unsigned)(sv * (int)arow + (d * HP + unit) * 4);
+    const unsigned oC = (unsigned)(sv * (int)crow + d * HP + unit);
+    const unsigned stepA = (unsigned)PS * (unsigned)arow, stepC = (unsigned)PS * (unsigned)crow;
+    // the lane's column in a tile row (32 stored values per 64-k chunk) and the rows of its own / its partner twin's deltas
+    const int col = ((lunit >> 4) * 32 + sp_pos(4 * (lunit & 15))) * 2;
+    const int oOwn = (4 * sq) * pitch + col, oPar = (4 * sq + 2) * pitch + col;
+    u64 *xbase = p.xch + (long)cluster * 2 * CS * (G * NT);
+    bool gaveup = false;
+
+    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, ccur;
+    float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
+
+    const int tfirst = d ? 0 : T - 1;
+    struct Stage { f32x4 a; float e, cp, th; } preA, preB;
+    auto prefetch = [&](int t, Stage &pre) {
+        t = t < 0 ? 0 : (t >= T ? T - 1 : t);
+        const int tprev = d ? t + 1 : t - 1;
+        const bool hasprev = tprev >= 0 && tprev < T;
+        const unsigned bA = (unsigned)t * stepA, bC = (unsigned)t * stepC;
+        const unsigned bCp = (unsigned)(hasprev ? tprev : t) * stepC;
+        pre.e = p.err[bC + oC];
+        pre.a = *(const f32x4 *)(p.acts + bA + oA);
+        pre.cp = p.cell[bCp + oC];
+        pre.th = p.th[bC + oC];
+    };
+
+    auto step = [&](int it, Stage &pre) {
+        const int t = d ? it : T - 1 - it;
+        char *dcur = smem + (it & 1) * plane;
+        char *dnxt = smem + ((it + 1) & 1) * plane;
+        const int tprev_ = d ? t + 1 : t - 1;
+        const bool hasprev_ = tprev_ >= 0 && tprev_ < T;       // !lastCall, LstmLayer.cu:947,981
+        const unsigned bD = (unsigned)t * stepA;
+        u64 *xslot = xbase + (long)(it & 1) * CS * (G * NT), *xprev = xbase + (long)((it + 1) & 1) * CS * (G * NT);
+        const u64 *theirs = xprev + (long)((member + 1) % CS) * (G * NT) + tid;
+        u64 *mine = xslot + (long)member * (G * NT) + tid;
+
+        const unsigned char dmy = dtab[2 * t + sq];
+        const float e_ = pre.e, c_ = pre.cp, th_ = pre.th;
+        const f32x4 a_ = pre.a;
+        const float cp = hasprev_ ? c_ : 0.f;
+
+        // own half of the BPTT product (LstmLayer.cu:939-942 / :973-976), while the partner's deltas travel
+        f32x4 accA = {e_, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};      // err enters as the C operand
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            const u32x4 a0 = *(const u32x4 *)(dcur + av0 + kc * 64), a1 = *(const u32x4 *)(dcur + av1 + kc * 64);
+            smma16(accA, a0, wsp[0][kc], spidx);
+            smma16(accA, a1, wsp[1][kc], spidx);
+        }
+        if (it > 0) {      // the partner's deltas of the previous step: rows (K half 1) of the tile being read
+            const u64 *slots[G] = {theirs, theirs + NT};
+            unsigned vals[G];
+            consume_all<G>(slots, p.xch_epoch + it, p.fault, vals, gaveup);
+            *(unsigned *)(dcur + oPar) = vals[0];                // (n, i): even row
+            *(unsigned *)(dcur + oPar + pitch) = vals[1];        // (f, o): odd row
+            lds_barrier();
+        }
+        prefetch(d ? t + 2 : t - 2, pre);      // behind the poll (it drains vmcnt)
+#pragma unroll
+        for (int kc = 0; kc < KCH; ++kc) {
+            const u32x4 a0 = *(const u32x4 *)(dcur + av0 + kc * 64), a1 = *(const u32x4 *)(dcur + av1 + kc * 64);
+            smma16(accB, a0, wsp[0][KCH + kc], spidx);
+            smma16(accB, a1, wsp[1][KCH + kc], spidx);
+        }
+        const float e = (accA[0] + accA[1]) + (accB[2] + accB[3]);
+        KEEP_TUPLE(accA, e); KEEP_TUPLE(accB, e);
+
+        // ComputeBlockErrorsFn, LstmLayer.cu:236-285, the explicit operation sequence of lstm_bwd_s2_kernel
+        const bool dummy = dmy != 0;
+        const float ni = a_[0], ig = a_[1], fg = a_[2], og = a_[3];
+        const float cs = ccur, th = th_;
+        float dog, ec, dni, dfg, dig;
+        {
+#pragma clang fp contract(off)
+            const float m = dummy ? 0.f : 1.f;
+            const float t2p = __builtin_fmaf(-og, og, og) * th;
+            const float vp = og * __builtin_fmaf(-th, th, 1.0f);
+            const float w = __builtin_fmaf(po, t2p, vp);
+            const float d2p = ig * __builtin_fmaf(-ni, ni, 1.0f);
+            const float d3p = __builtin_fmaf(-fg, fg, fg) * cp;              // cp = 0 at lastCall
+            const float d4p = __builtin_fmaf(-ig, ig, ig) * ni;
+            float car = fgn * ecn;                                          // zero carry at firstCall
+            car = __builtin_fmaf(pi, dign, car);
+            car = __builtin_fmaf(pf, dfgn, car);
+            dog = (t2p * m) * e;
+            ec = __builtin_fmaf(e, w * m, car * m);
+            dni = (d2p * m) * ec; dfg = (d3p * m) * ec; dig = (d4p * m) * ec;
+            fgn = fg * m;
+        }
+        dni = clip1(dni); dig = clip1(dig); dfg = clip1(dfg); dog = clip1(dog);
+        ecn = ec; dign = dig; dfgn = dfg;
+        ccur = cp;
+        sb[0] += dni; sb[1] += dig; sb[2] += dfg; sb[3] += dog;
+        spi = __builtin_fmaf(cp, dig, spi); spf = __builtin_fmaf(cp, dfg, spf); spo = __builtin_fmaf(cs, dog, spo);
+        const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
+        const u64 bits = __builtin_bit_cast(u64, dv);
+        publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
+        publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
+        *(unsigned *)(dnxt + oOwn) = (unsigned)bits;
+        *(unsigned *)(dnxt + oOwn + pitch) = (unsigned)(bits >> 32);
+        *(bf16x4 *)((__bf16 *)p.delta_op + bD + oA) = dv;
+        lds_barrier();
+    };
+
+    ccur = p.cell[(unsigned)tfirst * stepC + oC];
+    prefetch(tfirst, preA);
+    prefetch(d ? 1 : T - 2, preB);
+    lds_barrier();
+    for (int it = 0; it < T; it += 2) {
+        step(it, preA);
+        if (it + 1 < T) step(it + 1, preB);
+    }
+
+    // fold the two sequences of each unit column, then one atomic per (gate, unit) and workgroup
+    float v[7] = {sb[0], sb[1], sb[2], sb[3], spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
+    if (sq == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 template <int PREC, int HP, int UPC, int RPL, bool BWD>
@@ -990,7 +1245,15 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     if (attr_once.first()) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, p);
+    // backward: one helper workgroup per cluster behind the members (bwd_cluster_touch_ahead), while the chip has CUs to spare.
+    // Measured (same box, interleaved, ms per fraction with / without): long utterances (8 CUs x 64 units, T = 2000) 35.66 / 36.27
+    // and 35.79 / 36.16 (-1.4 %); reading B 2.819 / 2.811, LVCSR 10.19 / 10.10 (2 CUs x 128 units: +0.3 ... +0.8 %: an L2 hit
+    // is still longer than the half step hipcc's latch copies leave a prefetch there) -- so only the 8-CU shape gets them.
+    // CN_CLUSTER_HELPERS=1 / CN_NO_CLUSTER_HELPERS=1 force either way (A/B, tests).
+    int helpers = 0;
+    const bool want = getenv("CN_CLUSTER_HELPERS") ? true : (getenv("CN_NO_CLUSTER_HELPERS") ? false : CS == 8);
+    if (BWD && want && grid + (nclusters + 7) / 8 * 8 <= p.cluster_cus) helpers = (nclusters + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid + helpers), dim3(NT), lds, s, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_cluster_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UPC, RPL);
 }
 
@@ -1088,8 +1351,32 @@ static void launch_cluster_rpl(hipStream_t s, bool bwd, const LstmRec &p)
     else            { if (bwd) launch_cluster<PREC, HP, UPC, 2, true>(s, p); else launch_cluster<PREC, HP, UPC, 2, false>(s, p); }
 }
 
+// the s2c cut: bf16, Hp = 256, backward, one sequence per lane, an even number of sequences, both members of every cluster resident
+static bool s2c_applies(int prec, bool bwd, const LstmRec &p)
+{
+    // (the compiled kernel measures 25 % slower per step than the 8-wave cluster kernel -- reading B 2.77 -> 3.05 ms, LVCSR 9.88 ->
+    // 10.68 ms per fraction: 154 AGPR copies per step and one wave per SIMD to issue them --; it is the twin the hand-written loop
+    // is held against, selected with CN_S2C=1)
+    if (!bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2 || !getenv("CN_S2C")) return false;
+    const int nclusters = p.dirs * (p.PS / 2);
+    return (nclusters + 7) / 8 * 8 * 2 <= p.cluster_cus;
+}
+static void launch_s2c(hipStream_t s, const LstmRec &p)
+{
+    const int nclusters = p.dirs * (p.PS / 2), grid = (nclusters + 7) / 8 * 8 * 2;
+    constexpr int pitch = lds_pitch(8 * 64);
+    const size_t lds = 2 * 9 * (size_t)pitch + (((size_t)p.T * 2 + 15) & ~(size_t)15);
+    static DeviceOnce attr_once;
+    if (attr_once.first()) (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (one workgroup per CU: each claims the CU's whole LDS so that no gradient-GEMM workgroup is placed beside it, cn_lstm.hip)
+    size_t lds_claim = getenv("CN_NO_LDS_CLAIM") ? lds : (size_t)(160 * 1024 - 1024);
+    hipLaunchKernelGGL(lstm_bwd_s2c_kernel, dim3(grid), dim3(256), lds_claim < lds ? lds : lds_claim, s, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_bwd_s2c_kernel");
+}
+
 static void launch_cluster_shape(hipStream_t s, int prec, bool bwd, const LstmRec &p)
 {
+    if (s2c_applies(prec, bwd, p)) { launch_s2c(s, p); return; }
     if (prec == P_X3)                                       launch_cluster_rpl<P_X3, 256, 64>(s, bwd, p);
     else if (p.Hp == 256 && cluster_size(prec, 256) == 4)   launch_cluster_rpl<P_BF16, 256, 64>(s, bwd, p);
     else if (p.Hp == 256)                                   launch_cluster_rpl<P_BF16, 256, 128>(s, bwd, p);
