@@ -402,20 +402,32 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     // error product behind it 757 instead of 140 us; 13.3 -> 12.7 ms per fraction with the rule below)
     bool slow = c->side_slow && l->prev && l->prev->lstm;
     static const bool side_rule = getenv("CN_NO_SIDE_RULE") == nullptr;
+    // ~1.5 TFLOP/s per CU on the 64 x 64 tiles; the 256 x 256 kernel of the wide layers (cn_gemm_tn_big.hip) runs at ~3
+    const bool big = c->prec == P_BF16 && c->N >= 4096 && (l->lstm ? l->Hp >= 256 && l->Pp >= 192 : l->Lp >= 512 && l->Pp >= 192);
+    // CUs the recurrent kernel that follows on the main stream will occupy when it is a cluster launch (0: one-CU kernels)
+    int rec_cus = 0;
+    if (l->prev && l->prev->lstm) {
+        LstmRec r{};
+        r.Hp = l->prev->Hp; r.dirs = l->prev->dirs; r.PS = c->PSp; r.T = c->T; r.rpl = c->rpl; r.num_cus = r.cluster_cus = c->num_cus;
+        rec_cus = c->d_xch ? lstm_cluster_bwd_cus(c->prec, r) : 0;
+    }
     if (slow && side_rule) {
         const double flops = 2.0 * c->N * (l->lstm ? (double)l->dirs * 4 * l->Hp * (l->Pp + l->Hp) : (double)l->Lp * l->Pp);
-        // ~1.5 TFLOP/s per CU on the 64 x 64 tiles; the 256 x 256 kernel of the wide layers (cn_gemm_tn_big.hip) runs at ~3
-        const bool big = c->prec == P_BF16 && c->N >= 4096 && (l->lstm ? l->Hp >= 256 && l->Pp >= 192 : l->Lp >= 512 && l->Pp >= 192);
         const double t_side = flops / (c->side_cus * (big ? 3.0e12 : 1.5e12));
-        const double t_rec = c->T * (l->prev->Hp > 192 ? 1.4e-6 : 0.5e-6);                           // cluster / single-CU step
+        const double t_rec = c->T * (l->prev->Hp > 192 ? 1.2e-6 : 0.5e-6);                           // cluster / single-CU step
         if (t_side > 0.8 * t_rec) slow = false;
+        // a cluster grid that covers a large part of the chip (two sequences per two-CU cluster: 112-128 CUs, each claiming its
+        // CU's whole LDS) lands on the masked CUs too and leaves the masked stream a fraction of them: no slow lane then
+        // (LVCSR with the masked stream beside a 128-CU grid: gradient products 10.4 -> 19.2 ms per six fractions)
+        if (rec_cus > c->num_cus / 4) slow = false;
     }
     hipStream_t st = slow ? c->side_slow : c->side;
     // The 256 x 256 gradient kernel puts ONE long-lived workgroup on a CU (128 KB of LDS): beside a recurrent kernel it must leave
     // that kernel's CUs alone -- a cluster grid starts when ALL its workgroups are resident, and the recurrent workgroups claim a
-    // whole CU's LDS.  Masked stream: its CUs; unmasked beside a recurrent kernel: the chip less 64 CUs (52 - 64 workgroups at
-    // PS = 50 / 64).  (reading B with the kernel filling the chip: 2.79 -> 2.83 ms per fraction, the recurrent kernel waited.)
-    c->tn_cus = slow ? c->side_cus : (l->prev && l->prev->lstm && c->num_cus > 128 ? c->num_cus - 64 : 0);
+    // whole CU's LDS.  Masked stream: its CUs; unmasked beside a recurrent kernel: the chip less that kernel's grid (at least 64
+    // CUs: the one-CU kernels at PS = 50 / 64 take 52 - 64).  (reading B with the kernel filling the chip: 2.79 -> 2.83 ms per
+    // fraction, the recurrent kernel waited.)
+    c->tn_cus = slow ? c->side_cus : (l->prev && l->prev->lstm && c->num_cus > 128 ? std::max(64, c->num_cus - std::max(64, rec_cus + 8)) : 0);
     HIP_CHECK(hipStreamWaitEvent(st, l->ev_fork, 0));
     if (c->pf.valid && !c->pf.launched) launch_prefetch(c, st);      // covered by this layer's join event (same stream, in order)
     // the join event rides on the last kernel of the side work too (f returns true when it attached it)

@@ -123,6 +123,7 @@ int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);
 // `epoch`: the context's granule-tag counter; the launcher hands tags epoch + 1 ... epoch + T to this launch and advances
 // the counter by T + 1, so no caller can forget to (stale granules of an earlier launch never match)
 bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned *epoch);
+int lstm_cluster_bwd_cus(int prec, const LstmRec &p);     // CUs the backward cluster launch of this shape occupies (0 = no cluster shape)
 void lstm_cluster_stream_gone(hipStream_t s);         // cn_ctx_destroy: the per-device launch gate forgets the stream
 
 // ---- element-wise / packing kernels -----------------------------------------------------------

@@ -1211,6 +1211,142 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2c_kernel(LstmRec p)
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, bf16, Hp = 256, two sequences per cluster of two CUs: the time loop written by hand (round 5)
+// ---------------------------------------------------------------------------------------------
+// The cut, the layout, the operand order per accumulator and the arithmetic of lstm_bwd_s2c_kernel above (bit-equal on real
+// slots), the instruction stream of lstm_bwd_s2_asm_kernel (cn_lstm_s2.hip) with the exchange in the middle of the step; the
+// text of the loop is generated (tools/gen_s2c_loop.py -> cn_lstm_s2c_loop.inc; the step is described there).  W_rec^T: 32
+// fragments = all 256 AGPRs.  Members publish a granule of zeros for "step -1" in front of the loop, so that step 0 polls like
+// every other step.  Dummy slots as in the other hand-written loops: the pattern type alone decides.
+#include "cn_lstm_s2c_loop.inc"
+// CN_S2C_STAMP (tools/stamps_s2c.py; `make variantc NAME=s2cstamp DEFS=-DCN_S2C_STAMP`; never in the shipped build): every wave of
+// workgroup 0 sums s_memtime deltas per step segment (the segments are named in tools/gen_s2c_loop.py)
+#ifdef CN_S2C_STAMP
+__device__ unsigned cn_s2c_stamp_buf[4][8];
+extern "C" int cn_dbg_read_stamps_s2c(unsigned *host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cn_s2c_stamp_buf), sizeof(cn_s2c_stamp_buf)); }
+#endif
+__global__ __launch_bounds__(256) void lstm_bwd_s2c_asm_kernel(LstmRec p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HP = 256, UPC = 128, CS = 2, NT = 256, G = 2, KCS = 16, KCH = 8;
+    constexpr int pitch = lds_pitch(KCH * 64), plane = 9 * pitch;
+    static_assert(pitch == 544 && plane == 4896 && G * NT * 4 == 2048, "LDS / granule offsets of the generated loop");
+    static_assert(CN_GUARD_STEPS >= 5, "prefetch four steps ahead, c[prev] five");
+    int cluster, member;
+    cluster_of<CS>(cluster, member);
+    const int PS = p.PS, T = p.T, dirs = p.dirs;
+    if (cluster >= dirs * (PS / 2)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int ug = q >> 1, sq = q & 1;
+    const int d = cluster % dirs, s0 = (cluster / dirs) * 2;
+    const long arow = (long)dirs * 4 * HP, crow = (long)dirs * HP;
+
+    for (int i = tid * 4; i < 2 * plane; i += NT * 4) *(unsigned *)(smem + i) = 0u;
+
+    u32x8 w[2][KCS];
+    const char *Wd = (const char *)p.WrecT + (long)d * 4 * HP * HP * 2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kc = 0; kc < KCS; ++kc) {
+            const int kch = ((member + kc / KCH) % CS) * KCH + kc % KCH;
+            w[j][kc] = sp_load_bf16(Wd + ((long)(member * UPC + 32 * wave + 16 * j + c) * 4 * HP + kch * 64 + q * 16) * 2);
+        }
+    const int spidx = sp_index(c);
+    // ONE view of the tile: lanes c >= 8 read the rows of lanes c - 8 (tools/gen_s2c_loop.py); a lane keeps the sums of its own unit group
+    const unsigned av = (c & 7) * pitch + q * 16;
+    const unsigned long long ugm = 0xFFFFFFFF00000000ull;      // lanes of unit group 1 (q >= 2)
+
+    const int lunit = 32 * wave + 16 * ug + c, unit = member * UPC + lunit;
+    const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
+    const int sv = s0 + sq;
+    const unsigned col = ((lunit >> 4) * 32 + sp_pos(4 * (lunit & 15))) * 2;
+    const unsigned oT = (4 * sq) * pitch + col, oT1 = oT + plane, oTp = (4 * sq + 2) * pitch + col, oTp1 = oTp + plane;
+    // exchange granules: byte offsets of this lane's / its partner twin's first granule in slot set 0 / 1
+    const char *xch = (const char *)(p.xch + (long)cluster * 2 * CS * (G * NT));
+    const unsigned oXm0 = (unsigned)(((0 * CS + member) * (G * NT) + tid) * 8), oXm1 = (unsigned)(((1 * CS + member) * (G * NT) + tid) * 8);
+    const unsigned oXt0 = (unsigned)(((0 * CS + (member ^ 1)) * (G * NT) + tid) * 8), oXt1 = (unsigned)(((1 * CS + (member ^ 1)) * (G * NT) + tid) * 8);
+    // "step -1": zeros, tagged with this launch's first tag, in the slot set step 0 polls
+    publish((u64 *)(xch + oXm1), p.xch_epoch, 0u);
+    publish((u64 *)(xch + oXm1) + NT, p.xch_epoch, 0u);
+    unsigned tagc = p.xch_epoch;
+
+    // byte offsets of this lane, kept BIAS steps ahead of the time index, bases BIAS steps behind (lstm_bwd_s2_asm_kernel)
+    constexpr long BIAS = 8;
+    const long t0 = d ? 0 : T - 1, dt = d ? 1 : -1;
+    const long stepA = (long)PS * arow, stepC = (long)PS * crow;
+    const unsigned lC = (unsigned)(sv * (int)crow + d * HP + unit);
+    unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4;
+    unsigned oD = (unsigned)((t0 + BIAS) * stepA * 2) + lC * 8, oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
+    const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sD = (unsigned)(dt * stepA * 2), sP = (unsigned)(dt * PS);
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *cell = (const char *)p.cell - BIAS * stepC * 4, *th = (const char *)p.th - BIAS * stepC * 4;
+    const char *err = (const char *)p.err - BIAS * stepC * 4, *pat = p.pat - BIAS * PS;
+    const char *actspf = acts + 4 * dt * stepA * 4, *thpf = th + 4 * dt * stepC * 4, *errpf = err + (4 - 1) * dt * stepC * 4;
+    const char *cell1 = cell + dt * stepC * 4, *cellpf = cell + 5 * dt * stepC * 4, *patpf = pat + 4 * dt * PS;
+    const char *delta1 = (const char *)p.delta_op - BIAS * stepA * 2 - dt * stepA * 2;
+    unsigned cnt = (unsigned)T - 1;                  // steps behind the current one
+
+    float fgn = 0.f, ecn = 0.f, dign = 0.f, dfgn = 0.f, dni = 0.f, dog = 0.f;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f, spi = 0.f, spf = 0.f, spo = 0.f;
+    float ccA, ccB, th0, th1, th2, th3, cp0, cp1, cp2, cp3;
+    int pt0, pt1, pt2, pt3;
+    float x0, x1, m, t2m, wm, carm, d2m, d3m, d4m, car;
+    unsigned long long last, tq;
+    unsigned spin = 0, gave = 0;
+#ifdef CN_S2C_STAMP
+    unsigned st[7] = {0, 0, 0, 0, 0, 0, 0}, tz;
+    unsigned long long tm;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    lds_barrier();
+#ifdef CN_S2C_STAMP
+    unsigned tl = (unsigned)__builtin_amdgcn_s_memtime();
+    asm volatile(S2C_ASM_TEXT_STAMP
+#else
+    asm volatile(S2C_ASM_TEXT
+#endif
+        : [fgn] "+v"(fgn), [ecn] "+v"(ecn), [dign] "+v"(dign), [dfgn] "+v"(dfgn), [dni] "+v"(dni), [dog] "+v"(dog),
+          [sb0] "+v"(sb0), [sb1] "+v"(sb1), [sb2] "+v"(sb2), [sb3] "+v"(sb3), [spi] "+v"(spi), [spf] "+v"(spf), [spo] "+v"(spo),
+          [oA] "+v"(oA), [oC] "+v"(oC), [oD] "+v"(oD), [oP] "+v"(oP), [tagc] "+v"(tagc), [cnt] "+s"(cnt), [spin] "+s"(spin), [gave] "+s"(gave),
+          [last] "=&s"(last), [tq] "=&s"(tq),
+          [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [th0] "=&v"(th0), [th1] "=&v"(th1), [th2] "=&v"(th2), [th3] "=&v"(th3),
+          [cp0] "=&v"(cp0), [cp1] "=&v"(cp1), [cp2] "=&v"(cp2), [cp3] "=&v"(cp3),
+          [pt0] "=&v"(pt0), [pt1] "=&v"(pt1), [pt2] "=&v"(pt2), [pt3] "=&v"(pt3),
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [m] "=&v"(m), [t2m] "=&v"(t2m), [wm] "=&v"(wm), [carm] "=&v"(carm),
+          [d2m] "=&v"(d2m), [d3m] "=&v"(d3m), [d4m] "=&v"(d4m), [car] "=&v"(car)
+#ifdef CN_S2C_STAMP
+          , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]), [st6] "+s"(st[6]),
+          [tz] "=&s"(tz), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#endif
+        : [w0k0] "a"(w[0][0]), [w0k1] "a"(w[0][1]), [w0k2] "a"(w[0][2]), [w0k3] "a"(w[0][3]), [w0k4] "a"(w[0][4]), [w0k5] "a"(w[0][5]), [w0k6] "a"(w[0][6]), [w0k7] "a"(w[0][7]), [w0k8] "a"(w[0][8]), [w0k9] "a"(w[0][9]), [w0k10] "a"(w[0][10]), [w0k11] "a"(w[0][11]), [w0k12] "a"(w[0][12]), [w0k13] "a"(w[0][13]), [w0k14] "a"(w[0][14]), [w0k15] "a"(w[0][15]), [w1k0] "a"(w[1][0]), [w1k1] "a"(w[1][1]), [w1k2] "a"(w[1][2]), [w1k3] "a"(w[1][3]), [w1k4] "a"(w[1][4]), [w1k5] "a"(w[1][5]), [w1k6] "a"(w[1][6]), [w1k7] "a"(w[1][7]), [w1k8] "a"(w[1][8]), [w1k9] "a"(w[1][9]), [w1k10] "a"(w[1][10]), [w1k11] "a"(w[1][11]), [w1k12] "a"(w[1][12]), [w1k13] "a"(w[1][13]), [w1k14] "a"(w[1][14]), [w1k15] "a"(w[1][15]),
+          [spidx] "v"(spidx), [av] "v"(av), [ugm] "s"(ugm), [oT] "v"(oT), [oT1] "v"(oT1), [oTp] "v"(oTp), [oTp1] "v"(oTp1),
+          [oXm0] "v"(oXm0), [oXm1] "v"(oXm1), [oXt0] "v"(oXt0), [oXt1] "v"(oXt1), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
+          [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(cell), [cell1] "s"(cell1), [cellpf] "s"(cellpf), [th] "s"(th), [thpf] "s"(thpf),
+          [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta1] "s"(delta1), [xch] "s"(xch), [fault] "s"(p.fault),
+          [sA] "s"(sA), [sC] "s"(sC), [sD] "s"(sD), [sP] "s"(sP)
+        : "memory", "vcc", "scc",
+          "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
+
+#ifdef CN_S2C_STAMP
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int i = 0; i < 7; ++i) cn_s2c_stamp_buf[wave][i] = st[i];
+        cn_s2c_stamp_buf[wave][7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);      // 100 MHz ticks over the loop
+    }
+#endif
+    // fold the two sequences of each unit column, then one atomic per (gate, unit) and workgroup
+    float v[7] = {sb0, sb1, sb2, sb3, spi, spf, spo};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
+    if (sq == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------
 template <int PREC, int HP, int UPC, int RPL, bool BWD>
@@ -1354,10 +1490,13 @@ static void launch_cluster_rpl(hipStream_t s, bool bwd, const LstmRec &p)
 // the s2c cut: bf16, Hp = 256, backward, one sequence per lane, an even number of sequences, both members of every cluster resident
 static bool s2c_applies(int prec, bool bwd, const LstmRec &p)
 {
-    // (the compiled kernel measures 25 % slower per step than the 8-wave cluster kernel -- reading B 2.77 -> 3.05 ms, LVCSR 9.88 ->
-    // 10.68 ms per fraction: 154 AGPR copies per step and one wave per SIMD to issue them --; it is the twin the hand-written loop
-    // is held against, selected with CN_S2C=1)
-    if (!bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2 || !getenv("CN_S2C")) return false;
+    // (the COMPILED kernel of the cut measures 25 % slower per step than the 8-wave cluster kernel -- reading B 2.77 -> 3.05 ms, LVCSR
+    // 9.88 -> 10.68 ms per fraction: 154 AGPR copies per step and one wave per SIMD to issue them --; it is the twin the
+    // hand-written loop is held against, selected with CN_S2C=1.  CN_NO_S2C=1: the 8-wave kernel.)
+    if (!bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2 || getenv("CN_NO_S2C") || getenv("CN_BWD_PSUM")) return false;
+    // the hand-written loop addresses activations with 32-bit byte offsets that run 8 steps ahead (as the other hand-written loops);
+    // its compiled twin (CN_S2C=1) has no such limit but loses to the 8-wave kernel
+    if (!getenv("CN_S2C") && (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 >= 0xF0000000ull) return false;
     const int nclusters = p.dirs * (p.PS / 2);
     return (nclusters + 7) / 8 * 8 * 2 <= p.cluster_cus;
 }
@@ -1367,11 +1506,25 @@ static void launch_s2c(hipStream_t s, const LstmRec &p)
     constexpr int pitch = lds_pitch(8 * 64);
     const size_t lds = 2 * 9 * (size_t)pitch + (((size_t)p.T * 2 + 15) & ~(size_t)15);
     static DeviceOnce attr_once;
-    if (attr_once.first()) (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_once.first()) {
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    const bool hand = !getenv("CN_S2C");
     // (one workgroup per CU: each claims the CU's whole LDS so that no gradient-GEMM workgroup is placed beside it, cn_lstm.hip)
     size_t lds_claim = getenv("CN_NO_LDS_CLAIM") ? lds : (size_t)(160 * 1024 - 1024);
-    hipLaunchKernelGGL(lstm_bwd_s2c_kernel, dim3(grid), dim3(256), lds_claim < lds ? lds : lds_claim, s, p);
-    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_bwd_s2c_kernel");
+    hipLaunchKernelGGL(hand ? lstm_bwd_s2c_asm_kernel : lstm_bwd_s2c_kernel, dim3(grid), dim3(256), lds_claim < lds ? lds : lds_claim, s, p);
+    if (p.kname) snprintf(p.kname, CN_KNAME_LEN, hand ? "lstm_bwd_s2c_asm_kernel" : "lstm_bwd_s2c_kernel");
+}
+
+// CUs the backward cluster launch of this shape occupies (0: not a cluster shape) -- what a gradient GEMM beside it must leave free
+int lstm_cluster_bwd_cus(int prec, const LstmRec &p)
+{
+    const int CS = lstm_cluster_size(prec, p.Hp, p.dirs, p.PS, p.rpl, p.cluster_cus);
+    if (CS == 0) return 0;
+    if (s2c_applies(prec, true, p)) return (p.dirs * (p.PS / 2) + 7) / 8 * 8 * 2;
+    const int nclusters = p.dirs * (p.PS / (4 * p.rpl));
+    return (nclusters + 7) / 8 * 8 * (CS + (CS == 8 ? 1 : 0));      // (+ the helper workgroups of the 8-CU shape)
 }
 
 static void launch_cluster_shape(hipStream_t s, int prec, bool bwd, const LstmRec &p)

@@ -196,3 +196,18 @@ def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_co
         assert adds
         barrier = max(k for k in range(adds[-1], k1) if body[k] == "s_barrier")
         assert any("s_waitcnt vmcnt(0)" in body[k] for k in range(adds[-1], barrier)), body[adds[-1]:barrier + 1]
+
+
+def test_generated_loop_of_the_two_cu_backward_kernel_is_in_sync_with_its_generator():
+    """lstm-rnn_amd/csrc/cn_lstm_s2c_loop.inc is the output of tools/gen_s2c_loop.py (the step of lstm_bwd_s2c_asm_kernel as a
+    schedule: poll, own K half, exchange, partner K half, block errors; the timing build's text beside it)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "S2C_POLL"}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_s2c_loop.py")], capture_output=True, text=True, check=True, env=env).stdout
+    with open(os.path.join(root, "lstm-rnn_amd", "csrc", "cn_lstm_s2c_loop.inc")) as f:
+        assert f.read() == out
+    plain = out.split("#define S2C_ASM_TEXT_STAMP")[0]
+    assert plain.count("v_smfmac_f32_16x16x64_bf16") == 4 * 32          # four step bodies of 32 MFMAs
+    assert plain.count("ds_read_b128") == 4 * 16                        # ONE view: eight reads per K half
+    assert plain.count("s_barrier") == 4 * 2 and "s_memtime" not in plain

@@ -120,7 +120,7 @@ def test_single_layer_internals_hand_written_loops(pkg, orc):
 
 def test_reading_b_one_cu_forward_loop_and_two_cu_backward_clusters(pkg, orc):
     """39 -> 3 x blstm500 -> softmax183 (250 units per direction, Hp = 256) at PS = 16, T = 96: lstm_fwd_s2w_asm_kernel (generated
-    step body) and the 2-CU backward cluster kernel."""
+    step body) and the hand-written two-CU backward loop (lstm_bwd_s2c_asm_kernel, round 5)."""
     rng = np.random.RandomState(72)
     P, C, PS = 39, 183, 16
     layers = net_desc(P, [("blstm", 500)] * 3, C)
@@ -128,17 +128,22 @@ def test_reading_b_one_cu_forward_loop_and_two_cu_backward_clusters(pkg, orc):
     lengths = [96, 95, 93, 90, 90, 84, 80, 71, 66, 60, 52, 41, 30, 12, 3]
     xs, ts = random_sequences(rng, lengths, P, C=C)
     frac = pkg.make_fraction(xs, ts, PS)
-    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2w_asm_kernel", "lstm_bwd_cluster_kernel<0,256,128,1>"))
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2w_asm_kernel", "lstm_bwd_s2c_asm_kernel"))
     print("bf16 pinned, reading B:", {k: float("%.3g" % v) for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("variant", ["s2c", "helpers"])
+@pytest.mark.parametrize("variant", ["s2c", "cluster", "helpers"])
 def test_reading_b_backward_cluster_variants(pkg, orc, monkeypatch, variant):
-    """The same case through the other builds of the 2-CU backward pass: `s2c` = lstm_bwd_s2c_kernel (two sequences per cluster,
-    one wave per SIMD, K halves = own / partner units; CN_S2C=1: the compiled twin of the cut, slower than the 8-wave kernel and
-    not selected by default), `helpers` = the 8-wave kernel WITH the L2-warming helper workgroups the 8-CU shape gets by default
-    (CN_CLUSTER_HELPERS=1: helpers never write, so the launch must agree with the oracle like the one without them)."""
-    monkeypatch.setenv("CN_S2C" if variant == "s2c" else "CN_CLUSTER_HELPERS", "1")
+    """The same case through the other builds of the 2-CU backward pass: `s2c` = lstm_bwd_s2c_kernel (CN_S2C=1: the compiled twin
+    of the hand-written loop's cut, slower than the 8-wave kernel), `cluster` = the 8-wave cluster kernel of rounds 2-4 (four
+    sequences per cluster; CN_NO_S2C=1), `helpers` = that kernel WITH the L2-warming helper workgroups the 8-CU shape gets by
+    default (CN_CLUSTER_HELPERS=1: helpers never write, so the launch must agree with the oracle like the one without them)."""
+    if variant == "s2c":
+        monkeypatch.setenv("CN_S2C", "1")
+    else:
+        monkeypatch.setenv("CN_NO_S2C", "1")
+        if variant == "helpers":
+            monkeypatch.setenv("CN_CLUSTER_HELPERS", "1")
     rng = np.random.RandomState(72)
     P, C, PS = 39, 183, 16
     layers = net_desc(P, [("blstm", 500)] * 3, C)

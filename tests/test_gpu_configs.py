@@ -172,7 +172,7 @@ def test_config3_lvcsr_stack_at_sixteen_sequences_of_up_to_96_frames(pkg, orc, p
         ref, net, (e_ref, c_ref), (e, c) = run_both(pkg, orc, layers, weights, frac, PS, precision=precision)
         with net:
             if precision == 1:
-                assert net.recurrent_kernel(False) == "lstm_fwd_s2w_asm_kernel" and net.recurrent_kernel(True).startswith("lstm_bwd_cluster_kernel")
+                assert net.recurrent_kernel(False) == "lstm_fwd_s2w_asm_kernel" and net.recurrent_kernel(True) == "lstm_bwd_s2c_asm_kernel"
             real = real_mask(frac)
             y, yr = net.outputs().reshape(-1, C)[real], ref.outputs().reshape(-1, C)[real]
             assert np.abs(y - yr).max() < tol and np.abs(y.sum(1) - 1.0).max() < 1e-4
@@ -381,9 +381,10 @@ def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
     last 12 to validate on, identical initial weights (normal, sigma 0.1 as in the example's config.cfg), stochastic momentum
     SGD through the C++ driver in f32, bf16x3 and bf16 (tools/chime_convergence.py).  What the benchmarked bf16 arithmetic
     does to TRAINING (the single-pass distance is pinned elsewhere):
-      (i)  lr 1e-5 (the example's), 30 epochs -- the smooth part of training, validation class error 96 % -> ~70 %: bf16 follows
-           f32 epoch by epoch (measured over 20 epochs: <= 0.07 % absolute on the class error, 3e-4 relative on the error; bound here:
-           1 % absolute, 1 % relative -- towards epoch 30 single frames start to flip between the modes, 0.7 % seen for bf16x3);
+      (i)  lr 1e-5 (the example's), 20 epochs -- the smooth part of training, validation class error 96 % -> ~75 %: bf16 follows
+           f32 epoch by epoch (measured: <= 0.07 % absolute on the class error, 3e-4 relative on the error; bound here: 0.5 %
+           absolute, 0.5 % relative.  From epoch ~25 on the runs begin to decorrelate -- 0.9 % / 1 % seen at epoch 27 for bf16x3,
+           the fp32-tolerance mode -- which is what (ii) looks at);
       (ii) lr 3e-5, 60 epochs -- training to ~40 %: the three runs decorrelate like any three SGD runs (from epoch ~12 on the
            class error of ONE mode moves by +-3 % from epoch to epoch), so what is compared is the best epoch (what early stopping
            keeps) and the mean of the last ten: bf16 within 2 % absolute of f32 -- the fp32-tolerance mode bf16x3 itself ends 1.5 %
@@ -392,15 +393,15 @@ def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import chime_convergence as cc
-    smooth = cc.run(str(tmp_path), epochs=30, ps=10, lr=1e-5)
+    smooth = cc.run(str(tmp_path), epochs=20, ps=10, lr=1e-5)
     f32, b16, x3 = smooth["modes"]["f32"], smooth["modes"]["bf16"], smooth["modes"]["bf16x3"]
-    assert len(f32) == len(b16) == len(x3) == 30
+    assert len(f32) == len(b16) == len(x3) == 20
     assert f32[-1]["val_class_err"] < f32[0]["val_class_err"] - 15.0                 # it trains
     for a, b, c in zip(f32, b16, x3):
-        assert abs(a["val_class_err"] - b["val_class_err"]) <= 1.0, (a, b)
-        assert abs(a["val_err"] - b["val_err"]) <= 1e-2 * a["val_err"], (a, b)
-        assert abs(a["train_err"] - b["train_err"]) <= 1e-2 * a["train_err"], (a, b)
-        assert abs(a["val_class_err"] - c["val_class_err"]) <= 1.0 and abs(a["val_err"] - c["val_err"]) <= 1e-2 * a["val_err"], (a, c)
+        assert abs(a["val_class_err"] - b["val_class_err"]) <= 0.5, (a, b)
+        assert abs(a["val_err"] - b["val_err"]) <= 5e-3 * a["val_err"], (a, b)
+        assert abs(a["train_err"] - b["train_err"]) <= 5e-3 * a["train_err"], (a, b)
+        assert abs(a["val_class_err"] - c["val_class_err"]) <= 0.5 and abs(a["val_err"] - c["val_err"]) <= 5e-3 * a["val_err"], (a, c)
     far = cc.run(str(tmp_path), epochs=60, ps=10, lr=3e-5)
     stat = {}
     for mode, rows in far["modes"].items():

@@ -854,6 +854,50 @@ def test_hand_written_wide_forward_loop_equals_its_compiled_twin_bit_for_bit(pkg
     assert np.abs(got["asm"][1]["out"] - got["cluster"][1]["out"]).max() < 3e-2
 
 
+@pytest.mark.parametrize("kind,size,T", [("blstm", 500, 1), ("blstm", 500, 2), ("blstm", 500, 3), ("blstm", 500, 5), ("lstm", 250, 6), ("blstm", 512, 37),
+                                         ("blstm", 500, 64)])
+def test_hand_written_two_cu_backward_loop_equals_its_compiled_twin_bit_for_bit(pkg, orc, monkeypatch, kind, size, T):
+    """Hp = 256, backward, clusters of two CUs with two sequences each (cn_lstm_cluster.hip: lstm_bwd_s2c_asm_kernel, generated
+    loop text, 32 MFMAs per wave and step around the exchange) against lstm_bwd_s2c_kernel, the compiled kernel of the same cut:
+    all four deltas on every real slot bit-identical, gradients to the split-K atomics' last bits; and against the 8-wave cluster
+    kernel it replaces at the bf16 tolerances (another summation order of the same product).  T = 1, 2, 3, 5: the loop is left
+    after any step of its four-step body; T = 64 = the buffers' length: the prefetch runs into the guard steps."""
+    rng = np.random.RandomState(800 + T)
+    P, C, PS = 9, 7, 11
+    layers = net_desc(P, [(kind, size), (kind, size)], C)
+    weights = random_weights(layers, rng, 0.05)
+    lengths = [max(1, T - (i % 4) * (T // 4)) for i in range(PS - 1)]
+    lengths[0] = T
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    real = real_mask(frac)
+    got = {}
+    for mode, env in (("cluster", "CN_NO_S2C"), ("cpp", "CN_S2C"), ("asm", None)):
+        if env:
+            monkeypatch.setenv(env, "1")
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+            net.load_sequences(frac); net.compute_forward_pass()
+            net.compute_backward_pass()
+            name = net.recurrent_kernel(True)
+            vals = {}
+            for lay in net.layers[1:3]:
+                for dd in range(lay.dirs):
+                    for nm in ("niDeltas", "igDeltas", "fgDeltas", "ogDeltas"):
+                        vals["%s/%d/%s" % (lay.name, dd, nm)] = lay.internal(nm, dd).reshape(-1, lay.H)[real]
+            grads = {lay.name: lay.weight_updates() for lay in net.trainable_layers()}
+            got[mode] = (name, vals, grads)
+        if env:
+            monkeypatch.delenv(env)
+    assert got["asm"][0] == "lstm_bwd_s2c_asm_kernel" and got["cpp"][0] == "lstm_bwd_s2c_kernel"
+    assert got["cluster"][0].startswith("lstm_bwd_cluster_kernel"), got["cluster"][0]
+    for key, v in got["asm"][1].items():
+        assert np.array_equal(v, got["cpp"][1][key]), (key, np.abs(v - got["cpp"][1][key]).max())
+        assert np.abs(v - got["cluster"][1][key]).max() <= 2.0 ** -7 * max(1e-3, np.abs(got["cluster"][1][key]).max()), key
+    for name, g in got["asm"][2].items():
+        assert rel_err(g, got["cpp"][2][name]) < 1e-6, name
+        assert rel_err(g, got["cluster"][2][name]) < 2e-3, name
+
+
 @pytest.mark.parametrize("kind,size,T", [("blstm", 250, 1), ("blstm", 250, 2), ("blstm", 250, 5), ("lstm", 128, 9), ("blstm", 256, 37), ("blstm", 250, 64)])
 def test_hand_written_split_bf16_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
     """The same for the split-bf16 (CN_PREC_BF16X3) hand-written loops of the s2 cut against the compiled kernels of that cut
