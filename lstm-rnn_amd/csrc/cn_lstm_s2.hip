@@ -1195,8 +1195,13 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 // Dummy slots as in the forward loop: the pattern type alone decides (for t < minSeqLength the unused slots of a partial
 // fraction carry zero errors, so their deltas are zero either way).
 //
-// Fixed registers (clobbered): stage k = 0..3: v[200+12k : 203+12k] n,i,f,o; v[204+12k : 207+12k] / v[208+12k : 211+12k] the
-// accumulators of K half 0 / 1; v[248:249] the four bf16 deltas of the step.
+// Round 5: ONE view of the operand tile.  The two zero-padded views (one per unit group) cost two LDS reads per K chunk; with
+// lanes c >= 8 reading the rows of lanes c - 8 the A operand's rows 8 .. 15 repeat rows 0 .. 7, ONE read serves both unit
+// groups' MFMAs, and the MFMA of group j leaves that group's sums for both sequences in all four lane quarters -- in an
+// accumulator of its own; a lane keeps the sums of its own group (one select per step).  Four reads instead of eight per step,
+// four accumulators instead of two per stage, the same sixteen MFMAs in the same order per accumulator (bit-equal).
+// Fixed registers (clobbered): stage k = 0..3 at b = 168 + 20k: v[b : b+3] n,i,f,o; v[b+4 : b+7] / v[b+8 : b+11] the accumulators
+// of K half 0 / 1 of unit group 0; v[b+12 : b+15] / v[b+16 : b+19] of unit group 1; v[248:249] the four bf16 deltas of the step.
 #ifdef CN_S2_DIAG_NOMFMA
 #define S2B_MF(acc, a, w) ""
 #else
@@ -1257,55 +1262,51 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
 // of this step; R: LDS byte offset of the tile read; WT: operand holding the lane's address in the tile written (the two
 // dword offsets of ds_write2_b32 are 8-bit fields: its second row, one pitch = 72 dwords on, fits; the tile base does not);
 // PFCODE / PFECODE: the prefetch into this stage; BLOCKCODE: the block of the NEXT stage (behind a wait for its loads)
-#define S2B_STEP(ACCA, A0, A1, ACCB, B2, B3, CS, R, WT, PFCODE, PFECODE, BLOCKCODE) \
+#define S2B_STEP(ACCA, A0, A1, ACCB, B2, B3, ACCC, C0, C1, ACCD, D2, D3, CS, R, WT, PFCODE, PFECODE, BLOCKCODE) \
     S2B_ST(0) \
     "ds_read_b128 %[r00], %[av0] offset:" R "\n\t" \
-    "ds_read_b128 %[r10], %[av1] offset:" R "\n\t" \
     "ds_read_b128 %[r01], %[av0] offset:" R "+64\n\t" \
-    "ds_read_b128 %[r11], %[av1] offset:" R "+64\n\t" \
     "ds_read_b128 %[r02], %[av0] offset:" R "+128\n\t" \
-    "ds_read_b128 %[r12], %[av1] offset:" R "+128\n\t" \
     "ds_read_b128 %[r03], %[av0] offset:" R "+192\n\t" \
-    "ds_read_b128 %[r13], %[av1] offset:" R "+192\n\t" \
+    "v_mov_b32 " C0 ", " A0 "\n\t" \
     "v_mov_b32 " A1 ", 0\n\t" \
     "v_mov_b32 " B2 ", 0\n\t" \
     "v_mov_b32 " B3 ", 0\n\t" \
+    "v_mov_b32 " C1 ", 0\n\t" \
+    "v_mov_b32 " D2 ", 0\n\t" \
+    "v_mov_b32 " D3 ", 0\n\t" \
     PFCODE \
-    "s_waitcnt lgkmcnt(7)\n\t" \
+    "s_waitcnt lgkmcnt(3)\n\t" \
     S2B_ST(1) \
     S2B_MF(ACCA, "r00", "w0k0") \
     "v_add_u32 %[oA], %[oA], %[sA]\n\t" \
     S2B_MF(ACCB, "r00", "w0k4") \
     "v_add_u32 %[oC], %[oC], %[sC]\n\t" \
-    "s_waitcnt lgkmcnt(6)\n\t" \
-    S2B_MF(ACCA, "r10", "w1k0") \
+    S2B_MF(ACCC, "r00", "w1k0") \
     "v_add_u32 %[oD], %[oD], %[sD]\n\t" \
-    S2B_MF(ACCB, "r10", "w1k4") \
+    S2B_MF(ACCD, "r00", "w1k4") \
     "v_add_u32 %[oP], %[oP], %[sP]\n\t" \
-    "s_waitcnt lgkmcnt(5)\n\t" \
+    "s_waitcnt lgkmcnt(2)\n\t" \
     S2B_MF(ACCA, "r01", "w0k1") \
     S2B_MASK("t2m") \
     S2B_MF(ACCB, "r01", "w0k5") \
     S2B_MASK("wm") \
-    "s_waitcnt lgkmcnt(4)\n\t" \
-    S2B_MF(ACCA, "r11", "w1k1") \
+    S2B_MF(ACCC, "r01", "w1k1") \
     "v_mul_f32 %[carm], %[car], %[m]\n\t" \
-    S2B_MF(ACCB, "r11", "w1k5") \
+    S2B_MF(ACCD, "r01", "w1k5") \
     S2B_MASK("d2m") \
-    "s_waitcnt lgkmcnt(3)\n\t" \
+    "s_waitcnt lgkmcnt(1)\n\t" \
     S2B_MF(ACCA, "r02", "w0k2") \
     S2B_MASK("d3m") \
     S2B_MF(ACCB, "r02", "w0k6") \
     S2B_MASK("d4m") \
-    "s_waitcnt lgkmcnt(2)\n\t" \
-    S2B_MF(ACCA, "r12", "w1k2") \
-    S2B_MF(ACCB, "r12", "w1k6") \
-    "s_waitcnt lgkmcnt(1)\n\t" \
+    S2B_MF(ACCC, "r02", "w1k2") \
+    S2B_MF(ACCD, "r02", "w1k6") \
+    "s_waitcnt lgkmcnt(0)\n\t" \
     S2B_MF(ACCA, "r03", "w0k3") \
     S2B_MF(ACCB, "r03", "w0k7") \
-    "s_waitcnt lgkmcnt(0)\n\t" \
-    S2B_MF(ACCA, "r13", "w1k3") \
-    S2B_MF(ACCB, "r13", "w1k7") \
+    S2B_MF(ACCC, "r03", "w1k3") \
+    S2B_MF(ACCD, "r03", "w1k7") \
     S2B_ST(2) \
     "v_add_f32 %[sb0], %[sb0], %[dni]\n\t" \
     "v_add_f32 %[sb1], %[sb1], %[dign]\n\t" \
@@ -1318,7 +1319,11 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "s_nop 2\n\t" \
     "v_add_f32 %[x0], " A0 ", " A1 "\n\t" \
     "v_add_f32 %[x1], " B2 ", " B3 "\n\t" \
+    "v_add_f32 %[car], " C0 ", " C1 "\n\t" \
     "v_add_f32 %[x0], %[x0], %[x1]\n\t" \
+    "v_add_f32 %[x1], " D2 ", " D3 "\n\t" \
+    "v_add_f32 %[car], %[car], %[x1]\n\t" \
+    "v_cndmask_b32_e64 %[x0], %[x0], %[car], %[ugm]\n\t" \
     PFECODE \
     S2B_ST(3) \
     "v_mul_f32 %[dog], %[t2m], %[x0]\n\t" \
@@ -1346,14 +1351,14 @@ __device__ unsigned cn_s2_stamp_buf[4][8];
     "s_cbranch_scc1 9f\n\t"
 // tiles: plane = 9 * 288 = 2592 bytes; tile 0 at 0, tile 1 at 2592.  Stage k: registers 200 + 12 k ...; cell-state registers
 // alternate with the step parity (ccA holds the cell state of even steps)
-#define S2B_STEP_0 S2B_STEP("v[204:207]", "v204", "v205", "v[208:211]", "v210", "v211", "ccA", "0",    "oT1", S2B_PF("v[200:203]", "th0", "cp0", "pt0"), S2B_PFE("v204"), \
-                            S2B_BLOCK("v212", "v213", "v214", "v215", "th1", "cp1", "pt1", "ccA"))
-#define S2B_STEP_1 S2B_STEP("v[216:219]", "v216", "v217", "v[220:223]", "v222", "v223", "ccB", "2592", "oT",  S2B_PF("v[212:215]", "th1", "cp1", "pt1"), S2B_PFE("v216"), \
-                            S2B_BLOCK("v224", "v225", "v226", "v227", "th2", "cp2", "pt2", "ccB"))
-#define S2B_STEP_2 S2B_STEP("v[228:231]", "v228", "v229", "v[232:235]", "v234", "v235", "ccA", "0",    "oT1", S2B_PF("v[224:227]", "th2", "cp2", "pt2"), S2B_PFE("v228"), \
-                            S2B_BLOCK("v236", "v237", "v238", "v239", "th3", "cp3", "pt3", "ccA"))
-#define S2B_STEP_3 S2B_STEP("v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "ccB", "2592", "oT",  S2B_PF("v[236:239]", "th3", "cp3", "pt3"), S2B_PFE("v240"), \
-                            S2B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB"))
+#define S2B_STEP_0 S2B_STEP("v[172:175]", "v172", "v173", "v[176:179]", "v178", "v179", "v[180:183]", "v180", "v181", "v[184:187]", "v186", "v187", "ccA", "0", "oT1", S2B_PF("v[168:171]", "th0", "cp0", "pt0"), S2B_PFE("v172"), \
+                            S2B_BLOCK("v188", "v189", "v190", "v191", "th1", "cp1", "pt1", "ccA"))
+#define S2B_STEP_1 S2B_STEP("v[192:195]", "v192", "v193", "v[196:199]", "v198", "v199", "v[200:203]", "v200", "v201", "v[204:207]", "v206", "v207", "ccB", "2592", "oT", S2B_PF("v[188:191]", "th1", "cp1", "pt1"), S2B_PFE("v192"), \
+                            S2B_BLOCK("v208", "v209", "v210", "v211", "th2", "cp2", "pt2", "ccB"))
+#define S2B_STEP_2 S2B_STEP("v[212:215]", "v212", "v213", "v[216:219]", "v218", "v219", "v[220:223]", "v220", "v221", "v[224:227]", "v226", "v227", "ccA", "0", "oT1", S2B_PF("v[208:211]", "th2", "cp2", "pt2"), S2B_PFE("v212"), \
+                            S2B_BLOCK("v228", "v229", "v230", "v231", "th3", "cp3", "pt3", "ccA"))
+#define S2B_STEP_3 S2B_STEP("v[232:235]", "v232", "v233", "v[236:239]", "v238", "v239", "v[240:243]", "v240", "v241", "v[244:247]", "v246", "v247", "ccB", "2592", "oT", S2B_PF("v[228:231]", "th3", "cp3", "pt3"), S2B_PFE("v232"), \
+                            S2B_BLOCK("v168", "v169", "v170", "v171", "th0", "cp0", "pt0", "ccB"))
 // the stages of the first four steps: step k at offsets advanced by k steps (x0 / x1 / m: scratch offsets)
 #define S2B_FIRST(AXT, A0, TH, CP, PT) \
     "global_load_dwordx4 " AXT ", %[x0], %[acts]\n\t" \
@@ -1390,7 +1395,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
         for (int kc = 0; kc < KCS; ++kc)
             w[j][kc] = sp_load_bf16(Wd + ((long)(32 * wave + 16 * j + c) * 4 * HP + kc * 64 + q * 16) * 2);
     const int spidx = sp_index(c);
-    const unsigned av0 = (c < 8 ? c : 8) * pitch + q * 16, av1 = (c >= 8 ? c - 8 : 8) * pitch + q * 16;
+    // ONE view of the tile: lanes c >= 8 read the rows of lanes c - 8; a lane keeps the sums of its own unit group (ugm: group 1's lanes)
+    const unsigned av0 = (c & 7) * pitch + q * 16;
+    const unsigned long long ugm = 0xFFFFFFFF00000000ull;
 
     const int unit = 32 * wave + 16 * ug + c;
     const float pi = p.peep[(d * 3 + 0) * HP + unit], pf = p.peep[(d * 3 + 1) * HP + unit], po = p.peep[(d * 3 + 2) * HP + unit];
@@ -1420,7 +1427,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f, spi = 0.f, spf = 0.f, spo = 0.f;
     float ccA, ccB, th0, th1, th2, th3, cp0, cp1, cp2, cp3;
     int pt0, pt1, pt2, pt3;
-    u32x4 r00, r01, r02, r03, r10, r11, r12, r13;
+    u32x4 r00, r01, r02, r03;
     float x0, x1, m, t2m, wm, carm, d2m, d3m, d4m, car;
     unsigned long long last;
 #ifdef CN_S2_STAMP
@@ -1434,24 +1441,24 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
 #endif
     lds_barrier();
     asm volatile(
-        // (registers 2, 3 of the K-half-0 accumulators and 0, 1 of the K-half-1 accumulators collect products of rows that belong
-        // to the other half; they are never read -- cleared once so that they hold numbers)
-        "v_mov_b32 v206, 0\n\tv_mov_b32 v207, 0\n\tv_mov_b32 v208, 0\n\tv_mov_b32 v209, 0\n\t"
-        "v_mov_b32 v218, 0\n\tv_mov_b32 v219, 0\n\tv_mov_b32 v220, 0\n\tv_mov_b32 v221, 0\n\t"
-        "v_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\tv_mov_b32 v232, 0\n\tv_mov_b32 v233, 0\n\t"
-        "v_mov_b32 v242, 0\n\tv_mov_b32 v243, 0\n\tv_mov_b32 v244, 0\n\tv_mov_b32 v245, 0\n\t"
+        // (registers 2, 3 of the K-half-0 accumulators and 0, 1 of the K-half-1 accumulators -- of either unit group -- collect products
+        // of rows that belong to the other half; they are never read -- cleared once so that they hold numbers)
+        "v_mov_b32 v174, 0\n\tv_mov_b32 v175, 0\n\tv_mov_b32 v176, 0\n\tv_mov_b32 v177, 0\n\tv_mov_b32 v182, 0\n\tv_mov_b32 v183, 0\n\tv_mov_b32 v184, 0\n\tv_mov_b32 v185, 0\n\t"
+        "v_mov_b32 v194, 0\n\tv_mov_b32 v195, 0\n\tv_mov_b32 v196, 0\n\tv_mov_b32 v197, 0\n\tv_mov_b32 v202, 0\n\tv_mov_b32 v203, 0\n\tv_mov_b32 v204, 0\n\tv_mov_b32 v205, 0\n\t"
+        "v_mov_b32 v214, 0\n\tv_mov_b32 v215, 0\n\tv_mov_b32 v216, 0\n\tv_mov_b32 v217, 0\n\tv_mov_b32 v222, 0\n\tv_mov_b32 v223, 0\n\tv_mov_b32 v224, 0\n\tv_mov_b32 v225, 0\n\t"
+        "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v236, 0\n\tv_mov_b32 v237, 0\n\tv_mov_b32 v242, 0\n\tv_mov_b32 v243, 0\n\tv_mov_b32 v244, 0\n\tv_mov_b32 v245, 0\n\t"
         // cell state of the first processed step; the stages of the first four steps (beyond T: guard steps, never used)
         "global_load_dword %[ccA], %[oC], %[cell]\n\t"
         "v_mov_b32 %[x0], %[oA]\n\tv_mov_b32 %[x1], %[oC]\n\tv_mov_b32 %[m], %[oP]\n\t"
-        S2B_FIRST("v[200:203]", "v204", "th0", "cp0", "pt0")
-        S2B_FIRST("v[212:215]", "v216", "th1", "cp1", "pt1")
-        S2B_FIRST("v[224:227]", "v228", "th2", "cp2", "pt2")
-        S2B_FIRST("v[236:239]", "v240", "th3", "cp3", "pt3")
+        S2B_FIRST("v[168:171]", "v172", "th0", "cp0", "pt0")
+        S2B_FIRST("v[188:191]", "v192", "th1", "cp1", "pt1")
+        S2B_FIRST("v[208:211]", "v212", "th2", "cp2", "pt2")
+        S2B_FIRST("v[228:231]", "v232", "th3", "cp3", "pt3")
         "s_waitcnt vmcnt(0)\n\t"
         "s_cmp_eq_u32 %[cnt], 0\n\t"
         "s_cselect_b64 %[last], -1, 0\n\t"
         "s_nop 1\n\t"
-        S2B_BLOCK("v200", "v201", "v202", "v203", "th0", "cp0", "pt0", "ccB")
+        S2B_BLOCK("v168", "v169", "v170", "v171", "th0", "cp0", "pt0", "ccB")
         "1:\n\t"
         S2B_STEP_0
         S2B_STEP_1
@@ -1471,7 +1478,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
           [ccA] "=&v"(ccA), [ccB] "=&v"(ccB), [th0] "=&v"(th0), [th1] "=&v"(th1), [th2] "=&v"(th2), [th3] "=&v"(th3),
           [cp0] "=&v"(cp0), [cp1] "=&v"(cp1), [cp2] "=&v"(cp2), [cp3] "=&v"(cp3),
           [pt0] "=&v"(pt0), [pt1] "=&v"(pt1), [pt2] "=&v"(pt2), [pt3] "=&v"(pt3),
-          [r00] "=&v"(r00), [r01] "=&v"(r01), [r02] "=&v"(r02), [r03] "=&v"(r03), [r10] "=&v"(r10), [r11] "=&v"(r11), [r12] "=&v"(r12), [r13] "=&v"(r13),
+          [r00] "=&v"(r00), [r01] "=&v"(r01), [r02] "=&v"(r02), [r03] "=&v"(r03),
           [x0] "=&v"(x0), [x1] "=&v"(x1), [m] "=&v"(m), [t2m] "=&v"(t2m), [wm] "=&v"(wm), [carm] "=&v"(carm),
           [d2m] "=&v"(d2m), [d3m] "=&v"(d3m), [d4m] "=&v"(d4m), [car] "=&v"(car)
 #ifdef CN_S2_STAMP
@@ -1480,15 +1487,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
 #endif
         : [w0k0] "a"(w[0][0]), [w0k1] "a"(w[0][1]), [w0k2] "a"(w[0][2]), [w0k3] "a"(w[0][3]), [w0k4] "a"(w[0][4]), [w0k5] "a"(w[0][5]), [w0k6] "a"(w[0][6]), [w0k7] "a"(w[0][7]),
           [w1k0] "a"(w[1][0]), [w1k1] "a"(w[1][1]), [w1k2] "a"(w[1][2]), [w1k3] "a"(w[1][3]), [w1k4] "a"(w[1][4]), [w1k5] "a"(w[1][5]), [w1k6] "a"(w[1][6]), [w1k7] "a"(w[1][7]),
-          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [oT1] "v"(oT1), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
+          [spidx] "v"(spidx), [av0] "v"(av0), [ugm] "s"(ugm), [oT] "v"(oT), [oT1] "v"(oT1), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
           [acts] "s"(acts), [actspf] "s"(actspf), [cell] "s"(cell), [cell1] "s"(cell1), [cellpf] "s"(cellpf), [th] "s"(th), [thpf] "s"(thpf),
           [err] "s"(err), [errpf] "s"(errpf), [pat] "s"(pat), [patpf] "s"(patpf), [delta1] "s"(delta1),
           [sA] "s"(sA), [sC] "s"(sC), [sD] "s"(sD), [sP] "s"(sP)
         : "memory", "vcc", "scc",
-          "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211",
-          "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223",
-          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235",
-          "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
+          "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249");
 
 #ifdef CN_S2_STAMP
     if (blockIdx.x == 0 && lane == 0) {
