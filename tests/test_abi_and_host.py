@@ -203,7 +203,7 @@ def test_generated_loop_of_the_two_cu_backward_kernel_is_in_sync_with_its_genera
     schedule: poll, own K half, exchange, partner K half, block errors; the timing build's text beside it)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k != "S2C_POLL"}
+    env = {k: v for k, v in os.environ.items() if k not in ("S2C_POLL", "S2C_RMW")}
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_s2c_loop.py")], capture_output=True, text=True, check=True, env=env).stdout
     with open(os.path.join(root, "lstm-rnn_amd", "csrc", "cn_lstm_s2c_loop.inc")) as f:
         assert f.read() == out
