@@ -79,6 +79,27 @@ namespace cn {
 
 typedef unsigned long long u64;
 
+#ifndef CN_POLL_RMW
+#define CN_POLL_RMW 0
+#endif
+// K samples of granules, all in flight together: relaxed agent-scope loads (sc1), or -- CN_POLL_RMW -- returning atomic ORs of zero,
+// which execute in the L2 (hipcc folds an idempotent fetch_or into a load, so the instructions are written out: issued without a
+// wait, then ONE wait, then every result is re-defined behind it so that no use can be scheduled in front of the wait)
+template <int K>
+__device__ __forceinline__ void sample_all(const u64 *const (&slot)[K], u64 (&x)[K])
+{
+#if CN_POLL_RMW
+    const u64 zero = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("global_atomic_or_x2 %0, %1, %2, off sc0" : "=v"(x[i]) : "v"(slot[i]), "v"(zero) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < K; ++i) asm volatile("" : "+v"(x[i]));
+#else
+#pragma unroll
+    for (int i = 0; i < K; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 __device__ __forceinline__ void publish(u64 *slot, unsigned epoch, unsigned value)
 {
     __hip_atomic_store(slot, ((u64)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -131,8 +152,7 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
     } else {
     for (;;) {
         u64 x[K];
-#pragma unroll
-        for (int i = 0; i < K; ++i) x[i] = __hip_atomic_load(slot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sample_all<K>(slot, x);
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < K; ++i) { ok = ok && (unsigned)(x[i] >> 32) == epoch; val[i] = (unsigned)x[i]; }
