@@ -267,6 +267,7 @@ static void launch_nt(hipStream_t s, const GemmNT &g, hipEvent_t done)
 void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 {
     if (g.M <= 0 || g.N <= 0) return;
+    if (gemm_nt_mid_applies(prec, g)) { launch_gemm_nt_mid(s, g, done); return; }
     if (gemm_nt_big_applies(prec, g)) { launch_gemm_nt_big(s, prec, g, done); return; }
     // 64-row tiles when the 128-row grid leaves the chip short of workgroups (< 400 tiles: the N = 256 / 192 products of the
     // headline step, 244 tiles on 256 CUs) or the K loop is at most four k-tiles long (the input projections: a workgroup's

@@ -64,6 +64,9 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = 
 // 256 x 256 LDS-DMA variant for the MFMA-bound shapes (cn_gemm_big.hip); launch_gemm_nt dispatches to it
 bool gemm_nt_big_applies(int prec, const GemmNT &g);
 void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
+// 128 x 256 tiles, two workgroups per CU, for the output-bound short-K products (cn_gemm_nt_mid.hip)
+bool gemm_nt_mid_applies(int prec, const GemmNT &g);
+void launch_gemm_nt_mid(hipStream_t s, const GemmNT &g, hipEvent_t done = nullptr);
 // cu_budget: CUs the launch may fill with its one-per-CU workgroups when it goes to the 256 x 256 kernel (0 = the chip)
 void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget = 0);
 // 256 x 256 LDS-DMA variant for the products whose operands do not fit the caches (cn_gemm_tn_big.hip); launch_gemm_tn /

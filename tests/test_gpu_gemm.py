@@ -25,7 +25,7 @@ def lib(pkg):
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(60, 128, 32), (1000, 1024, 256), (130, 192, 96),
-                                   (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024)])
+                                   (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024), (9001, 3104, 160), (12500, 2048, 512)])
 def test_gemm_nt(lib, prec, shape):
     L, B = lib
     M, N, K = shape
@@ -47,6 +47,27 @@ def test_gemm_nt(lib, prec, shape):
     if prec == 2:       # split-bf16 x3: ~2^-16 per term, random signs -> a few 1e-5 * sqrt(K) on N(0,1) operands (float64 reference)
         ref64 = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
         assert np.abs(out - ref64).max() < 6e-5 * np.sqrt(K), np.abs(out - ref64).max()
+
+
+@pytest.mark.parametrize("shape", [(12500, 2048, 512), (9001, 3104, 160), (24577, 1024, 736), (3100, 4096, 128)])
+def test_gemm_nt_mid_is_exact_on_small_integers(lib, shape):
+    """The 128 x 256 two-workgroups-per-CU kernel (cn_gemm_nt_mid.hip; bf16, 128 <= K < 768 in whole k-tiles of 32, N <= 4096,
+    >= 384 tiles of 256 x 256): operands and bias are small integers, so every product and every fp32 partial sum is exact and
+    the result must EQUAL numpy's -- a row or k-chunk taken from the wrong place (the fill's XOR placement, the clamped edge
+    rows, the last partial tile row / column) cannot hide inside a tolerance."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randint(-3, 4, (M, K)).astype(np.float32); Bm = rng.randint(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.randint(-5, 6, N).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+    finally:
+        L.cn_ctx_destroy(ctx)
+    ref = (A.astype(np.int64) @ Bm.astype(np.int64).T + bias.astype(np.int64)).astype(np.float32)
+    assert np.array_equal(out, ref), np.argwhere(out != ref)[:4]
 
 
 @pytest.mark.parametrize("with_bias", [True, False])
@@ -80,7 +101,7 @@ def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape, with_bias, monkeypa
 @pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("flag", [0x100, 0x200])
 @pytest.mark.parametrize("act", [0, 2])
-@pytest.mark.parametrize("shape", [(300, 256, 64), (6500, 4128, 512), (25000, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(300, 256, 64), (6500, 4128, 512), (25000, 1024, 1024), (9001, 3104, 160)])
 def test_gemm_nt_operand_copy_output(lib, shape, act, flag, with_bias, monkeypatch):
     """The operand-type (bf16) copy of the result, with and without the fp32 result beside it: the small shape runs the 128 x 128
     kernel, the large ones the persistent 256 x 256 kernel, whose seam stores count in its vmcnt waits (16 or 8 per phase)."""

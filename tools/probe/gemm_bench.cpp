@@ -1,6 +1,6 @@
 // Times launch_gemm_nt / launch_gemm_tn on the shapes of the headline workload (bf16 operands, random data).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -c tools/probe/gemm_bench.cpp -o /tmp/gb.o &&
-//        hipcc --offload-arch=gfx950 /tmp/gb.o lstm-rnn_amd/csrc/cn_gemm.o lstm-rnn_amd/csrc/cn_gemm_big.o lstm-rnn_amd/csrc/cn_gemm_tn_big.o -o tools/probe/gemm_bench
+//        hipcc --offload-arch=gfx950 /tmp/gb.o lstm-rnn_amd/csrc/cn_gemm.o lstm-rnn_amd/csrc/cn_gemm_big.o lstm-rnn_amd/csrc/cn_gemm_tn_big.o lstm-rnn_amd/csrc/cn_gemm_nt_mid.o -o tools/probe/gemm_bench
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
