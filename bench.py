@@ -242,13 +242,17 @@ def main():
     # through the host).  It exercises the world > 1 control flow and stream ordering with real sums; never a measurement.
     # CN_BENCH_BACKEND=ipc: the same test situation, but the exchange is the LIBRARY's (cn_comm_init / cn_allreduce_grads /
     # cn_loss_read_global on its CN_COMM_BACKEND=ipc test backend); torch.distributed (gloo) carries the control plane only.
+    # CN_BENCH_BACKEND=p2p: the library's NATIVE exchange (CN_COMM_BACKEND=p2p: one stream-ordered kernel per bucket over
+    # peer-mapped memory, cn_comm_p2p.hip) in place of RCCL; one rank per GPU when the node has enough of them (a measurement),
+    # ranks sharing devices otherwise (a test).  gloo carries the control plane.
     backend = os.environ.get("CN_BENCH_BACKEND", "nccl")
-    if backend == "ipc":
-        os.environ["CN_COMM_BACKEND"] = "ipc"
+    if backend in ("ipc", "p2p"):
+        os.environ["CN_COMM_BACKEND"] = backend
     if backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d needs %d GPUs, this node has %d (one rank per GPU over RCCL; no device sharing)"
                          % (world, world, torch.cuda.device_count()))
-    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    shared_devices = backend != "nccl" and (backend != "p2p" or world > torch.cuda.device_count())
+    device_index = local_rank % torch.cuda.device_count() if shared_devices else local_rank
     torch.cuda.set_device(device_index)
     rendezvous_s = float(os.environ.get("CN_BENCH_RENDEZVOUS_TIMEOUT", "180"))
     if world > 1 or os.environ.get("CN_BENCH_FORCE_ALLREDUCE") == "1":
@@ -256,7 +260,7 @@ def main():
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index), timeout=datetime.timedelta(seconds=rendezvous_s))
         else:
-            dist.init_process_group("gloo" if backend == "ipc" else backend, timeout=datetime.timedelta(seconds=rendezvous_s))
+            dist.init_process_group("gloo" if backend in ("ipc", "p2p") else backend, timeout=datetime.timedelta(seconds=rendezvous_s))
 
     def bounded(what, seconds, fn, *a):
         """Run a blocking collective set-up call under a watchdog: a rank whose call does not return in time says which rank and
@@ -289,7 +293,7 @@ def main():
     # The gradient exchange is the library's own RCCL communicator (cn_comm_init / cn_allreduce_grads); torch.distributed
     # carries the control plane only (rendezvous id, barrier, max-over-ranks timing).  CN_BENCH_BACKEND=gloo swaps in the
     # torch path (compute_backward_pass_allreduce) as the test double for boxes with fewer GPUs than ranks.
-    native_comm = use_comm and backend in ("nccl", "ipc")
+    native_comm = use_comm and backend in ("nccl", "ipc", "p2p")
 
     def barrier():
         if world > 1:
@@ -403,6 +407,7 @@ def main():
         if native_comm:
             lo_hi = allmax([float(comm_world), -float(comm_world)])
             res["rccl_ranks"] = (int(-lo_hi[1]), int(lo_hi[0]))      # (min, max) over ranks
+            res["comm_backend"] = net.comm_backend()                 # (name, exchanges enqueued) as the LIBRARY reports them
         # what warm-up + the FIRST repetition's steps did to the weights is not separable from later repetitions; the
         # data-parallel equivalence test runs with min_seconds = 0 (CN_BENCH_MIN_SECONDS=0), i.e. one repetition
         upd = (wts.double() - w0.double())
@@ -467,8 +472,11 @@ def main():
     if rank == 0:
         exch = "none"
         if use_comm:
-            exch = ("flat" if flat_exchange else "per-layer, overlapped") + ((" (library communicator on its ipc TEST backend: not a measurement)" if backend == "ipc" else
-                                                                              " (library RCCL communicator)") if native_comm else " (torch.distributed test double)")
+            how = {"ipc": " (library communicator on its ipc TEST backend: not a measurement)",
+                   "p2p": " (library communicator, p2p backend: one kernel per bucket over peer-mapped memory" +
+                          ("; ranks SHARE devices: not a measurement)" if shared_devices else ")"),
+                   "nccl": " (library RCCL communicator)"}
+            exch = ("flat" if flat_exchange else "per-layer, overlapped") + (how[backend] if native_comm else " (torch.distributed test double)")
         out = {
             "metric": "train frames/sec (node), 3x250 BLSTM 39->183" if args.workload.startswith("timit_3x") else "train frames/sec (node), " + args.workload,
             "value": value, "unit": "frames/s",
@@ -485,6 +493,11 @@ def main():
         }
         out["check"] = {"error_sum": res["error_sum"], "update_l2": res["update_l2"], "update_sum": res["update_sum"],
                         **({"replicas_identical": res["replicas_identical"]} if "replicas_identical" in res else {}), "allreduce": exch}
+        if use_comm:
+            # backend: what the bound communicator says it runs (cn_comm_backend), not what the environment asked for
+            name, count = res.get("comm_backend", ("torch.distributed " + backend + " (test double)", None))
+            out["exchange"] = {"backend": name, "allreduces_enqueued": count, "granularity": "flat arena" if flat_exchange else "per layer",
+                               "one_rank_per_gpu": not shared_devices}
         if "host_frames_per_s" in res:
             out["load_path"] = {"value": res["host_frames_per_s"], "unit": "frames/s", "vs_resident": res["host_frames_per_s"] / value,
                                 "note": "same steps with every fraction handed over as HOST buffers through cn_fraction_load (pinned staging, upload of "
@@ -493,10 +506,10 @@ def main():
             out.update(roofline_records(res, wl, args.workload, args.parallel_sequences, args.precision, value))
             if native_comm:
                 ex = res["timing"].get("exchange", (0.0, 0))
-                out["exchange"] = {"rccl_ranks_min": res["rccl_ranks"][0], "rccl_ranks_max": res["rccl_ranks"][1],
+                out["exchange"].update({"ranks_min": res["rccl_ranks"][0], "ranks_max": res["rccl_ranks"][1],
                                    "allreduce_ms_per_step": ex[0] / max(1, res["timing_steps"]), "allreduces_per_step": ex[1] / max(1, res["timing_steps"]),
-                                   "note": "ranks as RCCL's own communicator reports them (cn_comm_info); device time of the per-layer all-reduces from "
-                                           "hipEvents on the library's communication stream during the event-timed pass"}
+                                   "note": "ranks as the library's communicator reports them (cn_comm_info); device time of the per-layer all-reduces from "
+                                           "hipEvents on the library's communication stream during the event-timed pass"})
         if also:
             out["also"] = also
             # the other readings of BASELINE configs[1] and the at-tolerance arithmetic modes, inside `config` so that a consumer

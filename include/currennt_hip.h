@@ -262,9 +262,17 @@ int  cn_ctx_take_accumulated(cn_ctx *ctx);
  * of weightUpdates per layer on RCCL over xGMI, then the identical UpdateWeightFn on every rank keeps the replicas
  * bit-identical without a broadcast.  librccl is opened at run time (dlopen "librccl.so.1"; a process that already
  * holds one, e.g. through PyTorch, shares it); the library has no link-time dependency on it. */
+/* CN_COMM_BACKEND=p2p in the environment selects the library's NATIVE exchange in place of RCCL, behind the same entry points:
+ * a shared-memory rendezvous named by the id, one region per rank (flag words + two staging halves) mapped into every peer
+ * through hipIpc, and cn_allreduce_grads = ONE stream-ordered kernel per bucket that stages, signals, sums in rank order and
+ * acknowledges through the peers' regions -- one shot for small buckets, reduce-scatter + all-gather over the full xGMI mesh
+ * for large ones (csrc/cn_comm_p2p.hip, csrc/cn_comm_ipc.cpp).  No host barrier after the first bucket; a peer that does not
+ * answer within CN_COMM_IPC_TIMEOUT seconds (default 120) fails the communicator and the next cn_loss_read_global raises
+ * CN_ERR_COMM.  One node, at most 8 ranks.  RCCL stays the default. */
 /* (Tests on a box with fewer GPUs than ranks: with CN_COMM_BACKEND=ipc in the environment the four entry points below keep their
  * contract on a host-blocking TEST backend for ranks that share a device -- a shared-memory rendezvous named by the id, hipIpc
- * staging buffers, sums in rank order (csrc/cn_comm_ipc.cpp).  Never a measurement.) */
+ * staging buffers, sums in rank order (csrc/cn_comm_ipc.cpp).  Never a measurement.  The p2p backend runs with shared devices
+ * too.) */
 #define CN_COMM_ID_BYTES 128
 /* rank 0: a fresh rendezvous id (ncclGetUniqueId); hand its 128 bytes to every rank out of band (pipe, file, MPI, ...) */
 int  cn_comm_unique_id(char *id /* [CN_COMM_ID_BYTES] */);
@@ -273,6 +281,9 @@ int  cn_comm_init(cn_ctx *ctx, const char *id /* [CN_COMM_ID_BYTES] */, int rank
 int  cn_comm_destroy(cn_ctx *ctx);
 /* rank / world size of the bound communicator; world = 0 when there is none.  Either pointer may be NULL. */
 int  cn_comm_info(const cn_ctx *ctx, int *rank, int *world);
+/* which exchange the bound communicator runs: "rccl", "p2p" or "ipc" ("" when there is none); *exchanges (may be NULL): the
+ * number of all-reduces cn_allreduce_grads has enqueued on it so far */
+const char *cn_comm_backend(const cn_ctx *ctx, int64_t *exchanges);
 /* all-reduce(SUM, fp32, in place) of the weightUpdates of `n` layers, in the order given, on the context's
  * communication stream: that stream waits for each layer's gradient work only (not for what the context's stream has
  * enqueued since: the backward pass of the layers below keeps running beside the exchange), and the context's stream

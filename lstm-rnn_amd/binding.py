@@ -35,7 +35,7 @@ EXPORTS = [
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_arm_update", "cn_ctx_accumulate_updates", "cn_ctx_take_accumulated", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
     "cn_layer_recurrent_kernel",
-    "cn_comm_unique_id", "cn_comm_init", "cn_comm_destroy", "cn_comm_info", "cn_allreduce_grads", "cn_loss_read_global",
+    "cn_comm_unique_id", "cn_comm_init", "cn_comm_destroy", "cn_comm_info", "cn_comm_backend", "cn_allreduce_grads", "cn_loss_read_global",
     # include/currennt_hip_debug.h
     "cn_dbg_gemm_nt", "cn_dbg_gemm_tn",
 ]
@@ -136,6 +136,8 @@ def load_library():
     L.cn_comm_init.argtypes = [vp, C.c_char_p, ci, ci]
     L.cn_comm_destroy.argtypes = [vp]
     L.cn_comm_info.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
+    L.cn_comm_backend.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.cn_comm_backend.restype = C.c_char_p
     L.cn_allreduce_grads.argtypes = [vp, C.POINTER(vp), ci]
     L.cn_loss_read_global.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_dbg_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci]

@@ -122,6 +122,7 @@ struct cn_ctx {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_comm = nullptr, ev_comm_fork = nullptr;
     bool comm_pending = false;
+    int64_t comm_exchanges = 0;                // all-reduces enqueued by cn_allreduce_grads (cn_comm_backend)
 
     // cn_ctx_arm_update: the momentum-SGD step of the coming backward pass is applied layer by layer, as soon as a layer's own
     // gradient is complete (on the stream that computed it), instead of for all layers behind the last backward kernel
@@ -1021,10 +1022,17 @@ int cn_comm_info(const cn_ctx *ctx, int *rank, int *world)
     return CN_OK;
 }
 
-// the test backend's exchange (host-blocking); a failure marks the segment so that the peers leave their barriers at once
+const char *cn_comm_backend(const cn_ctx *ctx, int64_t *exchanges)
+{
+    if (exchanges) *exchanges = ctx ? ctx->comm_exchanges : 0;
+    if (!ctx || !ctx->has_comm()) return "";
+    return ctx->comm ? "rccl" : ipc_comm_is_p2p(ctx->ipc) ? "p2p" : "ipc";
+}
+
+// the ipc / p2p backends' exchange (ipc: host-blocking); a failure marks the segment so that the peers leave their barriers at once
 static void ipc_reduce(cn_ctx *ctx, float *buf, size_t n)
 {
-    try { ipc_allreduce(ctx->ipc, buf, n, ctx->comm_stream); }
+    try { ipc_allreduce(ctx->ipc, buf, n, ctx->comm_stream, ctx->total); }
     catch (const std::exception &e) { ipc_comm_mark_failed(ctx->ipc); throw cn_error(CN_ERR_COMM, e.what()); }
 }
 
@@ -1050,6 +1058,7 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
             HIP_CHECK(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_comm_fork, 0));
             float *g = ctx->arena + ctx->total;
             Timed tm(ctx, KC_COMM, ctx->comm_stream);
+            ++ctx->comm_exchanges;
             if (test_double) launch_scale(ctx->comm_stream, g, ctx->total, 2.0f);
             else if (ctx->ipc) ipc_reduce(ctx, g, ctx->total);
             else if (ctx->total) RCCL_CHECK(rccl().AllReduce(g, g, ctx->total, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
@@ -1059,6 +1068,7 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
                 if (!l || l->ctx != ctx || !l->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_allreduce_grads: not a trainable layer of this context");
                 stream_wait_layer(l, ctx->comm_stream);
                 Timed tm(ctx, KC_COMM, ctx->comm_stream);          // (events on the communication stream: the exchange itself, not its wait)
+                ++ctx->comm_exchanges;
                 if (test_double) launch_scale(ctx->comm_stream, l->wu, (size_t)l->nw, 2.0f);
                 else if (ctx->ipc) ipc_reduce(ctx, l->wu, (size_t)l->nw);
                 else RCCL_CHECK(rccl().AllReduce(l->wu, l->wu, (size_t)l->nw, ncclFloat32, ncclSum, ctx->comm, ctx->comm_stream));
@@ -1576,7 +1586,7 @@ int cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
             check_fault(ctx);
             int cc; memcpy(&cc, &h[1], sizeof(int));
-            try { ipc_allreduce_loss(ctx->ipc, &h[0], &cc); }
+            try { ipc_comm_check(ctx->ipc, ctx->comm_stream); ipc_allreduce_loss(ctx->ipc, &h[0], &cc); }
             catch (const std::exception &e) { ipc_comm_mark_failed(ctx->ipc); throw cn_error(CN_ERR_COMM, e.what()); }
             if (error_sum) *error_sum = h[0];
             if (correct_sum) *correct_sum = cc;

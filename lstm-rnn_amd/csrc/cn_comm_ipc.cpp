@@ -9,6 +9,13 @@
 //   (peers' buffers through hipIpcOpenMemHandle) -> barrier.
 // Every rank adds the same numbers in the same order: the replicas stay bit-identical, as with RCCL's ring.  The call blocks the
 // host (two barriers per exchange) -- it is a functional double, never a measurement, and bench.py refuses it for `value`.
+//
+// CN_COMM_BACKEND=p2p -- the NATIVE small-message backend, same rendezvous: every rank owns a region (flag words + two staging
+// halves), publishes its hipIpc handle once (and again when a larger bucket arrives: the only host barriers of the backend), and
+// an all-reduce is ONE kernel on the caller's stream that stages, signals, sums and acknowledges through the peers' mapped
+// regions (cn_comm_p2p.hip).  Nothing blocks the host; a poll that times out on the device marks the communicator failed and the
+// next synchronising call (cn_loss_read_global, cn_comm_destroy) raises.  One rank per GPU over xGMI is the intended use; ranks
+// that share a device (the tests on a one-GPU box) run the same code.
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -70,6 +77,12 @@ struct IpcComm {
     float *peer[IPC_MAX_RANKS] = {};
     unsigned long long peer_gen[IPC_MAX_RANKS] = {};
     double timeout_s = 120.0;
+    // p2p mode (cn_comm_p2p.hip): my region = flag words, then two staging halves of half_cap floats; the peers' regions mapped
+    bool p2p = false;
+    unsigned long long *region = nullptr; size_t half_cap = 0;
+    unsigned long long *peer_region[IPC_MAX_RANKS] = {};
+    unsigned long long seq = 0;
+    size_t oneshot_max = 256 * 1024;             // floats: larger buckets go reduce-scatter + all-gather
 
     void barrier(const char *what)
     {
@@ -92,11 +105,17 @@ struct IpcComm {
     }
 };
 
+static bool p2p_selected()
+{
+    const char *b = getenv("CN_COMM_BACKEND");
+    return b && !strcmp(b, "p2p");
+}
 bool ipc_backend_selected()
 {
     const char *b = getenv("CN_COMM_BACKEND");
-    return b && !strcmp(b, "ipc");
+    return b && (!strcmp(b, "ipc") || !strcmp(b, "p2p"));
 }
+bool ipc_comm_is_p2p(const IpcComm *c) { return c && c->p2p; }
 
 // Segments this process created and nobody has unlinked yet (rank 0 unlinks inside ipc_comm_create): if the caller throws
 // between cn_comm_unique_id and cn_comm_init, or exits without ever calling it, the name would stay in /dev/shm.
@@ -144,7 +163,8 @@ IpcComm *ipc_comm_create(const char *id, int rank, int world)
     if (world > IPC_MAX_RANKS) throw std::runtime_error("ipc communicator: at most " + std::to_string(IPC_MAX_RANKS) + " ranks");
     if (id[0] != '/' || strncmp(id, "/cn_ipc_", 8)) throw std::runtime_error("ipc communicator: the id does not come from cn_comm_unique_id with CN_COMM_BACKEND=ipc");
     IpcComm *c = new IpcComm;
-    c->name = id; c->rank = rank; c->world = world;
+    c->name = id; c->rank = rank; c->world = world; c->p2p = p2p_selected();
+    if (const char *t = getenv("CN_P2P_ONESHOT_MAX")) c->oneshot_max = (size_t)atoll(t);
     if (const char *t = getenv("CN_COMM_IPC_TIMEOUT")) {
         const double v = atof(t);              // garbage or 0 would time every barrier out at once: keep the default then
         if (v >= 1.0) c->timeout_s = v;
@@ -171,6 +191,9 @@ void ipc_comm_destroy(IpcComm *c)
 {
     if (!c) return;
     for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->peer_region[r]) (void)hipIpcCloseMemHandle(c->peer_region[r]);
+    if (c->region) (void)hipFree(c->region);
+    for (int r = 0; r < c->world; ++r)
         if (r != c->rank && c->peer[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     if (c->staging) (void)hipFree(c->staging);
     if (c->sh) munmap(c->sh, sizeof(Shared));
@@ -179,10 +202,93 @@ void ipc_comm_destroy(IpcComm *c)
 
 void ipc_comm_mark_failed(IpcComm *c) { if (c && c->sh) c->sh->failed.store(1); }
 
-// all-reduce(SUM, fp32, in place) of buf[0..n) over the ranks; blocks the host; `st` is the stream the caller ordered behind
-// the producer of buf
-void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st)
+// p2p: (re)allocate my region for buckets of up to `want` floats and map everybody's.  Every rank gets here in the same call
+// (the networks are replicas: same bucket sizes in the same order), so the three host barriers pair up; the exchange counter
+// starts over with the fresh (zeroed) flag words.
+static void p2p_grow(IpcComm *c, size_t want, hipStream_t st)
 {
+    hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    c->barrier("cn_allreduce_grads (p2p: everybody idle)");           // nobody reads or writes the old regions any more
+    for (int r = 0; r < c->world; ++r)
+        if (r != c->rank && c->peer_region[r]) { hipck(hipIpcCloseMemHandle(c->peer_region[r]), "hipIpcCloseMemHandle"); c->peer_region[r] = nullptr; }
+    if (c->region) hipck(hipFree(c->region), "hipFree");
+    c->region = nullptr;
+    // a half is world x P2P_GROUPS slots; a slot holds the largest piece (rounded up to 4 floats)
+    const size_t slots = (size_t)c->world * P2P_GROUPS;
+    const size_t cap = ((want + slots - 1) / slots + 4) * slots;
+    const size_t bytes = (size_t)P2P_FLAG_WORDS * 8 + 2 * cap * sizeof(float);
+    // fine-grained: flag words and staged gradients are read by other devices while kernels of both sides run (coarse-grained
+    // memory is only coherent across devices at kernel boundaries); plain device memory if the runtime refuses
+    void *p = nullptr;
+    bool fine = true;
+    if (getenv("CN_P2P_COARSE") || hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        hipck(hipMalloc(&p, bytes), "hipMalloc(p2p region)");
+        fine = false;
+    }
+    if (getenv("CN_P2P_VERBOSE"))
+        fprintf(stderr, "p2p communicator: rank %d of %d: region of %zu bytes (%s), staging halves of %zu floats\n", c->rank, c->world, bytes,
+                fine ? "fine-grained" : "coarse-grained", cap);
+    c->region = (unsigned long long *)p; c->half_cap = cap; c->seq = 0;
+    hipck(hipMemset(p, 0, (size_t)P2P_FLAG_WORDS * 8), "hipMemset");
+    hipck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    Slot &mine = c->sh->slot[c->rank];
+    hipck(hipIpcGetMemHandle(&mine.handle, p), "hipIpcGetMemHandle");
+    mine.capacity.store(cap);
+    c->barrier("cn_allreduce_grads (p2p: regions published)");
+    for (int r = 0; r < c->world; ++r) {
+        if (r == c->rank) { c->peer_region[r] = c->region; continue; }
+        Slot &s = c->sh->slot[r];
+        if (s.capacity.load() != cap) throw std::runtime_error("ipc communicator: ranks disagree about the size of an exchange");
+        hipIpcMemHandle_t h = s.handle;
+        void *q = nullptr;
+        hipck(hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+        c->peer_region[r] = (unsigned long long *)q;
+    }
+    c->barrier("cn_allreduce_grads (p2p: regions mapped)");
+}
+
+static void p2p_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t hint)
+{
+    if (n == 0) return;
+    if (n > c->half_cap) p2p_grow(c, n > hint ? n : hint, st);
+    P2pArgs a{};
+    a.buf = buf; a.n = n; a.me = c->rank; a.world = c->world;
+    const size_t pieces = (size_t)c->world * P2P_GROUPS;
+    a.piece = ((n + pieces - 1) / pieces + 3) / 4 * 4;
+    a.slot = c->half_cap / pieces / 4 * 4;
+    if (a.piece > a.slot) throw std::runtime_error("p2p communicator: bucket larger than the staging half");
+    a.two_phase = c->world > 2 && n > c->oneshot_max;
+    if (getenv("CN_P2P_FORCE_TWO_PHASE")) a.two_phase = 1;
+    a.seq = ++c->seq;
+    a.timeout_ticks = (unsigned long long)(c->timeout_s * 1e8);
+    for (int r = 0; r < c->world; ++r) {
+        a.flags[r] = c->peer_region[r];
+        a.stage[r] = (float *)(c->peer_region[r] + P2P_FLAG_WORDS) + (a.seq & 1) * c->half_cap;
+    }
+    launch_p2p_allreduce(st, a);
+    hipck(hipGetLastError(), "p2p all-reduce kernel");
+}
+
+// p2p: did a poll time out on the device?  (host-synchronising: called where the host waits anyway)
+void ipc_comm_check(IpcComm *c, hipStream_t st)
+{
+    if (!c || !c->p2p || !c->region) return;
+    unsigned long long failed = 0;
+    hipck(hipMemcpyAsync(&failed, c->region + P2P_FAILED, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+    hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
+    if (failed) {
+        c->sh->failed.store(1);
+        throw std::runtime_error("p2p communicator: rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " waited more than " +
+                                 std::to_string((int)c->timeout_s) + " s for a peer inside a gradient exchange");
+    }
+}
+
+// all-reduce(SUM, fp32, in place) of buf[0..n) over the ranks; `st` is the stream the caller ordered behind the producer of
+// buf.  ipc mode blocks the host; p2p mode enqueues one kernel (capacity_hint: the largest bucket the caller will ever bring)
+void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t capacity_hint)
+{
+    if (c->p2p) { p2p_allreduce(c, buf, n, st, capacity_hint); return; }
     if (n == 0) { c->barrier("cn_allreduce_grads"); c->barrier("cn_allreduce_grads"); return; }
     Slot &mine = c->sh->slot[c->rank];
     if (n > c->capacity) {

@@ -211,8 +211,22 @@ void ipc_unique_id(char *id, size_t bytes);
 IpcComm *ipc_comm_create(const char *id, int rank, int world);
 void ipc_comm_destroy(IpcComm *c);
 void ipc_comm_mark_failed(IpcComm *c);
-void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st);
+void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t capacity_hint = 0);
+bool ipc_comm_is_p2p(const IpcComm *c);
+void ipc_comm_check(IpcComm *c, hipStream_t st);       // p2p: raise if a poll of the communicator timed out (synchronises st)
 void ipc_allreduce_loss(IpcComm *c, float *err, int *correct);
+// ---- CN_COMM_BACKEND=p2p: one stream-ordered kernel per bucket over peer-mapped regions (cn_comm_p2p.hip) -----------
+constexpr int P2P_GROUPS = 64, P2P_THREADS = 256;
+// a rank's region starts with 64-bit flag words: [word][source rank][workgroup]
+constexpr int P2P_READY = 0, P2P_REDUCED = 8 * P2P_GROUPS, P2P_DONE = 16 * P2P_GROUPS, P2P_FAILED = 24 * P2P_GROUPS, P2P_FLAG_WORDS = 24 * P2P_GROUPS + 64;
+struct P2pArgs {
+    float *buf; size_t n, piece, slot;         // the bucket (in place); floats per piece (even): n <= world * P2P_GROUPS * piece; per staging slot (>= piece)
+    float *stage[8];                           // staging half of this exchange, per rank (peers' mapped into this process)
+    unsigned long long *flags[8];              // flag words, per rank
+    int me, world, two_phase;
+    unsigned long long seq, timeout_ticks;     // exchange counter (from 1); poll deadline in ticks of the 100 MHz clock
+};
+void launch_p2p_allreduce(hipStream_t s, const P2pArgs &a);
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);
 void launch_accumulate(hipStream_t s, float *acc, const float *wu, size_t n, bool first);
 // gather a padded row-major fp32/op matrix into the reference layout [N][L]

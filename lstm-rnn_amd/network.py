@@ -292,6 +292,13 @@ class NeuralNetwork:
         B.check(self.lib.cn_comm_info(self.ctx, C.byref(r), C.byref(w)), self.ctx)
         return r.value, w.value
 
+    def comm_backend(self):
+        """(name, exchanges): which exchange the bound communicator runs ("rccl", "p2p", "ipc"; "" without one) and how many
+        all-reduces cn_allreduce_grads has enqueued on it (cn_comm_backend)."""
+        k = C.c_int64()
+        name = self.lib.cn_comm_backend(self.ctx, C.byref(k))
+        return (name or b"").decode(), k.value
+
     def allreduce_grads(self, layers=None):
         """SUM all-reduce of the weightUpdates of `layers` (None: the whole arena in one exchange) on the library's
         communication stream; the next update waits for it on the device."""

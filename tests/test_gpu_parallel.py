@@ -156,27 +156,92 @@ def test_per_layer_learning_rate_in_fused_update(pkg, orc):
                 assert np.abs(lay.weights() - ref.layer(lay.name).weights).max() < 5e-6, (fused, lay.name)
 
 
-@pytest.mark.parametrize("backend", ["gloo", "ipc"])
+def _run_p2p_ranks(tmp_path, world, mode, extra_env):
+    env = dict(os.environ, CN_COMM_BACKEND="p2p", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_rank.py"), str(r), str(world), str(tmp_path), mode],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, (r, outs[r][-3000:])
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+@pytest.mark.parametrize("oneshot_max", [None, 0, 3000])
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_exchange_sums_in_rank_order(pkg, tmp_path, world, oneshot_max):
+    """CN_COMM_BACKEND=p2p (cn_comm_p2p.hip) with `world` live ranks on one device, through the C ABI: every exchange -- per layer
+    (buckets of different sizes in a row, both staging halves, the first half reused) and the flat arena in one bucket -- must
+    leave ((g0 + g1) + g2) in float32 on EVERY rank, bit for bit: the same numbers added
+    in rank order, whether a workgroup sums a piece itself (one shot) or receives it from the rank that owns the slice
+    (reduce-scatter + all-gather: CN_P2P_ONESHOT_MAX=0 sends every bucket that way, 3000 floats splits the layers between the
+    two forms).  The global loss is the sum of the ranks' in rank order."""
+    env = {"CN_COMM_IPC_TIMEOUT": "60"}
+    if oneshot_max is not None:
+        env["CN_P2P_ONESHOT_MAX"] = str(oneshot_max)
+    res = _run_p2p_ranks(tmp_path, world, "sum", env)
+    n_layers = 3
+    for k in range(3):
+        want = res[0]["local_%d" % k].copy()
+        for r in range(1, world):
+            want = want + res[r]["local_%d" % k]                 # float32, rank order
+        assert np.abs(want).max() > 0
+        for r in range(world):
+            got = res[r]["reduced_%d" % k]
+            assert np.array_equal(got, want), (k, r, np.abs(got - want).max(), np.argwhere(got != want)[:4])
+    for r in range(world):
+        assert int(res[r]["exchanges"]) == 2 * n_layers + 1
+        assert np.array_equal(res[r]["loss"], res[0]["loss"])
+
+
+def test_p2p_exchange_times_out_when_a_peer_stays_away(pkg, tmp_path):
+    """A rank that never enters an exchange: the others' kernels give up after CN_COMM_IPC_TIMEOUT seconds of the device clock,
+    mark the communicator failed (their own region and every peer's), and the next cn_loss_read_global raises CN_ERR_COMM naming
+    the rank -- no host thread hangs, no kernel spins for ever."""
+    res = _run_p2p_ranks(tmp_path, 3, "absent", {"CN_COMM_IPC_TIMEOUT": "2"})
+    for r in (0, 1):
+        msg = str(res[r]["raised"])
+        assert "p2p communicator: rank %d of 3 waited more than 2 s" % r in msg, msg
+
+
+@pytest.mark.parametrize("backend", ["gloo", "ipc", "p2p", "p2p-two-phase"])
 @pytest.mark.parametrize("flat", [False, True])
 def test_bench_two_ranks_on_one_gpu_over_gloo(pkg, flat, backend):
     """bench.py with WORLD_SIZE = 2 on a one-GPU box: CN_BENCH_BACKEND=gloo lets both ranks share the device and
     reduces through the host, so the world > 1 control flow (per-layer exchange from the communication stream, or
     the flat exchange; barrier; max-over-ranks timing) runs with real sums.  Replicas must end bit-identical.
     backend "ipc": the exchange is the LIBRARY's own (cn_comm_init, one cn_allreduce_grads per layer on the communication stream,
-    cn_loss_read_global) on its test backend for ranks that share a device (cn_comm_ipc.cpp)."""
+    cn_loss_read_global) on its test backend for ranks that share a device (cn_comm_ipc.cpp).
+    backend "p2p": the library's NATIVE exchange (CN_COMM_BACKEND=p2p, cn_comm_p2p.hip: one stream-ordered kernel per bucket that
+    stages, signals, sums in rank order and acknowledges through the peers' hipIpc-mapped regions; no host barrier after the
+    first bucket) -- here with both ranks on one device; "p2p-two-phase" forces its reduce-scatter + all-gather form, which a
+    world of two would never pick."""
+    two_phase = backend == "p2p-two-phase"
+    backend = backend.split("-")[0]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29300 + os.getpid() % 250 + int(flat) + 2 * (backend == "ipc")), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+           "--master-port", str(29300 + os.getpid() % 250 + int(flat) + 2 * ["gloo", "ipc", "p2p"].index(backend) + 6 * two_phase), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
            "--warmup", "1", "--parallel-sequences", "8", "--tmin", "20", "--tmax", "30", "--no-cpu-baseline", "--no-roofline-pass", "--no-driver-leg"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CN_BENCH_BACKEND=backend, CN_BENCH_MIN_SECONDS="0")   # one repetition
     if flat:
         env["CN_BENCH_FLAT_ALLREDUCE"] = "1"
+    if two_phase:
+        env["CN_P2P_FORCE_TWO_PHASE"] = "1"
+    if backend == "p2p":
+        env["CN_COMM_IPC_TIMEOUT"] = "60"
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "dp2 over sequences"
     assert d["check"]["replicas_identical"] is True and np.isfinite(d["check"]["error_sum"])
     assert d["check"]["allreduce"].startswith("flat" if flat else "per-layer, overlapped")
-    assert ("test double" if backend == "gloo" else "ipc TEST backend") in d["check"]["allreduce"]
+    assert {"gloo": "test double", "ipc": "ipc TEST backend", "p2p": "p2p backend"}[backend] in d["check"]["allreduce"]
+    assert d["exchange"]["backend"] == ("torch.distributed gloo (test double)" if backend == "gloo" else backend) and d["exchange"]["one_rank_per_gpu"] is False
     # the same five steps in ONE process on the union of the two ranks' fractions (16 sequences per fraction): gradients
     # are sums over patterns, so the data-parallel run must move the weights the same way.  An exchange that read a
     # layer's gradient before it was complete, or an update that did not wait for the exchange, shows up here.

@@ -333,13 +333,16 @@ TWO_RANK_ENV = dict(CN_TEST_HOOKS="1", CN_COMM_BACKEND="ipc", CN_DP_SAME_DEVICE=
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("comm", ["ipc", "p2p"])
 @pytest.mark.parametrize("stochastic", ["true", "false"])
-def test_driver_two_ranks_on_one_gpu(pkg, tmp_path, stochastic):
+def test_driver_two_ranks_on_one_gpu(pkg, tmp_path, stochastic, comm):
     """`currennt_hip --gpus 2` with BOTH ranks alive (the reference has no counterpart, main.cpp:526-541): fork before
     any GPU call, rendezvous id through the pipe, DataSet::setShard under two live ranks, one gradient exchange per layer behind
     its backward pass (batch mode: one exchange of the epoch sum), cn_loss_read_global, rank 0 writes the files.  RCCL refuses two
     ranks on one device, so the library's exchange runs on its test backend (CN_COMM_BACKEND=ipc: hipIpc handles of the peers'
     gradients + a sum kernel in rank order, cn_comm_ipc.cpp) and both ranks use device 0 (CN_DP_SAME_DEVICE) -- never a measurement.
+    comm = "p2p": the library's native exchange instead (CN_COMM_BACKEND=p2p, cn_comm_p2p.hip: one stream-ordered kernel per
+    bucket over the peers' mapped regions), same two ranks on one device.
     9 sequences, 2 ranks x 2 parallel sequences: global fractions of 4, 4 and 1 sequences, so rank 1's share of the last one is
     EMPTY (an all-dummy fraction keeps the collectives matched).  The run must end in the network of the single-process run over
     the union fractions (parallel_sequences 4): sums over patterns in another order, nothing else (Optimizer.cu:37-104)."""
@@ -351,7 +354,7 @@ def test_driver_two_ranks_on_one_gpu(pkg, tmp_path, stochastic):
     a = subprocess.run(common + ["--parallel_sequences", "4", "--save_network", plain], capture_output=True, text=True, timeout=300)
     assert a.returncode == 0, a.stdout + a.stderr
     b = subprocess.run(common + ["--parallel_sequences", "2", "--gpus", "2", "--save_network", dp], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, **TWO_RANK_ENV))
+                       env=dict(os.environ, **dict(TWO_RANK_ENV, CN_COMM_BACKEND=comm)))
     assert b.returncode == 0, b.stdout + b.stderr
     assert "Data-parallel training with 2 ranks on device 0" in b.stdout
     ra, rb = _error_rows(a.stdout), _error_rows(b.stdout)
