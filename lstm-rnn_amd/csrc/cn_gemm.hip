@@ -571,6 +571,17 @@ void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int 
     GemmTN grp[TN_GROUP], big[TN_GROUP]; int ng = 0, nb = 0;
     bool any_big = false;
     for (int i = 0; i < n; ++i) any_big = any_big || (gs[i].M > 0 && gs[i].N > 0 && gs[i].K > 0 && gemm_tn_big_applies(prec, gs[i]));
+    {   // ... and the layer-1 group of the 256-wide layers (dW_in 2048 x 64 stays on the small tiles, the two dW_rec 1024 x 256 can go):
+        // nothing in it is large enough on its own, but it is the exposed tail of the step, and over many frames the pair does better
+        // on the 256 x 256 kernel -- tools/probe/gemm_bench, group alone, us small tiles / pair on the large kernel + dW_in behind it:
+        // K = 15 600 67.2 / 84.9, K = 35 200 142.5 / 121.0, K = 51 200 230.7 / 146.6.  From half a million outputs and 28 000 frames on.
+        const char *gk = getenv("CN_TNBIG_GROUP_MINK");                       // (read per launch: the tests switch it)
+        const long gmink = gk ? atol(gk) : 28000;
+        long outs = 0, kmin = 1L << 40;
+        for (int i = 0; i < n; ++i)
+            if (gs[i].M > 0 && gs[i].N > 0 && gs[i].K > 0 && gemm_tn_big_can(prec, gs[i])) { outs += (long)gs[i].M * gs[i].N; kmin = std::min<long>(kmin, gs[i].K); }
+        if (outs >= (1L << 19) && kmin >= gmink) any_big = true;
+    }
     for (int i = 0; i < n; ++i) {
         if (gs[i].M <= 0 || gs[i].N <= 0 || gs[i].K <= 0) continue;
         // one grouped launch of 256 x 256 tiles for the products large enough to want them and those that can ride along

@@ -854,6 +854,31 @@ def test_hand_written_wide_forward_loop_equals_its_compiled_twin_bit_for_bit(pkg
     assert np.abs(got["asm"][1]["out"] - got["cluster"][1]["out"]).max() < 3e-2
 
 
+def test_first_layer_gradient_group_on_the_large_tiles_over_many_frames(pkg, monkeypatch):
+    """The gradient group of the FIRST 256-wide layer (dW_in 2048 x 64 + two dW_rec 1024 x 256) has no member large enough for the
+    256 x 256 kernel on its own; from 28 000 frames on (cn_gemm.hip: launch_gemm_tn_group) the dW_rec pair goes there anyway and
+    dW_in follows on the small tiles -- it is the exposed tail of the LVCSR step.  Same products, another tiling and split-K: the
+    layer's weightUpdates must agree with the all-small-tiles launch (CN_TNBIG_GROUP_MINK above the frame count) to the order of
+    the fp32 atomics, here on 64 x 448 = 28 672 frames with ragged lengths."""
+    rng = np.random.RandomState(77)
+    P, C, PS, T = 40, 30, 64, 448
+    layers = net_desc(P, [("blstm", 512)], C)
+    weights = random_weights(layers, rng, 0.05)
+    lengths = [T - (i % 7) * 40 for i in range(PS)]
+    xs, ts = random_sequences(rng, lengths, P, C=C)
+    frac = pkg.make_fraction(xs, ts, PS)
+    got = {}
+    for mode in ("large", "small"):
+        if mode == "small":
+            monkeypatch.setenv("CN_TNBIG_GROUP_MINK", "100000000")
+        with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+            net.load_sequences(frac); net.compute_forward_pass(); net.compute_backward_pass()
+            got[mode] = {lay.name: lay.weight_updates() for lay in net.trainable_layers()}
+    for name, g in got["large"].items():
+        assert np.abs(g).max() > 0
+        assert rel_err(g, got["small"][name]) < 2e-5, (name, rel_err(g, got["small"][name]))
+
+
 @pytest.mark.parametrize("kind,size,T", [("blstm", 500, 1), ("blstm", 500, 2), ("blstm", 500, 3), ("blstm", 500, 5), ("lstm", 250, 6), ("blstm", 512, 37),
                                          ("blstm", 500, 64)])
 def test_hand_written_two_cu_backward_loop_equals_its_compiled_twin_bit_for_bit(pkg, orc, monkeypatch, kind, size, T):

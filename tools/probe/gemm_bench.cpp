@@ -97,7 +97,8 @@ int main()
     // the grouped launch of an LSTM layer's backward pass: dW_in + dW_rec per direction in ONE launch (cn_api.cpp: lstm_backward)
     struct Grp { int P, K, Hp, PS; const char *what; } grps[] = {{256, 15600, 128, 52, "layer 2/3 group (dW_in 1024x256 + 2 x dW_rec 512x128)"}, {64, 15600, 128, 52, "layer 1 group (dW_in 1024x64 + 2 x dW_rec 512x128)"},
         {512, 35200, 256, 64, "LVCSR layer 2-4 group (dW_in 2048x512 + 2 x dW_rec 1024x256), T = 550"}, {64, 35200, 256, 64, "LVCSR layer 1 group (dW_in 2048x64 + 2 x dW_rec 1024x256)"},
-        {512, 15600, 256, 52, "reading B layer 2/3 group"}, {1024, 32000, 512, 16, "long-utterance layer 2-5 group (dW_in 4096x1024 + 2 x dW_rec 2048x512)"}};
+        {512, 15600, 256, 52, "reading B layer 2/3 group"}, {64, 15600, 256, 52, "reading B layer 1 group (dW_in 2048x64 + 2 x dW_rec 1024x256): the exposed tail"},
+        {64, 51200, 256, 64, "LVCSR layer 1 group at T = 800: the exposed tail"}, {1024, 32000, 512, 16, "long-utterance layer 2-5 group (dW_in 4096x1024 + 2 x dW_rec 2048x512)"}};
     for (auto &gr : grps) {
         const int K = gr.K / mdiv, Hp = gr.Hp, R = 8 * Hp, PS = gr.PS;
         void *delta = rnd((size_t)K * R), *x = rnd((size_t)K * gr.P), *y = rnd((size_t)K * 2 * Hp);
