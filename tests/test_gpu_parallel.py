@@ -173,10 +173,9 @@ def _run_p2p_ranks(tmp_path, world, mode, extra_env):
     return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
 
 
-@pytest.mark.parametrize("oneshot_max", [None, 0, 3000])
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,oneshot_max", [(2, None), (2, 0), (2, 3000), (3, None), (3, 0), (3, 3000), (8, None), (8, 3000)])
 def test_p2p_exchange_sums_in_rank_order(pkg, tmp_path, world, oneshot_max):
-    """CN_COMM_BACKEND=p2p (cn_comm_p2p.hip) with `world` live ranks on one device, through the C ABI: every exchange -- per layer
+    """CN_COMM_BACKEND=p2p (cn_comm_p2p.hip) with `world` live ranks (2, 3 and the full 8) on one device, through the C ABI: every exchange -- per layer
     (buckets of different sizes in a row, both staging halves, the first half reused) and the flat arena in one bucket -- must
     leave ((g0 + g1) + g2) in float32 on EVERY rank, bit for bit: the same numbers added
     in rank order, whether a workgroup sums a piece itself (one shot) or receives it from the rank that owns the slice
