@@ -552,8 +552,11 @@ void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t don
     static const bool no8 = getenv("CN_NO_BIG8") != nullptr;
     // the persistent kernel: 32-bit byte offsets into every operand, whole 16-byte stores, and at least a dozen k-tiles per tile
     // (a seam costs about five k-tiles of time; CN_BIG8_MIN_K, read per launch, lets the tests run it on short K)
+    // ... or eight, when the launch is many tiles per CU long (>= 1000 tiles: the LVCSR layer and output products at K = 512 --
+    // tools/probe/gemm_bench, us non-persistent / persistent: 51 200 x 2048 203.4 / 193.8, 35 200 x 2048 138.8 / 134.9,
+    // 51 200 x 8000 710.8 / 652.7; reading B's 15 600 x 2048, 488 tiles: 51.5 / 54.7 and stays)
     const char *mk = getenv("CN_BIG8_MIN_K");
-    const int min_k = mk ? atoi(mk) : 12 * 64;
+    const int min_k = mk ? atoi(mk) : (nwg >= 1000 ? 8 * 64 : 12 * 64);
     const bool fits = (unsigned long long)g.M * g.lda * 2 < 0xfffffff0ull && (unsigned long long)g.N * g.ldb * 2 < 0xfffffff0ull &&
                       (!g.C || ((unsigned long long)g.M * g.ldc * 4 < 0xfffffff0ull && g.ldc % 4 == 0 && (uintptr_t)g.C % 16 == 0)) &&
                       (!g.C2 || ((unsigned long long)g.M * g.ldc2 * 2 < 0xfffffff0ull && g.ldc2 % 4 == 0 && (uintptr_t)g.C2 % 8 == 0)) &&

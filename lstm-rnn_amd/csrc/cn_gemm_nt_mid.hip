@@ -213,8 +213,9 @@ bool gemm_nt_mid_applies(int prec, const GemmNT &g)
     if (g.K % NM_BK != 0 || g.K < 4 * NM_BK || g.K >= 768 || g.N > 4096) return false;
     if (g.N % 4 != 0 || (g.C && (g.ldc % 4 || (uintptr_t)g.C % 16)) || (g.C2 && (g.ldc2 % 4 || (uintptr_t)g.C2 % 8)) || (uintptr_t)g.A % 16 || (uintptr_t)g.B % 16 || (g.bias && (uintptr_t)g.bias % 16) || !(g.C || g.C2) || g.lda % 8 || g.ldb % 8) return false;
     if ((unsigned long long)g.M * g.lda * 2 >= 0xfffffff0ull || (unsigned long long)g.N * g.ldb * 2 >= 0xfffffff0ull) return false;
+    // (from 1000 tiles on and K >= 512 the persistent 256 x 256 kernel takes the product: launch_gemm_nt_big)
     const long tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    return tiles >= 384;
+    return tiles >= 384 && (tiles < 1000 || g.K < 512);
 }
 
 void launch_gemm_nt_mid(hipStream_t s, const GemmNT &g, hipEvent_t done)

@@ -25,7 +25,8 @@ def lib(pkg):
 
 @pytest.mark.parametrize("prec", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(60, 128, 32), (1000, 1024, 256), (130, 192, 96),
-                                   (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024), (9001, 3104, 160), (12500, 2048, 512)])
+                                   (4200, 6176, 256), (6500, 4128, 512), (25000, 1024, 1024), (9001, 3104, 160), (12500, 2048, 512),
+                                   (16500, 4128, 512)])      # 1105 tiles of 256 x 256 at K = 512: the persistent kernel's short-K rule
 def test_gemm_nt(lib, prec, shape):
     L, B = lib
     M, N, K = shape
