@@ -408,5 +408,9 @@ def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
         ce = [r["val_class_err"] for r in rows]
         stat[mode] = (min(ce), float(np.mean(ce[-10:])))
         assert stat[mode][0] < 45.0, (mode, stat[mode])                               # from 91 % at epoch 1
+    # the noisy regime is not reproducible run to run even in ONE mode (the gradients' split-K atomics reorder; f32 itself has
+    # ended at 41.3 / 43.8 and 39.6 / 41.4 % best / last-ten on two runs of this test): the modes must land in the same region,
+    # not on the same numbers
     for mode in ("bf16", "bf16x3"):
-        assert abs(stat[mode][0] - stat["f32"][0]) <= 2.0 and abs(stat[mode][1] - stat["f32"][1]) <= 2.0, stat
+        assert abs(stat[mode][0] - stat["f32"][0]) <= 4.0 and abs(stat[mode][1] - stat["f32"][1]) <= 4.0, stat
+        assert stat[mode][1] < 48.0, stat
