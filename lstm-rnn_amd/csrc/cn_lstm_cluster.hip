@@ -42,6 +42,9 @@
 #ifndef CN_KHS_READ_AHEAD
 #define CN_KHS_READ_AHEAD 1
 #endif
+#ifndef CN_FWD_READ_AHEAD
+#define CN_FWD_READ_AHEAD 1
+#endif
 #ifndef CN_POLL_SLEEP
 #define CN_POLL_SLEEP 1
 #endif
@@ -331,6 +334,23 @@ __global__ __launch_bounds__(UPC * 4) void lstm_fwd_cluster_kernel(LstmRec p)
         // own units' part of the recurrent product: needs nothing from the partners
         auto product = [&](auto j0_, auto j1_) {          // K chunks [j0, j1) of the member-relative order
             constexpr int j0 = decltype(j0_)::value, j1 = decltype(j1_)::value;
+            if constexpr (SP && (!X3 || QUAD) && CN_FWD_READ_AHEAD && (j1 - j0) > 2) {
+                // the partners' chunks of the 8-CU shape (7 reads, 28 MFMAs): left to hipcc the reads are issued in pairs, each
+                // pair behind the MFMAs of the pair before it (two operand buffers), and every pair's LDS latency is exposed
+                // (1 250 cycles for 28 MFMAs by the stamps).  All reads first, then the MFMAs.
+                u32x4 a[j1 - j0];
+#pragma unroll
+                for (int j = j0; j < j1; ++j) a[j - j0] = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = j0; j < j1; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if constexpr (QUAD) { smma16(acc[g], a[j - j0], wsl[g][j], spidx); smma16(acc[g], a[j - j0], wsp[g][j], spidx); }
+                        else smma16(acc[g], a[j - j0], wsp[g][j], spidx);
+                    }
+                return;
+            }
 #pragma unroll
             for (int j = j0; j < j1; ++j) {
                 const u32x4 a = *(const u32x4 *)(ycur + c * pitch + j * 64 + q * 16);
