@@ -42,6 +42,9 @@
 #ifndef CN_KHS_READ_AHEAD
 #define CN_KHS_READ_AHEAD 1
 #endif
+#ifndef CN_BWD_READ_FENCE
+#define CN_BWD_READ_FENCE 1
+#endif
 #ifndef CN_FWD_READ_AHEAD
 #define CN_FWD_READ_AHEAD 1
 #endif
@@ -688,6 +691,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                 u32x4 a[NR];
 #pragma unroll
                 for (int j = 0; j < NR; ++j) a[j] = *(const u32x4 *)(dcur + c * pitch + (p0 * KH + j) * 64 + q * 16);
+                // (round 5: without this hipcc sinks the reads back between the MFMAs, one or two ahead of their use)
+                if constexpr (CN_BWD_READ_FENCE) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pp = p0; pp < p1; ++pp)
 #pragma unroll
