@@ -42,6 +42,12 @@
 #ifndef CN_KHS_READ_AHEAD
 #define CN_KHS_READ_AHEAD 1
 #endif
+#ifndef CN_POLL_DELAY_MANY
+#define CN_POLL_DELAY_MANY 2
+#endif
+#ifndef CN_POLL_DELAY_7
+#define CN_POLL_DELAY_7 1
+#endif
 #ifndef CN_BWD_READ_FENCE
 #define CN_BWD_READ_FENCE 1
 #endif
@@ -156,6 +162,12 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
         if (++spins > (1 << 20)) { *fault = 1; gaveup = true; break; }
     }
     } else {
+    // many granules per thread (8-CU shapes: 7 forward, 14 backward): a sample that leaves before the partners' values are in L2
+    // costs a whole extra round trip, so the FIRST one waits s_sleep(n) = n x 64 cycles.  Swept on the long-utterance workload
+    // (ms per fraction; backward n / forward n): 0 / 0 33.1; 2 / 2 31.85; 4 / 4 32.7; 6 / 6 33.8; 9 / 9 35.3; 2 / 1 31.71;
+    // 1 / 1 31.70; 3 / 1 31.8; 2 / 3 32.0 -- two for the backward kernel's 14 granules, one for the forward kernel's 7.
+    if constexpr (K > 8 && CN_POLL_DELAY_MANY > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_MANY);
+    else if constexpr (K > 4 && CN_POLL_DELAY_7 > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_7);
     for (;;) {
         u64 x[K];
         sample_all<K>(slot, x);
