@@ -16,7 +16,9 @@ them.  A step:
     e = A0 + A1 + B2 + B3 of the lane's unit group, block errors, deltas -> bf16: publish (two tagged 8-byte granules), own rows
     of the NEXT tile, delta_op; block of the next step; barrier
 Where the poll is issued was measured (S2C_POLL=top | early | both; reading B / LVCSR ms per fraction, same box, interleaved):
-top of the step 2.59 / 9.39; in front of the previous step's last barrier (its sample often arrives in L2 before the partner's
+top of the step 2.59 / 9.39 (later in the round, other box: 2.573 / 9.30); behind MFMA 2 / 4 / 6 / 9 of the own half, prefetch
+behind it ("mid", S2C_POLL_AT; what a delayed first sample bought the 8-CU kernels): 2.80 / 9.93, 2.81 / 9.93, 2.82 / 10.0,
+2.83 / 10.08 -- here the own half is long enough for the top sample to come back with the data; in front of the previous step's last barrier (its sample often arrives in L2 before the partner's
 store: retries) 2.61 / 9.49; both samples 2.64 / 9.64 (the extra sample costs more than it finds, as in the 8-wave kernels).
 
 ONE view of the tile (round 5; the s2 kernels read it through two zero-padded views, one per unit group): lanes c >= 8 read the
@@ -31,6 +33,7 @@ w{j}k{kc} (256 AGPRs).  vmcnt per step, in order: poll x2, prefetch x4, outputEr
 """
 import os
 
+POLL_AT = int(os.environ.get("S2C_POLL_AT", "4"))     # "mid": the own half's MFMA (0 .. 11) behind which the sample leaves
 POLL = os.environ.get("S2C_POLL", "top")        # where a step's poll is issued: "top" of the step, "early" (in front of the previous step's
                                                 # last barrier), "both" (two samples: the early one is looked at first)
 STAMP = False        # the second text (S2C_ASM_TEXT_STAMP, -DCN_S2C_STAMP builds): s_memtime deltas per step segment summed into st0 .. st6
@@ -136,10 +139,13 @@ def step(o, k):
     for r in (s["A1"][0], s["A1"][1], s["B2"][0], s["B3"][0], s["B2"][1], s["B3"][1]):
         o("v_mov_b32 %s, 0" % r)
     # ---- prefetch of step t+4 into this stage (its block was formed at the end of the previous step: the registers are dead)
-    o("global_load_dwordx4 %s, %%[oA], %%[actspf]" % s["AX"])
-    o("global_load_dword %%[%s], %%[oC], %%[thpf]" % s["TH"])
-    o("global_load_dword %%[%s], %%[oC], %%[cellpf]" % s["CP"])
-    o("global_load_ubyte %%[%s], %%[oP], %%[patpf]" % s["PT"])
+    prefetch = ["global_load_dwordx4 %s, %%[oA], %%[actspf]" % s["AX"],
+                "global_load_dword %%[%s], %%[oC], %%[thpf]" % s["TH"],
+                "global_load_dword %%[%s], %%[oC], %%[cellpf]" % s["CP"],
+                "global_load_ubyte %%[%s], %%[oP], %%[patpf]" % s["PT"]]
+    if POLL != "mid":
+        for t in prefetch:
+            o(t)
     # ---- own K half while the granules travel; offsets and the factor-m products in its gaps (one VALU per gap)
     own_fill = {0: ["v_add_u32 %[oA], %[oA], %[sA]"], 1: ["v_add_u32 %[oC], %[oC], %[sC]"], 2: ["v_add_u32 %[oD], %[oD], %[sD]"],
                 3: ["v_add_u32 %[oP], %[oP], %[sP]"], 4: ["v_mul_f32 %[t2m], %[t2m], %[m]"], 5: ["v_mul_f32 %[wm], %[wm], %[m]"],
@@ -149,6 +155,18 @@ def step(o, k):
                 10: ["v_add_f32 %[sb0], %[sb0], %[dni]"], 11: ["v_add_f32 %[sb1], %[sb1], %[dign]"],
                 12: ["v_add_f32 %[sb2], %[sb2], %[dfgn]"], 13: ["v_add_f32 %[sb3], %[sb3], %[dog]"],
                 14: ["v_fmac_f32 %%[spi], %%[%s], %%[dign]" % CS], 15: ["v_fmac_f32 %%[spf], %%[%s], %%[dfgn]" % CS]}
+    if POLL == "mid":
+        # the sample leaves behind MFMA number POLL_AT of the own half (a sample that leaves before the partner's granules are in L2
+        # costs a whole extra round trip), the prefetch behind it (the order of the vector-memory queue stays poll, prefetch: the
+        # wait for the sample leaves the prefetch in flight), the offsets' move to the next step behind the prefetch
+        tmp = Text()
+        poll_issue(tmp, "oXt%d" % (1 - par))
+        moves = [own_fill[i][0] for i in range(4)]
+        for i in range(4):
+            own_fill[i] = []
+        own_fill[POLL_AT] = own_fill.get(POLL_AT, []) + tmp.lines + prefetch
+        for i in range(4):
+            own_fill[POLL_AT + 1 + i] = own_fill.get(POLL_AT + 1 + i, []) + [moves[i]]
     phase(o, s["A"][0], s["A"][1], 0, R, own_fill)
     stamp(o, 1)                                          # 1: top + own half
     # ---- the partner's deltas: wait for the two poll loads (the four prefetch loads behind them stay in flight), check the tags
@@ -222,7 +240,7 @@ def step(o, k):
     block(o, nx["N"], nx["I"], nx["F"], nx["O"], nx["TH"], nx["CP"], nx["PT"], CS)
     # the next step's poll: the partner published about as long ago as this member did (the block above), its store has had that
     # time to reach L2; the sample comes back behind the next step's own half
-    if POLL != "top":
+    if POLL in ("early", "both"):
         poll_issue(o, "oXt%d" % par)
     o("s_waitcnt lgkmcnt(0)")
     stamp(o, 6)                                          # 6: wait for the stage + block
@@ -290,7 +308,7 @@ def text():
     o("s_nop 1")
     s0 = stage_regs(0)
     block(o, s0["N"], s0["I"], s0["F"], s0["O"], s0["TH"], s0["CP"], s0["PT"], "ccB")
-    if POLL != "top":
+    if POLL in ("early", "both"):
         poll_issue(o, "oXt1")                           # step 0 polls the "step -1" granules (zeros) the members publish in front of the loop
     o("1:")
     for k in range(4):
