@@ -45,6 +45,9 @@
 #ifndef CN_POLL_DELAY_MANY
 #define CN_POLL_DELAY_MANY 2
 #endif
+#ifndef CN_POLL_DELAY_PSUM
+#define CN_POLL_DELAY_PSUM 8        // partial-sum backward kernel (bf16x3, 4 CUs): reading B at tolerance, rec_bwd 12.63 -> 12.02 ms per six fractions (4: 12.25, 6: 12.10, 9: 12.02, 12: 12.17)
+#endif
 #ifndef CN_POLL_DELAY_7
 #define CN_POLL_DELAY_7 1
 #endif
@@ -133,7 +136,7 @@ __device__ __forceinline__ unsigned consume(const u64 *slot, unsigned epoch, int
 // instead of one per granule (7 partners x RPL granules in the 8-CU shape)
 // A poll that times out (a partner never arrived: not resident, or faulted) sets the fault word AND `gaveup`: the thread
 // does not wait again, so a broken launch ends after one time-out (~1 s) instead of one per time step.
-template <int K>
+template <int K, int DELAY = -1>
 __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigned epoch, int *fault, unsigned (&val)[K], bool &gaveup)
 {
     int spins = gaveup ? (1 << 21) : 0;
@@ -166,8 +169,9 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
     // costs a whole extra round trip, so the FIRST one waits s_sleep(n) = n x 64 cycles.  Swept on the long-utterance workload
     // (ms per fraction; backward n / forward n): 0 / 0 33.1; 2 / 2 31.85; 4 / 4 32.7; 6 / 6 33.8; 9 / 9 35.3; 2 / 1 31.71;
     // 1 / 1 31.70; 3 / 1 31.8; 2 / 3 32.0 -- two for the backward kernel's 14 granules, one for the forward kernel's 7.
-    if constexpr (K > 8 && CN_POLL_DELAY_MANY > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_MANY);
-    else if constexpr (K > 4 && CN_POLL_DELAY_7 > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_7);
+    if constexpr (DELAY > 0) __builtin_amdgcn_s_sleep(DELAY);
+    else if constexpr (DELAY < 0 && K > 8 && CN_POLL_DELAY_MANY > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_MANY);
+    else if constexpr (DELAY < 0 && K > 4 && CN_POLL_DELAY_7 > 0) __builtin_amdgcn_s_sleep(CN_POLL_DELAY_7);
     for (;;) {
         u64 x[K];
         sample_all<K>(slot, x);
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_psum_kernel(LstmRec 
             unsigned vals[CS - 1];
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j) slots[j] = xslot + ((long)member * CS + (member + 1 + j) % CS) * NT + tid;
-            consume_all<CS - 1>(slots, p.xch_epoch + it + 1, p.fault, vals, gaveup);
+            consume_all<CS - 1, CN_POLL_DELAY_PSUM>(slots, p.xch_epoch + it + 1, p.fault, vals, gaveup);
 #pragma unroll
             for (int j = 0; j < CS - 1; ++j) e += __uint_as_float(vals[j]);
         }
