@@ -519,6 +519,10 @@ __global__ __launch_bounds__(512) void gemm_nt_big8_kernel(GemmNT p, int tiles_n
 bool gemm_nt_big_applies(int prec, const GemmNT &g)
 {
     const bool f32 = prec != P_BF16;     // the LDS-DMA kernel is bf16 only (P_F32 / P_X3 operands are fp32 in memory)
+    // split-bf16: the fp32 instance of this kernel multiplies with EXACT fp32 MFMAs (1/16 of the bf16 rate), the 128-column
+    // kernel with three bf16 MFMAs per product (3/16): until round 5 the mode's large products came here and ran at a third of the
+    // speed they have there (reading B at tolerance: gemm_wide 7.89 -> 5.03 ms per six fractions, 3.07 -> 3.41 M frames/s)
+    if (prec == P_X3) return false;
     static const bool off = getenv("CN_NO_BIG_GEMM") != nullptr;
     const int KB = BG_ROWB / (f32 ? 4 : 2);
     if (off || g.K % KB != 0 || g.K < 4 * KB) return false;
