@@ -199,7 +199,7 @@ __global__ void pack_group_kernel(PackGroup grp)
     int i = 0;
 #pragma unroll
     for (int k = 1; k < PACK_GROUP_MAX; ++k) if (k < grp.n && (int)blockIdx.x >= grp.first[k]) i = k;
-    const PackItem &it = grp.item[i];
+    const PackItem it = grp.item[i];     // (a copy: through a reference into the argument struct hipcc re-loads fields inside the loops)
     const int count = (i + 1 < grp.n ? grp.first[i + 1] : (int)gridDim.x) - grp.first[i];
     if (it.update) {      // cn_sgd_update_all: the weight update rides on the pack (one launch instead of two on the critical tail)
         const PackUpd upd{it.w_rw, it.wu, it.wd, it.lr, it.mom, it.wu_rw};

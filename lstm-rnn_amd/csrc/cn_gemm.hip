@@ -336,7 +336,9 @@ __global__ __launch_bounds__(tn_threads(BM)) void gemm_tn_kernel(GemmTNGroup grp
     int gi = 0;
 #pragma unroll
     for (int i = 1; i < TN_GROUP; ++i) if ((int)blockIdx.x >= grp.first_block[i]) gi = i;
-    const GemmTN &p = grp.p[gi];
+    // a COPY of the product's description: through a reference into the kernel-argument struct (the index is dynamic) hipcc re-loaded
+    // M / N / lda / ldb with an s_load + wait in front of every global load of the K loop (ISA, round 5)
+    const GemmTN p = grp.p[gi];
     const int tiles_n = grp.tiles_n[gi], ntiles = grp.ntiles[gi], kchunk = grp.kchunk[gi];
     const int bid = blockIdx.x - grp.first_block[gi];
 
