@@ -118,6 +118,16 @@ typedef struct cn_fraction {
 int  cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **out);
 int  cn_ctx_destroy(cn_ctx *ctx);
 int  cn_ctx_synchronize(cn_ctx *ctx);                                   /* [sync] */
+/* Named integer options of a context (no counterpart in the reference, whose Cpu path has nothing to choose):
+ *   "deterministic"  1: every sum over the patterns of a fraction -- weight gradients (ComputeWeightUpdateFn,
+ *                    LstmLayer.cu:289-512; FeedForwardLayer.cu:82-102,200-207), bias / peephole / column sums, the error --
+ *                    is formed in a fixed order (partials stored by their producers, added by one thread per output), so
+ *                    two runs on the same inputs give BIT-IDENTICAL gradients and weights, like the reference's serial
+ *                    sums.  0: fp32 atomics in arrival order.  Default: 1 for CN_PREC_F32 / CN_PREC_BF16X3 (the parity
+ *                    modes), 0 for CN_PREC_BF16; the environment variable CN_DETERMINISTIC=0/1 sets the default.
+ * Unknown names fail with CN_ERR_BAD_ARG.  May be changed between fractions.                                       */
+int  cn_ctx_set_option(cn_ctx *ctx, const char *name, int value);
+int  cn_ctx_get_option(const cn_ctx *ctx, const char *name, int *value);
 /* The weight-gradient GEMMs of a backward pass run on an internal side stream beside the next layer's
  * recurrent kernel.  Every entry point of this library orders itself behind them; call cn_ctx_join before
  * ANOTHER library (e.g. RCCL through torch.distributed) reads weightUpdates on the ctx stream: it makes the

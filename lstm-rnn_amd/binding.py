@@ -28,7 +28,7 @@ BUF = {
 
 # every symbol include/currennt_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_ctx_join", "cn_layer_join", "cn_layer_join_stream", "cn_ctx_stream", "cn_last_error", "cn_device_arch", "cn_device_count", "cn_device_name",
+    "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_ctx_set_option", "cn_ctx_get_option", "cn_ctx_join", "cn_layer_join", "cn_layer_join_stream", "cn_ctx_stream", "cn_last_error", "cn_device_arch", "cn_device_count", "cn_device_name",
     "cn_version", "cn_layer_create", "cn_layer_destroy", "cn_layer_size", "cn_layer_kind_of",
     "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_fraction_prefetch_resident", "cn_layer_forward",
     "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
@@ -88,6 +88,8 @@ def load_library():
     L.cn_ctx_create.argtypes = [ci, ci, vp, C.POINTER(vp)]
     L.cn_ctx_destroy.argtypes = [vp]
     L.cn_ctx_synchronize.argtypes = [vp]
+    L.cn_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.cn_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
     L.cn_ctx_join.argtypes = [vp]
     L.cn_layer_join.argtypes = [vp]
     L.cn_layer_join_stream.argtypes = [vp, vp]

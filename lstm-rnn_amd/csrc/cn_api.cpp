@@ -72,6 +72,12 @@ struct cn_ctx {
     bool overlap = true;
     bool attach_forks = true;                  // CN_NO_ATTACHED_FORKS=1: fork / join / update events recorded with hipEventRecord
     bool f32 = true;                           // operands are fp32 in memory (CN_PREC_F32 and CN_PREC_BF16X3)
+    // option "deterministic": every sum over the patterns of a fraction (weight gradients, bias / peephole / column sums, the
+    // error) is formed in a fixed order -- partials stored by their producers, added by one thread per output -- instead of
+    // with fp32 atomics in arrival order: two runs give bit-identical weights, as the reference's Cpu path does (one logical
+    // thread per weight, serial sum: LstmLayer.cu:289-512, FeedForwardLayer.cu:82-102).  On by default in the parity modes
+    // (CN_PREC_F32, CN_PREC_BF16X3), opt-in for CN_PREC_BF16; CN_DETERMINISTIC=0/1 sets the default of new contexts.
+    bool det = false;
     int prec = P_F32;                          // arithmetic of the MFMA products: P_F32 / P_BF16 / P_X3 (cn_internal.h)
     int num_cus = 256;                         // hipDeviceProp_t::multiProcessorCount of the bound device
     std::string arch;
@@ -201,6 +207,11 @@ struct cn_layer {
     bool pack_pending = false;
 
     char kname[2][CN_KNAME_LEN] = {{0}, {0}};   // recurrent kernels the last forward / backward pass launched (written by the launchers)
+
+    // deterministic mode (allocated at the first backward pass that needs them)
+    float *det_ws = nullptr;              // split-K partial products: DET_MAX_SPLITS copies of [dWin | dWrec]
+    float *gpart = nullptr; int gpart_slots = 0;   // LSTM: per-workgroup bias / peephole sums (LstmRec::gpart)
+    float *det_colpart = nullptr;         // dense layers: per-workgroup column sums (det_colsum_part_floats)
 
     std::vector<void *> owned;            // device allocations to free
 
@@ -584,6 +595,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
         static const int margin = getenv("CN_COMM_CU_MARGIN") ? atoi(getenv("CN_COMM_CU_MARGIN")) : 32;
         r.cluster_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
     }
+    r.gpart = nullptr; r.gpart_slots = 0; r.det_grid = nullptr;
     r.kname = nullptr;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
     if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }
@@ -591,6 +603,23 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
 }
 
 // the single-CU recurrent kernels keep two operand tiles (and, backward, one byte per time step and sequence) in LDS
+// deterministic mode: the layer's workspaces for stored partial sums (zeroed; owned by the layer)
+void ensure_det(cn_layer *l)
+{
+    cn_ctx *c = l->ctx;
+    if (l->det_ws) return;
+    if (l->lstm) {
+        const size_t R = (size_t)l->dirs * 4 * l->Hp;
+        l->det_ws = (float *)dalloc(l, (size_t)DET_MAX_SPLITS * (R * l->Pp + R * l->Hp) * sizeof(float));
+        // one slot per workgroup of the backward kernel: at most one workgroup per sequence, direction and cluster member
+        l->gpart_slots = l->dirs * c->PSp * 8 + 64;
+        l->gpart = (float *)dalloc(l, (size_t)l->gpart_slots * 7 * l->dirs * l->Hp * sizeof(float));
+    } else {
+        l->det_ws = (float *)dalloc(l, (size_t)DET_MAX_SPLITS * l->Lp * l->Pp * sizeof(float));
+        l->det_colpart = (float *)dalloc(l, det_colsum_part_floats(l->Lp) * sizeof(float));
+    }
+}
+
 void check_rec_lds(const cn_layer *l, bool bwd)
 {
     const cn_ctx *c = l->ctx;
@@ -651,9 +680,12 @@ void lstm_backward(cn_layer *l)
     repack(l);
     bool fork_attached = false;
     // (the packed gradient accumulators are zero here: allocation clears them, the unpack kernel re-clears them)
+    int det_grid = 0;
+    if (c->det) ensure_det(l);
     {   // K5+K6+K7 and the bias / peephole sums of K9
         Timed tm(c, KC_REC_BWD);
         LstmRec r; lstm_rec_args(l, r); r.kname = l->kname[1];
+        if (c->det) { r.gpart = l->gpart; r.gpart_slots = l->gpart_slots; r.det_grid = &det_grid; }
         if (!launch_lstm_cluster(c->stream, c->prec, true, r, &c->xch_epoch)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
@@ -683,6 +715,7 @@ void lstm_backward(cn_layer *l)
             GemmTN g{};
             g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
+            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; }
             gs[ng++] = g;
             // K9 recurrent weights: dWrec[(j,g)][i] = sum_t delta[t][(j,g)] y[prev(t)][i]
             if (N > PS) {
@@ -694,10 +727,18 @@ void lstm_backward(cn_layer *l)
                     else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
                     r.lda = R; r.ldb = l->Lp;
                     r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
+                    if (c->det) { r.ws = l->det_ws + (size_t)DET_MAX_SPLITS * ((size_t)R * l->Pp + (size_t)d * 4 * Hp * Hp); r.ws_splits = DET_MAX_SPLITS; }
                     gs[ng++] = r;
                 }
             }
             launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus);      // the three products side by side in one launch
+            if (c->det) {
+                // the workgroups' bias / peephole sums, added in workgroup order (dbias and dpeep are neighbours, in the gradient
+                // block and in a slot alike)
+                const int slot = 7 * l->dirs * Hp;
+                const FoldItem f{l->dbias, l->gpart, (long)slot, det_grid, 1, slot, slot, 1, 1};
+                launch_fold(st, &f, 1);
+            }
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -748,6 +789,7 @@ void ff_backward(cn_layer *l)
     cn_ctx *c = l->ctx;
     const int N = c->N;
     repack(l);
+    if (c->det) ensure_det(l);
     {
         Timed tm(c, KC_OTHER);
         if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
@@ -755,7 +797,7 @@ void ff_backward(cn_layer *l)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
                                    with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6, l->sm_lazy ? l->sm_stat : nullptr,
-                                   softmax_fast(c), c->d_colpart);
+                                   softmax_fast(c), c->d_colpart, c->det ? l->det_colpart : nullptr);
             l->sm_lazy_next = !l->sm_read;
             if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
@@ -766,7 +808,7 @@ void ff_backward(cn_layer *l)
             if (l->mcc_pending) launch_mcc_backward(c->stream, y, c->d_tcls, N, l->size, l->Lp, l->err);
             if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, y, l->err, c->d_pat, N, l->size, l->Lp);
             launch_ff_delta(c->stream, c->f32, ff_act(l->kind), y, l->err, l->delta_op, N, l->size, l->Lp);
-            launch_colsum(c->stream, l->err, N, l->Lp, l->dbias);
+            launch_colsum(c->stream, l->err, N, l->Lp, l->dbias, c->det ? l->det_colpart : nullptr);
         }
         l->mcc_pending = false;
     }
@@ -787,6 +829,7 @@ void ff_backward(cn_layer *l)
             GemmTN g{};
             g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
+            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; }
             launch_gemm_tn(st, c->prec, g, c->tn_cus);
         }
         {
@@ -862,6 +905,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             c->side_slow = masked_stream(device_id, ncu, prop.multiProcessorCount);
             c->side_cus = ncu;
         }
+        c->det = precision != CN_PREC_BF16;
+        if (const char *e = getenv("CN_DETERMINISTIC")) c->det = atoi(e) != 0;
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
         if (const char *e = getenv("CN_NO_ATTACHED_FORKS")) c->attach_forks = atoi(e) == 0;
         if (const char *e = getenv("CN_RPL")) c->rpl_override = atoi(e);   // experiments: force 4/8/16 sequences per workgroup
@@ -914,6 +959,24 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->acc); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
         delete ctx;
+    });
+}
+
+int cn_ctx_set_option(cn_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) { g_last_error = "cn_ctx_set_option: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        if (!strcmp(name, "deterministic")) { ctx->det = value != 0; return; }
+        throw cn_error(CN_ERR_BAD_ARG, std::string("cn_ctx_set_option: unknown option \"") + name + "\"");
+    });
+}
+
+int cn_ctx_get_option(const cn_ctx *ctx, const char *name, int *value)
+{
+    if (!ctx || !name || !value) { g_last_error = "cn_ctx_get_option: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        if (!strcmp(name, "deterministic")) { *value = ctx->det ? 1 : 0; return; }
+        throw cn_error(CN_ERR_BAD_ARG, std::string("cn_ctx_get_option: unknown option \"") + name + "\"");
     });
 }
 
@@ -983,20 +1046,44 @@ int cn_comm_init(cn_ctx *ctx, const char *id, int rank, int world)
         if (world < 1 || rank < 0 || rank >= world) throw cn_error(CN_ERR_BAD_ARG, "cn_comm_init: rank " + std::to_string(rank) + " outside world of " + std::to_string(world));
         if (ctx->has_comm()) throw cn_error(CN_ERR_STATE, "cn_comm_init: this context already has a communicator");
         HIP_CHECK(hipSetDevice(ctx->device));
+        if (!ctx->comm_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm_fork, hipEventDisableTiming));
+        }
         if (ipc_backend_selected()) {
-            try { ctx->ipc = ipc_comm_create(id, rank, world); }
-            catch (const std::exception &e) { throw cn_error(CN_ERR_COMM, e.what()); }
+            char fallback[CN_COMM_ID_BYTES];
+            bool p2p_ok = true;
+            try {
+                ctx->ipc = ipc_comm_create(id, rank, world);
+                // p2p: first contact.  Regions mapped, both forms of the exchange on a known bucket, one shared verdict.
+                if (ipc_comm_is_p2p(ctx->ipc))
+                    p2p_ok = ipc_comm_p2p_selfcheck(ctx->ipc, ctx->comm_stream, [](char *out) {
+                        ncclUniqueId u;
+                        rccl_check(rccl().GetUniqueId(&u), "ncclGetUniqueId");
+                        memcpy(out, &u, sizeof(u));
+                    }, fallback);
+            }
+            catch (const cn_error &) { if (ctx->ipc) { ipc_comm_mark_failed(ctx->ipc); ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr; } throw; }
+            catch (const std::exception &e) {
+                if (ctx->ipc) { ipc_comm_mark_failed(ctx->ipc); ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr; }
+                throw cn_error(CN_ERR_COMM, e.what());
+            }
+            if (!p2p_ok) {
+                // some rank saw a wrong sum or a time-out through a peer mapping: nobody trains on this backend.  Every rank got the
+                // same verdict and the id rank 0 made: the job goes on over RCCL and says so.
+                ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr;
+                fprintf(stderr, "cn_comm_init: rank %d of %d: CN_COMM_BACKEND=p2p failed its first-contact self-check; falling back to RCCL\n", rank, world);
+                ncclUniqueId u;
+                memcpy(&u, fallback, sizeof(u));
+                RCCL_CHECK(rccl().CommInitRank(&ctx->comm, world, u, rank));
+            }
         } else {
             ncclUniqueId u;
             memcpy(&u, id, sizeof(u));
             RCCL_CHECK(rccl().CommInitRank(&ctx->comm, world, u, rank));
         }
         ctx->comm_rank = rank; ctx->comm_world = world;
-        if (!ctx->comm_stream) {
-            HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
-            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm_fork, hipEventDisableTiming));
-        }
     });
 }
 
@@ -1008,9 +1095,16 @@ int cn_comm_destroy(cn_ctx *ctx)
         HIP_CHECK(hipSetDevice(ctx->device));
         HIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->ipc) { ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr; }
+        std::string failure;
+        if (ctx->ipc) {
+            // p2p: a poll that timed out on the device is reported here at the latest (the resources go either way)
+            try { ipc_comm_check(ctx->ipc, ctx->comm_stream); }
+            catch (const std::exception &e) { ipc_comm_mark_failed(ctx->ipc); failure = e.what(); }
+            ipc_comm_destroy(ctx->ipc); ctx->ipc = nullptr;
+        }
         else RCCL_CHECK(rccl().CommDestroy(ctx->comm));
         ctx->comm = nullptr; ctx->comm_world = 0; ctx->comm_rank = 0; ctx->comm_pending = false;
+        if (!failure.empty()) throw cn_error(CN_ERR_COMM, failure);
     });
 }
 
@@ -1027,6 +1121,14 @@ const char *cn_comm_backend(const cn_ctx *ctx, int64_t *exchanges)
     if (exchanges) *exchanges = ctx ? ctx->comm_exchanges : 0;
     if (!ctx || !ctx->has_comm()) return "";
     return ctx->comm ? "rccl" : ipc_comm_is_p2p(ctx->ipc) ? "p2p" : "ipc";
+}
+
+// p2p: a wait inside an exchange kernel timed out (host-mapped word, no synchronisation): no update on top of a NaN gradient
+static void comm_check_fast(cn_ctx *ctx)
+{
+    if (!ctx->ipc) return;
+    try { ipc_comm_check_fast(ctx->ipc); }
+    catch (const std::exception &e) { throw cn_error(CN_ERR_COMM, e.what()); }
 }
 
 // the ipc / p2p backends' exchange (ipc: host-blocking); a failure marks the segment so that the peers leave their barriers at once
@@ -1220,7 +1322,8 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && size == 1)                                  // MulticlassClassificationLayer.cu:146-147
                 throw cn_error(CN_ERR_SHAPE, "The multiclass classification post output layer cannot be used for an output layer size of 1");
             l->post = true; l->Lp = preceding->Lp;
-            if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && preceding->kind == CN_LAYER_SOFTMAX && !ctx->d_rowstat)
+            // (every post output layer: the per-pattern terms of its error pass through here and are summed in a fixed order)
+            if (kind == CN_LAYER_MULTICLASS_CLASSIFICATION && !ctx->d_rowstat)
                 HIP_CHECK(hipMalloc((void **)&ctx->d_rowstat, maxN * 2 * sizeof(float)));
             if (kind != CN_LAYER_MULTICLASS_CLASSIFICATION) {
                 l->targets = (float *)dalloc(l, maxN * size * sizeof(float));
@@ -1507,9 +1610,11 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
             Timed tm(c, KC_OTHER);
             if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
                 launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss, true);
-            else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-                launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true);
-            else {
+            else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
+                flush_loss(c);
+                launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss, true, c->d_rowstat);
+                c->rowstat_of = nullptr;       // (the row statistics now are this evaluation's terms)
+            } else {
                 flush_loss(c);
                 launch_post_eval(c->stream, post_kind(post), posteriors(o), post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss, true);
                 c->rowstat_of = nullptr;       // the softmax row statistics were overwritten
@@ -1547,9 +1652,10 @@ int cn_loss_accumulate(cn_layer *post)
         Timed tm(c, KC_OTHER);
         if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o)
             launch_rowstat_reduce(c->stream, c->d_rowstat, c->N, c->d_loss_acc, false);
-        else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION)
-            launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false);
-        else {
+        else if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION) {
+            launch_mcc_eval(c->stream, posteriors(o), c->d_tcls, c->N, post->size, o->Lp, c->d_loss_acc, false, c->d_rowstat);
+            c->rowstat_of = nullptr;
+        } else {
             launch_post_eval(c->stream, post_kind(post), posteriors(o), post->targets, c->d_pat, c->N, o->size, o->Lp, c->d_rowstat, c->d_loss_acc, false);
             c->rowstat_of = nullptr;
         }
@@ -1782,6 +1888,7 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
         cn_ctx *c = layer->ctx;
         HIP_CHECK(hipSetDevice(c->device));
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_sgd_update: layer has no weights");
+        comm_check_fast(c);
         finalize(c);
         join_side(c);
         if (layer->updated) {            // cn_ctx_arm_update: this layer's step ran behind its gradient; nothing left but the wait above
@@ -1842,6 +1949,7 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
     if (!ctx) { g_last_error = "cn_sgd_update_all: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         HIP_CHECK(hipSetDevice(ctx->device));
+        comm_check_fast(ctx);
         finalize(ctx);
         join_side(ctx);
         // cn_ctx_arm_update: layers whose step ran behind their gradient are complete (the wait above orders this stream behind

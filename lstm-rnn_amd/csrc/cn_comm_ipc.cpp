@@ -13,9 +13,13 @@
 // CN_COMM_BACKEND=p2p -- the NATIVE small-message backend, same rendezvous: every rank owns a region (flag words + two staging
 // halves), publishes its hipIpc handle once (and again when a larger bucket arrives: the only host barriers of the backend), and
 // an all-reduce is ONE kernel on the caller's stream that stages, signals, sums and acknowledges through the peers' mapped
-// regions (cn_comm_p2p.hip).  Nothing blocks the host; a poll that times out on the device marks the communicator failed and the
-// next synchronising call (cn_loss_read_global, cn_comm_destroy) raises.  One rank per GPU over xGMI is the intended use; ranks
-// that share a device (the tests on a one-GPU box) run the same code.
+// regions (cn_comm_p2p.hip).  Nothing blocks the host; a poll that times out on the device marks the communicator failed, turns
+// the workgroup's share of the gradient into NaN and sets a host-mapped word: the next call into the communicator
+// (cn_allreduce_grads, cn_sgd_update*, cn_loss_read_global, cn_comm_destroy) raises.  One rank per GPU over xGMI is the intended
+// use; ranks that share a device (the tests on a one-GPU box) run the same code.  cn_comm_init runs a first-contact self-check
+// through every peer's mapping (ipc_comm_p2p_selfcheck) and fails over to RCCL, with a message, when any rank sees a wrong sum:
+// the first time two DEVICES meet must not be a silent wrong gradient.  cn_comm_destroy is collective in this mode (a host
+// barrier in front of the unmapping: a peer may still be reading my staging half when my own kernel has finished).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -51,6 +55,8 @@ struct Shared {
     std::atomic<unsigned> arrived;               // sense-reversing barrier
     std::atomic<unsigned> sense;
     std::atomic<unsigned> failed;                // a rank gave up: everybody leaves
+    std::atomic<unsigned> selfcheck_bad;         // p2p: some rank's first-contact self-check saw a wrong sum or a time-out
+    char rccl_id[128];                           // ... then rank 0 leaves the id of the RCCL communicator to fail over to here
     Slot slot[IPC_MAX_RANKS];
 };
 
@@ -83,6 +89,8 @@ struct IpcComm {
     unsigned long long *peer_region[IPC_MAX_RANKS] = {};
     unsigned long long seq = 0;
     size_t oneshot_max = 256 * 1024;             // floats: larger buckets go reduce-scatter + all-gather
+    unsigned long long *host_failed = nullptr, *host_failed_dev = nullptr;   // host-mapped word the kernel sets when a wait times out
+    bool force_two_phase = false, coarse = false, verbose = false;           // CN_P2P_FORCE_TWO_PHASE / _COARSE / _VERBOSE, read once at create
 
     void barrier(const char *what)
     {
@@ -165,6 +173,9 @@ IpcComm *ipc_comm_create(const char *id, int rank, int world)
     IpcComm *c = new IpcComm;
     c->name = id; c->rank = rank; c->world = world; c->p2p = p2p_selected();
     if (const char *t = getenv("CN_P2P_ONESHOT_MAX")) c->oneshot_max = (size_t)atoll(t);
+    c->force_two_phase = getenv("CN_P2P_FORCE_TWO_PHASE") != nullptr;
+    c->coarse = getenv("CN_P2P_COARSE") != nullptr;
+    c->verbose = getenv("CN_P2P_VERBOSE") != nullptr;
     if (const char *t = getenv("CN_COMM_IPC_TIMEOUT")) {
         const double v = atof(t);              // garbage or 0 would time every barrier out at once: keep the default then
         if (v >= 1.0) c->timeout_s = v;
@@ -184,12 +195,33 @@ IpcComm *ipc_comm_create(const char *id, int rank, int world)
         throw;
     }
     if (rank == 0) { shm_unlink(id); ipc_forget_pending(id); }           // every rank holds a mapping now: nothing stays behind in /dev/shm
+    if (c->p2p) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            munmap(p, sizeof(Shared)); delete c;
+            throw std::runtime_error("p2p communicator: no host-mapped memory for the failure word");
+        }
+        memset(h, 0, 64);
+        c->host_failed = (unsigned long long *)h; c->host_failed_dev = (unsigned long long *)d;
+    }
     return c;
 }
 
+static bool p2p_failed_word(const IpcComm *c) { return c->host_failed && *(volatile unsigned long long *)c->host_failed != 0; }
+
+// The caller has synchronised its own streams.  p2p: that only says MY kernels are through -- a peer may still be reading my
+// staging half (one-shot step 2, all-gather step 4) and will still write its DONE words into my region, so the ranks meet on the
+// host before anybody unmaps or frees (cn_comm_destroy is collective in this mode; a failed communicator skips the meeting).
 void ipc_comm_destroy(IpcComm *c)
 {
     if (!c) return;
+    if (c->p2p && c->region && c->sh && !c->sh->failed.load() && !p2p_failed_word(c)) {
+        try { c->barrier("cn_comm_destroy (p2p: nobody reads a peer's region any more)"); }
+        catch (const std::exception &e) { fprintf(stderr, "%s\n", e.what()); }
+    }
+    if (c->host_failed) (void)hipHostFree(c->host_failed);
     for (int r = 0; r < c->world; ++r)
         if (r != c->rank && c->peer_region[r]) (void)hipIpcCloseMemHandle(c->peer_region[r]);
     if (c->region) (void)hipFree(c->region);
@@ -221,12 +253,18 @@ static void p2p_grow(IpcComm *c, size_t want, hipStream_t st)
     // memory is only coherent across devices at kernel boundaries); plain device memory if the runtime refuses
     void *p = nullptr;
     bool fine = true;
-    if (getenv("CN_P2P_COARSE") || hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
+    if (c->coarse) {                      // asked for (an A/B switch for one-device boxes): never a silent degradation
         hipck(hipMalloc(&p, bytes), "hipMalloc(p2p region)");
         fine = false;
+    } else {
+        const hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw std::runtime_error(std::string("p2p communicator: no fine-grained device memory for the exchange region (") + hipGetErrorString(e) +
+                                     "); coarse-grained memory is not coherent across devices while kernels run -- set CN_P2P_COARSE=1 only for ranks that share one device");
+        }
     }
-    if (getenv("CN_P2P_VERBOSE"))
+    if (c->verbose)
         fprintf(stderr, "p2p communicator: rank %d of %d: region of %zu bytes (%s), staging halves of %zu floats\n", c->rank, c->world, bytes,
                 fine ? "fine-grained" : "coarse-grained", cap);
     c->region = (unsigned long long *)p; c->half_cap = cap; c->seq = 0;
@@ -248,26 +286,94 @@ static void p2p_grow(IpcComm *c, size_t want, hipStream_t st)
     c->barrier("cn_allreduce_grads (p2p: regions mapped)");
 }
 
-static void p2p_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t hint)
+void ipc_comm_check_fast(IpcComm *c)
 {
-    if (n == 0) return;
-    if (n > c->half_cap) p2p_grow(c, n > hint ? n : hint, st);
+    if (c && c->p2p && p2p_failed_word(c)) {
+        c->sh->failed.store(1);
+        throw std::runtime_error("p2p communicator: rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " waited more than " +
+                                 std::to_string((int)c->timeout_s) + " s for a peer inside a gradient exchange (the gradient of that exchange was set to NaN)");
+    }
+}
+
+// one exchange kernel; form: 0 = by size, 1 = one shot, 2 = reduce-scatter + all-gather
+static void p2p_launch(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t hint, int form, double timeout_s)
+{
+    const size_t pieces = (size_t)c->world * P2P_GROUPS;
+    const size_t piece = ((n + pieces - 1) / pieces + 3) / 4 * 4;
+    // the regrow test IS the launch condition (piece <= slot): slot rounds down, piece rounds up
+    if (!c->region || piece > c->half_cap / pieces / 4 * 4) p2p_grow(c, n > hint ? n : hint, st);
     P2pArgs a{};
     a.buf = buf; a.n = n; a.me = c->rank; a.world = c->world;
-    const size_t pieces = (size_t)c->world * P2P_GROUPS;
-    a.piece = ((n + pieces - 1) / pieces + 3) / 4 * 4;
+    a.piece = piece;
     a.slot = c->half_cap / pieces / 4 * 4;
     if (a.piece > a.slot) throw std::runtime_error("p2p communicator: bucket larger than the staging half");
-    a.two_phase = c->world > 2 && n > c->oneshot_max;
-    if (getenv("CN_P2P_FORCE_TWO_PHASE")) a.two_phase = 1;
+    a.two_phase = form ? form == 2 : (c->force_two_phase || (c->world > 2 && n > c->oneshot_max));
     a.seq = ++c->seq;
-    a.timeout_ticks = (unsigned long long)(c->timeout_s * 1e8);
+    a.timeout_ticks = (unsigned long long)(timeout_s * 1e8);
+    a.host_failed = c->host_failed_dev;
     for (int r = 0; r < c->world; ++r) {
         a.flags[r] = c->peer_region[r];
         a.stage[r] = (float *)(c->peer_region[r] + P2P_FLAG_WORDS) + (a.seq & 1) * c->half_cap;
     }
     launch_p2p_allreduce(st, a);
     hipck(hipGetLastError(), "p2p all-reduce kernel");
+}
+
+static void p2p_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t hint)
+{
+    ipc_comm_check_fast(c);               // a communicator that failed does not take another gradient
+    if (n == 0) return;
+    p2p_launch(c, buf, n, st, hint, 0, c->timeout_s);
+}
+
+// First contact (cn_comm_init): regions allocated and mapped, then both forms of the exchange on a bucket with a known answer --
+// every (rank, workgroup) flag word and one staged line per (peer, workgroup) cross every mapping, under the device-side
+// time-out.  The verdict is shared: if ANY rank saw a wrong sum or a time-out, every rank returns false and carries the id rank 0
+// made for the fall-back communicator.
+bool ipc_comm_p2p_selfcheck(IpcComm *c, hipStream_t st, void (*make_id)(char *), char *rccl_id)
+{
+    const int W = c->world;
+    const size_t n = (size_t)W * P2P_GROUPS * 16 + 3;            // 16 floats (one 64-byte line) per piece and an odd tail
+    std::string why;
+    float *d = nullptr;
+    // (an exception in here leaves the ranks out of step inside the host barriers: it fails the communicator for everybody)
+    try { p2p_grow(c, 64 * 1024, st); }
+    catch (...) { c->sh->failed.store(1); throw; }
+    try {
+        std::vector<float> h(n), back(n);
+        hipck(hipMalloc((void **)&d, n * sizeof(float)), "hipMalloc(self-check)");
+        const double t_check = c->timeout_s < 15.0 ? c->timeout_s : 15.0;
+        for (int form = 1; form <= 2 && why.empty(); ++form) {
+            for (size_t i = 0; i < n; ++i) h[i] = (float)((c->rank + 1) * (int)(i % 251 + 1) + form);
+            hipck(hipMemcpyAsync(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice, st), "hipMemcpyAsync");
+            p2p_launch(c, d, n, st, 0, form, t_check);
+            hipck(hipMemcpyAsync(back.data(), d, n * sizeof(float), hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
+            hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
+            if (p2p_failed_word(c)) { why = "a peer's flag did not arrive"; break; }
+            for (size_t i = 0; i < n; ++i) {
+                const float want = (float)(W * (W + 1) / 2 * (int)(i % 251 + 1) + W * form);     // small integers: exact in fp32, any order
+                if (back[i] != want) {
+                    why = std::string(form == 1 ? "one-shot" : "two-phase") + " sum wrong at element " + std::to_string(i) + ": " + std::to_string(back[i]) + " instead of " + std::to_string(want);
+                    break;
+                }
+            }
+        }
+    } catch (const std::exception &e) { why = e.what(); }
+    if (d) (void)hipFree(d);
+    if (const char *inj = getenv("CN_P2P_SELFCHECK_FAIL"))       // fault injection for the fail-over test: "all" or a rank
+        if (!strcmp(inj, "all") || atoi(inj) == c->rank) why = "fault injected by CN_P2P_SELFCHECK_FAIL";
+    if (!why.empty()) {
+        fprintf(stderr, "p2p communicator: rank %d of %d: first-contact self-check FAILED (%s)\n", c->rank, W, why.c_str());
+        c->sh->selfcheck_bad.store(1);
+    }
+    c->barrier("cn_comm_init (p2p: self-check verdicts)");
+    if (!c->sh->selfcheck_bad.load()) return true;
+    if (c->rank == 0) make_id(c->sh->rccl_id);
+    c->barrier("cn_comm_init (p2p: fall-back id)");
+    memcpy(rccl_id, c->sh->rccl_id, sizeof(c->sh->rccl_id));
+    c->barrier("cn_comm_init (p2p: fall-back id read)");         // (also the meeting ipc_comm_destroy would otherwise hold)
+    c->sh->failed.store(1);                                      // the p2p communicator is abandoned: its destroy does not wait for anybody
+    return false;
 }
 
 // p2p: did a poll time out on the device?  (host-synchronising: called where the host waits anyway)
@@ -277,7 +383,7 @@ void ipc_comm_check(IpcComm *c, hipStream_t st)
     unsigned long long failed = 0;
     hipck(hipMemcpyAsync(&failed, c->region + P2P_FAILED, 8, hipMemcpyDeviceToHost, st), "hipMemcpyAsync");
     hipck(hipStreamSynchronize(st), "hipStreamSynchronize");
-    if (failed) {
+    if (failed || p2p_failed_word(c)) {
         c->sh->failed.store(1);
         throw std::runtime_error("p2p communicator: rank " + std::to_string(c->rank) + " of " + std::to_string(c->world) + " waited more than " +
                                  std::to_string((int)c->timeout_s) + " s for a peer inside a gradient exchange");

@@ -22,13 +22,20 @@
 // RCCL's ring and with the ipc test backend.
 // Memory model: the regions are fine-grained allocations and EVERY access to a staging half or a flag word is a relaxed
 // system-scope atomic (8 bytes; `sc0 sc1` on the instruction: written through to / read from memory, never from a non-coherent
-// cache line), so "release" is a wait for the outstanding stores (`s_waitcnt vmcnt(0)`, a workgroup-scope fence) + barrier in
-// front of the flag store, and "acquire" is the barrier behind the poll -- no L2 write-back or invalidate, which a system-scope
-// fence costs every time while the backward kernels beside the exchange keep the L2s full of dirty lines (first version: 37 us
-// per exchange on one rank, most of it in `buffer_wbl2`).  The gradient itself (a.buf) is ordinary stream-ordered memory.
+// cache line), so "release" is: EVERY wave waits for its own outstanding stores with an explicit `s_waitcnt vmcnt(0)` (gfx9 counts
+// stores in vmcnt), then the workgroup barrier, then the flag store; "acquire" is the barrier behind the poll.  The wait is
+// written out in asm: a workgroup-scope release fence compiles to NO vmcnt wait on gfx950 (round 5 shipped exactly that, the ISA
+// showed `s_waitcnt lgkmcnt(0); s_barrier` only, so the staging stores of waves 1-3 were unordered against wave 0's flag store
+// into the peer's region; tests/test_abi_and_host.py now reads the ISA for the wait).  No L2 write-back or invalidate, which a
+// system-scope fence costs every time while the backward kernels beside the exchange keep the L2s full of dirty lines (first
+// version: 37 us per exchange on one rank, most of it in `buffer_wbl2`).  The gradient itself (a.buf) is ordinary stream-ordered
+// memory.
 // Flags only grow (k is the communicator's exchange counter); a poll that sees nothing for `timeout` ticks of the 100 MHz clock
-// sets the region's `failed` word (and the peers'), after which no poll of the communicator waits any more -- the host reads the
-// word at its next synchronising call and raises CN_ERR_COMM.
+// sets the region's `failed` word (and the peers'), after which no poll of the communicator waits any more.  A workgroup whose
+// wait ended that way does NOT go on summing whatever the peers' halves hold: it overwrites its pieces of the gradient with NaN,
+// sets the host-mapped word `a.host_failed` and leaves -- an update that follows cannot quietly apply a partial sum, and the host
+// raises CN_ERR_COMM at its next call into the communicator (cn_allreduce_grads, cn_sgd_update*, cn_loss_read_global,
+// cn_comm_destroy).
 #include "cn_internal.h"
 
 namespace cn {
@@ -42,39 +49,46 @@ __device__ __forceinline__ u64 get(const u64 *p) { return __hip_atomic_load(p, _
 __device__ __forceinline__ float2 as_f2(u64 v) { float2 f; __builtin_memcpy(&f, &v, 8); return f; }
 __device__ __forceinline__ u64 as_u64(float2 f) { u64 v; __builtin_memcpy(&v, &f, 8); return v; }
 
-// thread-level wait: *p >= want, or the communicator failed, or the deadline passed (then it fails the communicator)
-__device__ __forceinline__ void flag_wait(const P2pArgs &a, const u64 *p, u64 want)
+// thread-level wait: *p >= want (returns false), or the communicator failed, or the deadline passed (then it fails the
+// communicator); both of those return true
+__device__ __forceinline__ bool flag_wait(const P2pArgs &a, const u64 *p, u64 want)
 {
     const u64 *failed = a.flags[a.me] + P2P_FAILED;
     const u64 t0 = __builtin_amdgcn_s_memrealtime();
     int spins = 0;
     while (get(p) < want) {
         if ((++spins & 63) == 0) {
-            if (get(failed)) return;
+            if (get(failed)) return true;
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
                 for (int r = 0; r < a.world; ++r) put(a.flags[r] + P2P_FAILED, 1);
-                return;
+                return true;
             }
         }
         __builtin_amdgcn_s_sleep(1);
     }
+    return false;
 }
 
+// every wave: my stores (staging half, gradient) have been acknowledged and my loads have returned.  gfx9 counts both in vmcnt.
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // this workgroup's stores to its staging half have completed (and its loads from the peers' have returned) before thread
-// r < world writes `word[me][b] = k` into rank r's region
+// r < world writes `word[me][b] = k` into rank r's region: drain in EVERY wave, then the barrier, then the flag
 __device__ __forceinline__ void signal_all(const P2pArgs &a, int word, int b)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    drain_vmem();
     __syncthreads();
     if ((int)threadIdx.x < a.world) put(a.flags[threadIdx.x] + word + a.me * P2P_GROUPS + b, a.seq);
 }
-// wait for `word[r][b] >= want` of all ranks r (only >= 0: of that rank)
-__device__ __forceinline__ void wait_ranks(const P2pArgs &a, int word, int b, int only, u64 want)
+// wait for `word[r][b] >= want` of all ranks r (only >= 0: of that rank).  Block-uniform result: true = a wait of this workgroup
+// ended without its flag (time-out here or a failed communicator)
+__device__ __forceinline__ bool wait_ranks(const P2pArgs &a, int word, int b, int only, u64 want)
 {
     const int t = threadIdx.x;
-    if (only >= 0) { if (t == 0) flag_wait(a, a.flags[a.me] + word + only * P2P_GROUPS + b, want); }
-    else if (t < a.world) flag_wait(a, a.flags[a.me] + word + t * P2P_GROUPS + b, want);
-    __syncthreads();
+    int bad = 0;
+    if (only >= 0) { if (t == 0) bad = flag_wait(a, a.flags[a.me] + word + only * P2P_GROUPS + b, want); }
+    else if (t < a.world) bad = flag_wait(a, a.flags[a.me] + word + t * P2P_GROUPS + b, want);
+    return __syncthreads_or(bad) != 0;
 }
 
 __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2pArgs a)
@@ -87,8 +101,15 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2pArgs a)
     #define P2P_PIECE(s) const size_t lo = ((size_t)(s) * P2P_GROUPS + b) * piece, hi = lo + piece < a.n ? lo + piece : a.n, \
                                       base = ((size_t)(s) * P2P_GROUPS + b) * slot / 2, pairs = hi > lo ? (hi - lo + 1) / 2 : 0
 
+    // a wait that ended without its flag: pieces (*, b) of the gradient -- the ones this workgroup writes in either form -- become
+    // NaN (some may hold sums already, some not: none of it may be used), the host-mapped word tells the host, nothing is signalled
+    #define P2P_FAIL_IF(cond) if (cond) { \
+        for (int s = 0; s < W; ++s) { P2P_PIECE(s); (void)base; (void)pairs; for (size_t e = lo + t; e < hi; e += P2P_THREADS) a.buf[e] = __builtin_nanf(""); } \
+        if (t == 0 && a.host_failed) put(a.host_failed, 1); \
+        return; }
+
     // 0. slot (*, b) of this half is free once the workgroups b of all ranks have finished exchange k - 2
-    if (a.seq > 2) wait_ranks(a, P2P_DONE, b, -1, a.seq - 2);
+    if (a.seq > 2) P2P_FAIL_IF(wait_ranks(a, P2P_DONE, b, -1, a.seq - 2))
     for (int s = 0; s < W; ++s) {
         P2P_PIECE(s);
         for (size_t i = t; i < pairs; i += P2P_THREADS) {
@@ -100,7 +121,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2pArgs a)
     // 1.
     signal_all(a, P2P_READY, b);
     // 2.
-    wait_ranks(a, P2P_READY, b, -1, a.seq);
+    P2P_FAIL_IF(wait_ranks(a, P2P_READY, b, -1, a.seq))
     const int s_first = a.two_phase ? me : 0, s_last = a.two_phase ? me + 1 : W;
     for (int s = s_first; s < s_last; ++s) {
         P2P_PIECE(s);
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2pArgs a)
         signal_all(a, P2P_REDUCED, b);
         for (int d = 1; d < W; ++d) {
             const int s = (me + d) % W;
-            wait_ranks(a, P2P_REDUCED, b, s, a.seq);
+            P2P_FAIL_IF(wait_ranks(a, P2P_REDUCED, b, s, a.seq))
             const u64 *theirs = (const u64 *)a.stage[s];
             P2P_PIECE(s);
             for (size_t i0 = t; i0 < pairs; i0 += 4 * P2P_THREADS) {
@@ -152,6 +173,7 @@ __global__ __launch_bounds__(P2P_THREADS) void p2p_allreduce_kernel(P2pArgs a)
     }
     // last: my reads of the peers' halves have returned
     signal_all(a, P2P_DONE, b);
+    #undef P2P_FAIL_IF
     #undef P2P_PIECE
 }
 

@@ -380,8 +380,64 @@ void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *er
     else     hipLaunchKernelGGL(ff_delta_kernel<false>, dim3(blocks), dim3(256), 0, s, act, y, err, delta_op, N, L, Lp);
 }
 
+// ---------------------------------------------------------------------------------------------
+// deterministic mode: partial sums (split-K partial products, per-workgroup bias / peephole / column sums) are STORED by their
+// producers and added here in a fixed order -- ((p0 + p1) + p2) + ... -- by one thread per output, so a gradient no longer
+// depends on the order in which workgroups retire (the reference sums serially, one logical thread per weight:
+// LstmLayer.cu:289-512, FeedForwardLayer.cu:82-102).
+// ---------------------------------------------------------------------------------------------
+struct FoldGroup { FoldItem it[FOLD_MAX]; int first_block[FOLD_MAX + 1]; };
+__global__ __launch_bounds__(256) void fold_kernel(FoldGroup g)
+{
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < FOLD_MAX; ++i) if ((int)blockIdx.x >= g.first_block[i]) gi = i;
+    const FoldItem f = g.it[gi];
+    const long total = (long)f.rows * f.cols;
+    const long base = (long)(blockIdx.x - g.first_block[gi]) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long e = base + 256 * k;
+        if (e >= total) break;
+        const long idx = (e / f.cols) * f.ld + e % f.cols;
+        float *p = f.part + idx;
+        float t = 0.f;
+        int s = 0;
+        for (; s + 4 <= f.nparts; s += 4) {            // four loads in flight, added in order
+            const float a = p[0], b = p[f.stride], c = p[2 * f.stride], d = p[3 * f.stride];
+            if (f.clear) { p[0] = 0.f; p[f.stride] = 0.f; p[2 * f.stride] = 0.f; p[3 * f.stride] = 0.f; }
+            t = s ? t + a : a; t += b; t += c; t += d;
+            p += 4 * f.stride;
+        }
+        for (; s < f.nparts; ++s) {
+            const float a = *p;
+            if (f.clear) *p = 0.f;
+            t = s ? t + a : a;
+            p += f.stride;
+        }
+        f.dst[idx] = f.accumulate ? f.dst[idx] + t : t;
+    }
+}
+void launch_fold(hipStream_t s, const FoldItem *items, int n)
+{
+    while (n > 0) {
+        FoldGroup g{};
+        int blocks = 0, m = n < FOLD_MAX ? n : FOLD_MAX;
+        for (int i = 0; i < FOLD_MAX; ++i) {
+            g.first_block[i] = blocks;
+            if (i >= m) { g.first_block[i] = 0x7fffffff; continue; }
+            g.it[i] = items[i];
+            blocks += (int)(((long)items[i].rows * items[i].cols + 1023) / 1024);
+        }
+        g.first_block[FOLD_MAX] = blocks;
+        if (blocks) hipLaunchKernelGGL(fold_kernel, dim3(blocks), dim3(256), 0, s, g);
+        items += m; n -= m;
+    }
+}
+
 // colsum[j] += sum_n err[n][j]; block = 256 threads = 8 row lanes x 32 columns, rows strided over the grid
-__global__ void colsum_kernel(const float *err, int N, int Lp, float *colsum)
+// (det_part: the workgroup's sums are stored to its row of det_part instead, launch_colsum folds the rows in workgroup order)
+__global__ void colsum_kernel(const float *err, int N, int Lp, float *colsum, float *det_part)
 {
     __shared__ float part[8][33];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
@@ -394,16 +450,18 @@ __global__ void colsum_kernel(const float *err, int N, int Lp, float *colsum)
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) t += part[r][cx];
-            atomicAdd(&colsum[c0 + cx], t);
+            if (det_part) det_part[(long)blockIdx.x * Lp + c0 + cx] = t;
+            else atomicAdd(&colsum[c0 + cx], t);
         }
         __syncthreads();
     }
 }
-void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum)
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part)
 {
     if (N <= 0) return;
     int blocks = (N + 63) / 64; if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, err, N, Lp, colsum);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, err, N, Lp, colsum, det_part);
+    if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -828,7 +886,8 @@ __device__ __forceinline__ void rowstat_reduce_wave(const float2 *rowstat, int N
 }
 template <bool F32>
 __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
-                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2, float *loss_part, float *colpart)
+                                       float *err, void *delta_op, float *colsum, const float2 *rowstat, float *loss2, float *loss_part, float *colpart,
+                                       float *det_part)
 {
     const unsigned nwg = gridDim.x - (loss2 ? (unsigned)MCC_LOSS_WGS : 0u);
     if (loss2 && blockIdx.x >= nwg) { rowstat_reduce_wave(rowstat, N, loss2, -1.0f, (int)(blockIdx.x - nwg), loss_part); return; }
@@ -914,6 +973,10 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
             if (lane < 16) part[wv][4 * (c + 16 * g) + e] = v;
         }
     __syncthreads();
+    if (det_part) {          // deterministic mode: this workgroup's row of partials, folded in workgroup order by the launcher
+        for (int j = threadIdx.x; j < Lp; j += 256) det_part[(long)blockIdx.x * Lp + j] = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
+        return;
+    }
     if (!colpart) {
         for (int j = threadIdx.x; j < Lp; j += 256) atomicAdd(&colsum[j], (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]));
         return;
@@ -957,7 +1020,7 @@ __global__ void softmax_mcc_bwd_kernel(const float *y, const int *tcls, const ch
 template <bool F32, int LAZY>
 __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *__restrict__ y, const int *__restrict__ tcls, const char *__restrict__ pat,
                                                                    int N, int L, int Lp, float *__restrict__ err, void *__restrict__ delta_op,
-                                                                   float *colsum, const float2 *__restrict__ smstat)
+                                                                   float *colsum, const float2 *__restrict__ smstat, float *det_part)
 {
     typedef __attribute__((ext_vector_type(4))) float f32x4;
     typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -1027,7 +1090,10 @@ __global__ __launch_bounds__(256) void softmax_mcc_bwd_wide_kernel(const float *
         const int j = 4 * (tid + 256 * k);
         if (j < Lp) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(&colsum[j + e], cs[k][e]);
+            for (int e = 0; e < 4; ++e) {
+                if (det_part) det_part[(long)blockIdx.x * Lp + j + e] = cs[k][e];
+                else atomicAdd(&colsum[j + e], cs[k][e]);
+            }
         }
     }
 }
@@ -1036,37 +1102,41 @@ bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
 size_t softmax_mcc_bwd_colpart_floats() { return MCC_COL_REPL * 256 + 1; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part, const float *smstat, bool fast,
-                            float *colpart)
+                            float *colpart, float *det_part)
 {
     if (N <= 0) return;
     if (Lp > 256) {
         int blocks = N < 1536 ? N : 1536;      // (two to three workgroups per CU are resident, 170 VGPRs: 512 ... 2048 measured)
         const float2 *sm = (const float2 *)smstat;
-#define CN_BWD_WIDE(F, Z) hipLaunchKernelGGL((softmax_mcc_bwd_wide_kernel<F, Z>), dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, sm)
+#define CN_BWD_WIDE(F, Z) hipLaunchKernelGGL((softmax_mcc_bwd_wide_kernel<F, Z>), dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, sm, det_part)
         if (f32) { if (!sm) CN_BWD_WIDE(true, 0); else if (fast) CN_BWD_WIDE(true, 2); else CN_BWD_WIDE(true, 1); }
         else     { if (!sm) CN_BWD_WIDE(false, 0); else if (fast) CN_BWD_WIDE(false, 2); else CN_BWD_WIDE(false, 1); }
 #undef CN_BWD_WIDE
+        if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
         return;
     }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
+    const int nwg = blocks;
     if (loss2 && !loss_part) loss2 = nullptr;
     if (loss2) blocks += MCC_LOSS_WGS;
-    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart);
-    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart);
+    if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart, det_part);
+    else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart, det_part);
+    if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, nwg, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
 }
+size_t det_colsum_part_floats(int Lp) { return (size_t)1536 * Lp; }      // the most workgroups any of the column-sum producers launches
 
 // ---------------------------------------------------------------------------------------------
-// post output layers.  loss2[0] = error (float), loss2[1] = #correct (int bits), both accumulated
-// with one atomic per workgroup after a fixed-order in-block reduction.
+// post output layers.  loss2[0] = error (float), loss2[1] = #correct (int bits).  One wave per pattern; the per-pattern
+// term lands in rowstat[N] = {log p_target, correct} -- what the softmax forward pass leaves there for its own rows -- and
+// is summed in a fixed order by rowstat_reduce_kernel: reproducible, no float atomics (round 6; before: one atomic per
+// workgroup, in arrival order).
 // ---------------------------------------------------------------------------------------------
-__global__ void mcc_rows_kernel(const float *y, const int *tcls, int N, int L, int Lp, float *loss2)
+__global__ void mcc_rows_kernel(const float *y, const int *tcls, int N, int L, int Lp, float2 *rowstat)
 {
-    __shared__ float sl[4]; __shared__ int sc[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float lsum = 0.f; int csum = 0;
     for (long row = (long)blockIdx.x * 4 + wv; row < N; row += (long)gridDim.x * 4) {
         const int tc = tcls[row];
-        if (tc < 0) continue;                                     // MulticlassClassificationLayer.cu:61-62
+        if (tc < 0) { if (lane == 0) rowstat[row] = make_float2(0.f, 0.f); continue; }   // MulticlassClassificationLayer.cu:61-62
         const float *r = y + row * Lp;
         // CountCorrectClassificationsFn :89-99: first strictly greater value wins, start (0, class 0)
         float best = 0.f; int bi = 0;
@@ -1077,26 +1147,15 @@ __global__ void mcc_rows_kernel(const float *y, const int *tcls, int N, int L, i
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
         if (best <= 0.f) bi = 0;
-        if (lane == 0) {
-            lsum += logf(fmaxf(NL_MIN, r[tc]));                   // :65-66
-            csum += (bi == tc) ? 1 : 0;
-        }
-    }
-    if (lane == 0) { sl[wv] = lsum; sc[wv] = csum; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = (sl[0] + sl[1]) + (sl[2] + sl[3]);
-        int c = sc[0] + sc[1] + sc[2] + sc[3];
-        atomicAdd(&loss2[0], -t);                                 // calculateError returns -sum, :212
-        atomicAdd((int *)&loss2[1], c);
+        if (lane == 0) rowstat[row] = make_float2(logf(fmaxf(NL_MIN, r[tc])), (bi == tc) ? 1.f : 0.f);   // :65-66
     }
 }
-void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2, bool reset)
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2, bool reset, float *rowstat)
 {
-    if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s);
-    if (N <= 0) return;
-    int blocks = (N + 3) / 4; if (blocks > 256) blocks = 256;       // 2 same-address atomics per block: keep them few
-    hipLaunchKernelGGL(mcc_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, loss2);
+    if (N <= 0) { if (reset) (void)hipMemsetAsync(loss2, 0, 2 * sizeof(float), s); return; }
+    int blocks = (N + 3) / 4; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(mcc_rows_kernel, dim3(blocks), dim3(256), 0, s, y, tcls, N, L, Lp, (float2 *)rowstat);
+    launch_rowstat_reduce(s, rowstat, N, loss2, reset);            // calculateError returns -sum, :212
 }
 
 __global__ void mcc_backward_kernel(const float *y, const int *tcls, int N, int L, int Lp, float *err)

@@ -483,7 +483,9 @@ __global__ __launch_bounds__(tn_threads(BM)) void gemm_tn_kernel(GemmTNGroup grp
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * RM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (m >= p.M) continue;
-                atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
+                // deterministic mode: this split's partial goes to its own copy of C, folded in split order afterwards (launch_fold)
+                if (p.ws) p.ws[(long)split * p.M * p.ldc + (long)m * p.ldc + n] = acc[i][j][r];
+                else atomicAdd(&p.C[(long)m * p.ldc + n], acc[i][j][r]);
             }
         }
     }
@@ -494,6 +496,7 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
 {
     using G = TnGeom<PREC, BM, BN>;
     GemmTNGroup grp{};
+    FoldItem fold[TN_GROUP]; int nfold = 0;
     int blocks = 0;
     long all_tiles = 0;
     for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + BM - 1) / BM) * ((gs[i].N + BN - 1) / BN);
@@ -513,12 +516,14 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         int splits = (int)((target + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * G::BK - 1) / (4 * G::BK);
         if (splits > maxsplit) splits = maxsplit;
-        if (splits > cap_atomic) splits = (int)cap_atomic;
+        if (splits > cap_atomic && !g.ws) splits = (int)cap_atomic;
+        if (g.ws && splits > g.ws_splits) splits = g.ws_splits;
         if (splits < 1) splits = 1;
         int kchunk = ((g.K + splits - 1) / splits + G::BK - 1) / G::BK * G::BK;
         splits = (g.K + kchunk - 1) / kchunk;
         grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk;
         blocks += ntiles * splits;
+        if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
     }
     grp.first_block[TN_GROUP] = blocks;
     if (blocks == 0) return;
@@ -529,6 +534,7 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     }
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(G::NT), lds, s, grp);
+    if (nfold) launch_fold(s, fold, nfold);          // deterministic mode: C = the partials of the splits, added in split order
 }
 
 // tile shape of one launch (all products of a group share it)

@@ -192,6 +192,8 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnBigGroup grp)
     // split-K: fp32 atomics (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
     const int fr = lane & 31, fh = lane >> 5;
     const bool whole = m0 + TB_BM <= p.M;
+    // deterministic mode: this split's partial is stored to its own copy of C and folded in split order afterwards (launch_fold)
+    float *const cbase = p.ws ? p.ws + (long)split * p.M * p.ldc : p.C;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fr;
@@ -199,11 +201,14 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnBigGroup grp)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int mb = m0 + wm * 128 + i * 32 + 4 * fh;
-            float *c0 = p.C + (long)mb * p.ldc + n;
+            float *c0 = cbase + (long)mb * p.ldc + n;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int dm = (r & 3) + 8 * (r >> 2);
-                if (whole || mb + dm < p.M) atomicAdd(c0 + (long)dm * p.ldc, acc[i][j][r]);
+                if (whole || mb + dm < p.M) {
+                    if (p.ws) c0[(long)dm * p.ldc] = acc[i][j][r];
+                    else atomicAdd(c0 + (long)dm * p.ldc, acc[i][j][r]);
+                }
             }
         }
     }
@@ -244,6 +249,7 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
     TnBigGroup grp{};
+    FoldItem fold[TB_GROUP]; int nfold = 0;
     long all_tiles = 0;
     for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + TB_BM - 1) / TB_BM) * ((gs[i].N + TB_BN - 1) / TB_BN);
     int blocks = 0;
@@ -258,15 +264,18 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
         const int target = target_env ? target_env : (cu_budget > 0 ? std::min(cu_budget, cus) : cus);
         int splits = (int)std::max(1L, target / all_tiles);
         const long cap_atomic = std::max(1L, (64L << 20) / ((long)g.M * g.N * 4));
-        splits = (int)std::min<long>(splits, cap_atomic);
+        if (!g.ws) splits = (int)std::min<long>(splits, cap_atomic);
+        else splits = std::min(splits, g.ws_splits);
         splits = std::min(splits, std::max(1, g.K / (16 * TB_BK)));
         int kchunk = ((g.K + splits - 1) / splits + TB_BK - 1) / TB_BK * TB_BK;
         splits = (g.K + kchunk - 1) / kchunk;
         grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk; grp.splits[i] = splits;
         blocks += 8 * ((ntiles * splits + 7) / 8);
+        if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
     }
     grp.first_block[TB_GROUP] = blocks;
     hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(blocks), dim3(512), TB_LDS, s, grp);
+    if (nfold) launch_fold(s, fold, nfold);
 }
 
 }  // namespace cn

@@ -57,7 +57,17 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
     const void *B; long ldb;      // [K][N] op
     float *C; long ldc;           // [M][N] fp32, pre-zeroed
     int M, N, K;                  // M, N multiples of 32
+    // deterministic mode (cn_ctx option "deterministic"): split s STORES its partial product to ws + s * M * ldc (same pitch as
+    // C) and a second launch adds the partials IN SPLIT ORDER into C -- the sum over the frames no longer depends on the order in
+    // which workgroups retire (ComputeWeightUpdateFn, LstmLayer.cu:289-512, is one serial sum per weight).  nullptr: fp32 atomics.
+    float *ws; int ws_splits;     // workspace of ws_splits * M * ldc floats; the launcher never cuts K into more splits than that
 };
+constexpr int DET_MAX_SPLITS = 8;
+// dst[r][c] (+)= part[0][r][c] + part[1][r][c] + ... in that order, r < rows, c < cols (partials share dst's pitch `ld`, one every
+// `stride` floats).  accumulate: onto what dst holds (else dst is overwritten); clear: the partials are zeroed behind the read.
+struct FoldItem { float *dst; float *part; long stride; int nparts, rows, cols, ld, accumulate, clear; };
+constexpr int FOLD_MAX = 4;
+void launch_fold(hipStream_t s, const FoldItem *items, int n);
 // `done`: optional event that completes with the kernel itself (hipExtLaunchKernelGGL stop event): a fork point for
 // another stream without a marker packet on this stream (an hipEventRecord between two kernels costs the second one ~7 us)
 void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
@@ -94,6 +104,11 @@ struct LstmRec {
     float *dbias;                 // [dirs][Hp][4] fp32 accumulators (pre-zeroed)
     float *dpeep;                 // [dirs][3][Hp]
     float bias;                   // JSON bias value (scales the bias gradient)
+    // deterministic mode: workgroup b of the backward kernel STORES its bias / peephole sums into slot b of gpart (a slot: dbias's
+    // [dirs][Hp][4] then dpeep's [dirs][3][Hp], 7 * dirs * Hp floats; entries a workgroup does not own stay zero) instead of adding
+    // them to dbias / dpeep with atomics; the launcher writes the grid it used to *det_grid (<= gpart_slots or it refuses) and the
+    // caller folds the slots in workgroup order (launch_fold, clear = 1).  nullptr: atomics.
+    float *gpart; int gpart_slots; int *det_grid;
     int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
     // multi-CU cluster kernels (cn_lstm_cluster.hip)
     unsigned long long *xch;      // exchange granules (nullable: cluster path off), zeroed at allocation
@@ -105,6 +120,9 @@ struct LstmRec {
     char *kname;                  // nullable, CN_KNAME_LEN bytes: the launcher writes the name of the kernel it instantiated
 };
 constexpr int CN_KNAME_LEN = 64;
+// every launcher of a recurrent kernel reports its grid (deterministic mode folds that many slots of gpart) and refuses one
+// the slots do not cover
+void lstm_note_grid(const LstmRec &p, int grid);
 // time steps of zeros the library keeps in front of and behind acts / cell / th / err / pat of an LSTM layer (cn_api.cpp:
 // dalloc_guarded): a recurrent loop may load up to this many steps outside [0, T)
 constexpr int CN_GUARD_STEPS = 6;
@@ -165,7 +183,10 @@ void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P,
 // delta = act'(y) * err (in place on err, all N slots: FeedForwardLayer.cu:72-79), op copy for the GEMMs
 void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *err, void *delta_op, int N, int L, int Lp);
 // column sums of delta over the N slots (FeedForwardLayer.cu:82-102): colsum[j] += sum_n err[n][j]
-void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum);
+// det_part (nullable; deterministic mode): det_colsum_part_floats(Lp) floats; the workgroups store their partial sums there and a
+// second launch adds them in workgroup order
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part = nullptr);
+size_t det_colsum_part_floats(int Lp);
 // softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
 // optional: tcls + rowstat[N][2] = {log p_target, argmax == target} for the multiclass loss
 // smstat (nullable, wide rows only: softmax_fwd_can_be_lazy): the LAZY form -- y keeps the logits, smstat[N][2] = {offset, sum};
@@ -187,7 +208,7 @@ void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N
 // `loss_part`: 16 x {float sum, int count} + one arrival counter (zero between launches) for the sixteen reduction workgroups
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr,
-                            const float *smstat = nullptr, bool fast = false, float *colpart = nullptr);
+                            const float *smstat = nullptr, bool fast = false, float *colpart = nullptr, float *det_part = nullptr);
 bool softmax_mcc_bwd_takes_loss(int Lp);
 // `colpart` (nullable; narrow rows): softmax_mcc_bwd_colpart_floats() zeroed floats the launch spreads its column-sum atomics over
 // (replicas folded into colsum by the last workgroup; zero again when the launch ends)
@@ -195,7 +216,8 @@ size_t softmax_mcc_bwd_colpart_floats();
 // e_i <- y_i (e_i - sum_j y_j e_j) (SoftmaxLayer.cu:317-349), dummies skipped
 void launch_softmax_bwd(hipStream_t s, const float *y, float *err, const char *pat, int N, int L, int Lp);
 // multiclass_classification: loss/#correct reduction and error injection
-void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/, bool reset);
+// rowstat: [N][2] scratch the per-pattern terms pass through (summed in a fixed order: launch_rowstat_reduce)
+void launch_mcc_eval(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *loss2 /*[2]*/, bool reset, float *rowstat);
 void launch_mcc_backward(hipStream_t s, const float *y, const int *tcls, int N, int L, int Lp, float *err);
 // sse
 // UpdateWeightFn over a flat range
@@ -214,6 +236,11 @@ void ipc_comm_mark_failed(IpcComm *c);
 void ipc_allreduce(IpcComm *c, float *buf, size_t n, hipStream_t st, size_t capacity_hint = 0);
 bool ipc_comm_is_p2p(const IpcComm *c);
 void ipc_comm_check(IpcComm *c, hipStream_t st);       // p2p: raise if a poll of the communicator timed out (synchronises st)
+void ipc_comm_check_fast(IpcComm *c);                  // p2p: the same from the host-mapped word the kernel sets (no synchronisation)
+// p2p: allocate and map the regions and run the first-contact self-check (flags and staged lines through every peer's mapping,
+// both forms of the exchange, sums verified on the host).  False: some rank saw a wrong sum or a time-out -- every rank gets the
+// same answer -- and `rccl_id` (CN_COMM_ID_BYTES) holds what rank 0's `make_id` produced: the caller fails over to RCCL.
+bool ipc_comm_p2p_selfcheck(IpcComm *c, hipStream_t st, void (*make_id)(char *), char *rccl_id);
 void ipc_allreduce_loss(IpcComm *c, float *err, int *correct);
 // ---- CN_COMM_BACKEND=p2p: one stream-ordered kernel per bucket over peer-mapped regions (cn_comm_p2p.hip) -----------
 constexpr int P2P_GROUPS = 64, P2P_THREADS = 256;
@@ -225,6 +252,7 @@ struct P2pArgs {
     unsigned long long *flags[8];              // flag words, per rank
     int me, world, two_phase;
     unsigned long long seq, timeout_ticks;     // exchange counter (from 1); poll deadline in ticks of the 100 MHz clock
+    unsigned long long *host_failed;           // host-mapped word: set when a wait of this exchange ended without its flag
 };
 void launch_p2p_allreduce(hipStream_t s, const P2pArgs &a);
 void launch_sgd(hipStream_t s, float *w, const float *wu, float *wd, size_t n, float lr, float mom, hipEvent_t done = nullptr);

@@ -34,6 +34,8 @@
 //     flight.)
 //   * fw/bw halves are written straight into the interleaved [N][2*Hp] layer output.
 #include "cn_internal.h"
+#include <stdexcept>
+#include <string>
 #include "cn_lstm_device.h"
 
 #include <cstdio>
@@ -879,10 +881,7 @@ __global__ __launch_bounds__(HP ? HP * 4 / UG : 1024) void lstm_bwd_kernel(LstmR
             v[i] += __shfl_xor(v[i], 32);
         }
         if (q == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * Hp + unit[u]) * 4 + g], p.bias * v[g]);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * Hp + unit[u]], v[4 + g]);
+            lstm_grad_sums_out(p, Hp, d, unit[u], v);
         }
     }
 }
@@ -908,8 +907,16 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t d
     // 229 us per backward launch in the step timeline); the GEMMs lose 26 of 256 CUs instead.
     size_t lds_claim = lds;
     if (p.dirs * nsg <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    lstm_note_grid(p, p.dirs * nsg);
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UG, RPL);
+}
+
+void lstm_note_grid(const LstmRec &p, int grid)
+{
+    if (p.det_grid) *p.det_grid = grid;
+    if (p.gpart && grid > p.gpart_slots)
+        throw std::runtime_error("deterministic mode: a recurrent kernel of " + std::to_string(grid) + " workgroups, " + std::to_string(p.gpart_slots) + " partial-sum slots");
 }
 
 template <int PREC, bool BWD, int HP, int UG>

@@ -894,10 +894,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
     if (q == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1082,10 +1079,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_psum_kernel(LstmRec 
 #pragma unroll
     for (int i = 0; i < 7; ++i) { v[i] += __shfl_xor(v[i], 16); v[i] += __shfl_xor(v[i], 32); }
     if (q == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1264,10 +1258,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2c_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
     if (sq == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1400,10 +1391,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2c_asm_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
     if (sq == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1432,6 +1420,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
             static DeviceOnce attr_once_p;
             if (attr_once_p.first()) (void)hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             const size_t lds_p = 2 * 16 * (size_t)lds_pitch(4 * UPC);
+            lstm_note_grid(p, grid);
             hipLaunchKernelGGL(kp, dim3(grid), dim3(NT), lds_p, s, p);
             if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_bwd_cluster_psum_kernel<%d,%d,%d>", PREC, HP, UPC);
             return;
@@ -1450,6 +1439,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     int helpers = 0;
     const bool want = getenv("CN_CLUSTER_HELPERS") ? true : (getenv("CN_NO_CLUSTER_HELPERS") ? false : CS == 8);
     if (BWD && want && grid + (nclusters + 7) / 8 * 8 <= p.cluster_cus) helpers = (nclusters + 7) / 8 * 8;
+    lstm_note_grid(p, grid);                       // (the helper workgroups form no sums)
     hipLaunchKernelGGL(kern, dim3(grid + helpers), dim3(NT), lds, s, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_cluster_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UPC, RPL);
 }
@@ -1574,6 +1564,7 @@ static void launch_s2c(hipStream_t s, const LstmRec &p)
     const bool hand = !getenv("CN_S2C");
     // (one workgroup per CU: each claims the CU's whole LDS so that no gradient-GEMM workgroup is placed beside it, cn_lstm.hip)
     size_t lds_claim = getenv("CN_NO_LDS_CLAIM") ? lds : (size_t)(160 * 1024 - 1024);
+    lstm_note_grid(p, grid);
     hipLaunchKernelGGL(hand ? lstm_bwd_s2c_asm_kernel : lstm_bwd_s2c_kernel, dim3(grid), dim3(256), lds_claim < lds ? lds : lds_claim, s, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, hand ? "lstm_bwd_s2c_asm_kernel" : "lstm_bwd_s2c_kernel");
 }

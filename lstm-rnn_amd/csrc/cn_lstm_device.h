@@ -132,6 +132,26 @@ __device__ __forceinline__ void sp_load_split(const float *p, u32x8 &hi, u32x8 &
     hi = sp_join(h0, h1); lo = sp_join(l0, l1);
 }
 
+// The bias / peephole sums a backward workgroup has formed over its time steps and sequences for unit `unit` of direction d
+// (v[0..3]: gate deltas n, i, f, o; v[4..6]: peephole terms i, f, o) leave for the gradient: one atomic per (gate, unit) and
+// workgroup, or -- deterministic mode -- one plain store into the workgroup's slot of p.gpart (LstmRec, cn_internal.h).
+template <typename REC>
+__device__ __forceinline__ void lstm_grad_sums_out(const REC &p, int HP, int d, int unit, const float (&v)[7])
+{
+    if (p.gpart) {
+        float *slot = p.gpart + (size_t)blockIdx.x * (size_t)(7 * p.dirs * HP);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) slot[(d * HP + unit) * 4 + g] = p.bias * v[g];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) slot[4 * p.dirs * HP + (d * 3 + g) * HP + unit] = v[4 + g];
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+}
+
 // workgroup barrier that orders LDS traffic only: global prefetch loads and the activation stores
 // stay in flight across it (a __syncthreads() would drain vmcnt every step)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

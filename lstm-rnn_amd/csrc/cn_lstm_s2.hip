@@ -1160,10 +1160,7 @@ __global__ __launch_bounds__(HP * 2) void lstm_bwd_s2_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
     if (sq == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1508,10 +1505,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_asm_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
     if (sq == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1759,10 +1753,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_s2_x3_asm_kernel(LstmRec p)
 #pragma unroll
     for (int i = 0; i < 7; ++i) v[i] += __shfl_xor(v[i], 16);
     if (sq == 0) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(&p.dbias[(d * HP + unit) * 4 + g], p.bias * v[g]);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) atomicAdd(&p.dpeep[(d * 3 + g) * HP + unit], v[4 + g]);
+        lstm_grad_sums_out(p, HP, d, unit, v);
     }
 }
 
@@ -1817,6 +1808,7 @@ void launch_lstm_s2w(hipStream_t s, bool bwd, const LstmRec &p, hipEvent_t done)
     }
     const bool hand = !getenv("CN_NO_S2W_ASM");
     const size_t lds = 2 * 5 * (size_t)lds_pitch(256) + 64 + 4 * (size_t)(hand ? S2W_STREAM_COUNT * 2048 : 32768);
+    lstm_note_grid(p, p.dirs * (p.PS / 2));
     hipExtLaunchKernelGGL(hand ? lstm_fwd_s2w_asm_kernel : lstm_fwd_s2w_kernel, dim3(p.dirs * (p.PS / 2)), dim3(256), lds, s, nullptr, done, 0, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, hand ? "lstm_fwd_s2w_asm_kernel" : "lstm_fwd_s2w_kernel");
 }
@@ -1833,6 +1825,7 @@ static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
             const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
             size_t lds_claim = lds;
             if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+            lstm_note_grid(p, p.dirs * (p.PS / 2));
             hipExtLaunchKernelGGL(akern, dim3(p.dirs * (p.PS / 2)), dim3(256), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
             if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2%s_asm_kernel", BWD ? "bwd" : "fwd", PREC == P_X3 ? "_x3" : "");
             return;
@@ -1845,6 +1838,7 @@ static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
     // claim the CU's whole LDS so that no workgroup of a concurrently running kernel is placed beside it (cn_lstm.hip)
     size_t lds_claim = lds;
     if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    lstm_note_grid(p, p.dirs * (p.PS / 2));
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * (p.PS / 2)), dim3(HP * 2), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2_kernel<%d,%d>", BWD ? "bwd" : "fwd", PREC, HP);
 }

@@ -95,7 +95,7 @@ class Layer:
 
 class NeuralNetwork:
     def __init__(self, layers, weights=None, parallel_sequences=1, max_seq_length=1,
-                 precision=B.PREC_F32, device=0, stream=None, seed=None):
+                 precision=B.PREC_F32, device=0, stream=None, seed=None, deterministic=None):
         self.lib = B.load_library()
         self.parallel_sequences, self.max_seq_length = int(parallel_sequences), int(max_seq_length)
         self.PS = self.parallel_sequences
@@ -104,6 +104,8 @@ class NeuralNetwork:
         ctx = C.c_void_p()
         B.check(self.lib.cn_ctx_create(device, precision, stream, C.byref(ctx)))
         self.ctx = ctx
+        if deterministic is not None:                 # None: the library's default (on in the parity modes, off for bf16)
+            self.set_option("deterministic", 1 if deterministic else 0)
         self.layers = []
         self.T = self.Tmin = self.N = 0
         try:
@@ -275,6 +277,15 @@ class NeuralNetwork:
                 w.wait()            # orders the context's stream behind the reduction
 
     # -- data-parallel training through the library's own RCCL communicator -----------------------
+    def set_option(self, name, value):
+        """cn_ctx_set_option: named integer options of the context ("deterministic": fixed-order gradient sums)."""
+        B.check(self.lib.cn_ctx_set_option(self.ctx, name.encode(), int(value)), self.ctx)
+
+    def get_option(self, name):
+        v = C.c_int()
+        B.check(self.lib.cn_ctx_get_option(self.ctx, name.encode(), C.byref(v)), self.ctx)
+        return v.value
+
     def comm_unique_id(self):
         """Rank 0: 128 rendezvous bytes (ncclGetUniqueId) to hand to every rank out of band."""
         buf = C.create_string_buffer(B.COMM_ID_BYTES)

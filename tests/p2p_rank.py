@@ -1,7 +1,11 @@
 """One rank of tests/test_gpu_parallel.py::test_p2p_exchange_*: python p2p_rank.py <rank> <world> <dir> <mode>.
 All ranks share device 0 (CN_COMM_BACKEND=p2p runs with shared devices).  Writes <dir>/rank<r>.npz:
   local_k / reduced_k: the weightUpdates arena before / after exchange k (per-layer exchanges, then one flat exchange).
-mode "absent": the LAST rank stays away from the final exchange; the others report what cn_loss_read_global raised."""
+mode "absent": the LAST rank stays away from the final exchange; the others report what cn_loss_read_global raised, what the
+  update that follows raised and what the gradient of the failed exchange holds.
+mode "soak:<iters>": <iters> rounds of three per-layer exchanges back to back (bucket sizes that alternate between the one-shot and
+  the two-phase form under CN_P2P_ONESHOT_MAX) on gradients with a known integer answer, every sum checked on the device.
+mode "failover": CN_P2P_SELFCHECK_FAIL is set -- the communicator must come up as "rccl" and still reduce (world 1)."""
 import os
 import sys
 import time
@@ -39,7 +43,19 @@ def main():
                 time.sleep(0.05)
             uid = open(idfile, "rb").read()
         net.comm_init(uid, rank, world)
+        if mode == "failover":
+            assert net.comm_backend()[0] == "rccl", net.comm_backend()
+            net.load_sequences(frac); net.compute_forward_pass(); net.loss_accumulate(); net.compute_backward_pass()
+            before = np.concatenate([l.weight_updates().reshape(-1) for l in net.trainable_layers()])
+            net.allreduce_grads(net.trainable_layers())
+            after = np.concatenate([l.weight_updates().reshape(-1) for l in net.trainable_layers()])
+            np.savez(os.path.join(d, "rank%d.npz" % rank), before=before, after=after, backend=np.array(net.comm_backend()[0]))
+            return
         assert net.comm_backend()[0] == "p2p", net.comm_backend()
+        if mode.startswith("soak"):
+            soak(pkg, net, rank, world, int(mode.split(":")[1]))
+            np.savez(os.path.join(d, "rank%d.npz" % rank), exchanges=np.array(net.comm_backend()[1]))
+            return
 
         def arena():
             return np.concatenate([l.weight_updates().reshape(-1) for l in net.trainable_layers()])
@@ -64,11 +80,57 @@ def main():
                 out["raised"] = np.array("nothing")
             except pkg.CurrenntHipError as e:
                 out["raised"] = np.array(str(e))
+            out["poisoned"] = arena()                            # the exchange that failed left NaN, not a partial sum
+            try:
+                net.update_weights(1e-3, 0.9)                    # ... and no update goes on top of it
+                out["update_raised"] = np.array("nothing")
+            except pkg.CurrenntHipError as e:
+                out["update_raised"] = np.array(str(e))
             np.savez(os.path.join(d, "rank%d.npz" % rank), **out)
             os._exit(0)                                          # (the communicator is dead: no collective teardown)
         err, correct = net.loss_read_global()
         out["loss"] = np.array([err, correct])
     np.savez(os.path.join(d, "rank%d.npz" % rank), **out)
+
+
+def soak(pkg, net, rank, world, iters):
+    """Gradients with small-integer entries that depend on (element, exchange, rank): the sum over the ranks is exact in float32
+    whatever the order, so every element of every exchange is checked bit for bit."""
+    import torch
+    layers = net.trainable_layers()
+    wptr, gptr, dptr, count = net.param_arena()
+    g = torch.as_tensor(pkg.parallel.DeviceArray(gptr, count), device="cuda")
+    idx = torch.arange(count, device="cuda", dtype=torch.int64)
+    # where each layer's weightUpdates sit in the arena (4-float padding between layers stays out of the exchanges)
+    spans, off = [], 0
+    for l in layers:
+        n = l.weight_updates().size
+        spans.append((off, n)); off += n + (-n) % 4
+    mask = torch.zeros(count, dtype=torch.bool, device="cuda")
+    for o, n in spans:
+        mask[o:o + n] = True
+
+    def pattern(k, r):
+        return (((idx * 7 + k * 13 + r * 31) % 257) - 128).to(torch.float32)
+    for k in range(iters):
+        g.copy_(pattern(k, rank))
+        torch.cuda.synchronize()
+        if k % 3 == 2:
+            net.allreduce_grads(None)                            # the flat arena (padding included) in one bucket
+            full = True
+        else:
+            net.allreduce_grads(layers if k % 2 == 0 else layers[::-1])   # three buckets back to back, both orders
+            full = False
+        net.synchronize()
+        want = pattern(k, 0)
+        for r in range(1, world):
+            want = want + pattern(k, r)
+        got = g.clone()
+        ok = torch.equal(got, want) if full else torch.equal(got[mask], want[mask])
+        if not ok:
+            bad = torch.nonzero((got != want) & (mask if not full else torch.ones_like(mask)))[:5].reshape(-1).tolist()
+            raise SystemExit("rank %d: exchange round %d: wrong sums at arena elements %s: got %s, want %s"
+                             % (rank, k, bad, got[bad].tolist(), want[bad].tolist()))
 
 
 if __name__ == "__main__":

@@ -198,6 +198,51 @@ def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_co
         assert any("s_waitcnt vmcnt(0)" in body[k] for k in range(adds[-1], barrier)), body[adds[-1]:barrier + 1]
 
 
+def test_p2p_exchange_drains_every_wave_before_each_flag_store(tmp_path):
+    """p2p_allreduce_kernel (cn_comm_p2p.hip) hands staged gradients to its peers through flag words in THEIR regions: READY
+    (my staging half is written), REDUCED (my slice of it holds the sums), DONE (my reads of the peers' halves have returned).
+    Each hand-off is only sound when every wave of the workgroup has had its own stores acknowledged (loads returned) before
+    the barrier in front of the flag store.  A workgroup-scope release fence compiles to no vmcnt wait on gfx950 (round 5
+    shipped that), so the wait is written in asm and the ISA is read here: exactly three asm `s_waitcnt vmcnt(0)`, each one in
+    straight-line code in front of an `s_barrier`, the flag store (`global_store_dwordx2 ... sc0 sc1`) the first store behind
+    that barrier, and the staging stores of the copy loop / the reduced slice in front of the drain."""
+    import shutil, subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "p2p.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(out),
+                    os.path.join(root, "lstm-rnn_amd", "csrc", "cn_comm_p2p.hip")], check=True, capture_output=True)
+    lines = out.read_text().splitlines()
+    st = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*p2p_allreduce_kernel\w*:", l))
+    end = next(i for i in range(st, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = [l.strip() for l in lines[st:end]]
+    drains = [k + 1 for k, l in enumerate(body[:-2]) if l.startswith(";;#ASMSTART") and body[k + 1] == "s_waitcnt vmcnt(0)" and body[k + 2].startswith(";;#ASMEND")]
+    assert len(drains) == 3, drains                          # READY, REDUCED, DONE
+    is_mem = lambda l: l.startswith(("global_", "buffer_", "flat_", "scratch_"))
+    is_jump = lambda l: l.startswith(("s_branch", "s_cbranch", "s_endpgm")) or re.match(r"^\.?\w+:", l)
+    for d in drains:
+        bar = next(k for k in range(d, len(body)) if body[k] == "s_barrier")
+        between = body[d + 1:bar]
+        assert len(between) <= 6 and not any(is_mem(l) or is_jump(l) for l in between), between
+        # behind the barrier: the flag store is the first store (the flag pointer a.flags[t] is a load from the argument block)
+        first_store = next(l for l in body[bar + 1:] if l.startswith("global_store") or l.startswith("global_atomic"))
+        assert re.match(r"global_store_dwordx2 .* sc0 sc1$", first_store), first_store
+    # READY: the copy loop's staging stores sit in front of the first drain; REDUCED: the reduced slice's between drains 0 and 1
+    staged = [k for k, l in enumerate(body) if re.match(r"global_store_dwordx2 .* sc0 sc1$", l)]
+    assert any(k < drains[0] for k in staged)
+    assert any(drains[0] < k < drains[1] for k in staged)
+    # no barrier in the kernel is followed by a flag store without a drain directly in front of it: every s_barrier whose next
+    # memory instruction (straight line) is an sc0 sc1 store must be one of the three above
+    for k, l in enumerate(body):
+        if l != "s_barrier":
+            continue
+        nxt = next((m for m in body[k + 1:] if is_mem(m) or is_jump(m)), "")
+        if re.match(r"global_store_dwordx2 .* sc0 sc1$", nxt):
+            assert any(d < k <= d + 7 for d in drains), body[max(0, k - 8):k + 4]
+
+
 def test_generated_loop_of_the_two_cu_backward_kernel_is_in_sync_with_its_generator():
     """lstm-rnn_amd/csrc/cn_lstm_s2c_loop.inc is the output of tools/gen_s2c_loop.py (the step of lstm_bwd_s2c_asm_kernel as a
     schedule: poll, own K half, exchange, partner K half, block errors; the timing build's text beside it)."""

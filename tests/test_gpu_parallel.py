@@ -207,6 +207,34 @@ def test_p2p_exchange_times_out_when_a_peer_stays_away(pkg, tmp_path):
     for r in (0, 1):
         msg = str(res[r]["raised"])
         assert "p2p communicator: rank %d of 3 waited more than 2 s" % r in msg, msg
+        # the exchange that gave up did not leave a partial sum behind: its whole gradient is NaN, and the update that follows
+        # raises instead of applying it (cn_sgd_update_all reads the host-mapped failure word)
+        assert np.isnan(res[r]["poisoned"]).all()
+        assert "p2p communicator: rank %d of 3 waited more than 2 s" % r in str(res[r]["update_raised"]), res[r]["update_raised"]
+
+
+def test_p2p_soak_eight_ranks_alternating_forms(pkg, tmp_path):
+    """8 live ranks, 900 rounds = 2 100 exchanges: per-layer buckets back to back in both orders (CN_P2P_ONESHOT_MAX=3000 sends the
+    two LSTM layers through reduce-scatter + all-gather and the softmax layer through the one-shot form, so the forms alternate
+    inside a round) and every third round the flat arena in one bucket; the gradients are small integers that depend on
+    (element, round, rank), so EVERY element of EVERY exchange has one exact answer.  A flag that overtakes a staging store, a
+    staging half reused too early or a slot index off by one shows here as a wrong element (tests/p2p_rank.py::soak)."""
+    res = _run_p2p_ranks(tmp_path, 8, "soak:900", {"CN_COMM_IPC_TIMEOUT": "60", "CN_P2P_ONESHOT_MAX": "3000"})
+    rounds = 900
+    per_round = [3, 3, 1]
+    want = sum(per_round[k % 3] for k in range(rounds))
+    assert want >= 2000
+    for r in range(8):
+        assert int(res[r]["exchanges"]) == want
+
+
+def test_p2p_first_contact_failure_falls_back_to_rccl(pkg, tmp_path):
+    """cn_comm_init with CN_COMM_BACKEND=p2p runs a self-check through every peer mapping (both forms of the exchange on a bucket
+    with a known answer).  A rank whose check fails (here: injected) makes EVERY rank abandon the backend: the communicator that
+    comes up is RCCL, with a message, and it reduces.  (World 1: RCCL takes one rank per device, the box has one.)"""
+    res = _run_p2p_ranks(tmp_path, 1, "failover", {"CN_COMM_IPC_TIMEOUT": "30", "CN_P2P_SELFCHECK_FAIL": "0"})
+    assert str(res[0]["backend"]) == "rccl"
+    assert np.array_equal(res[0]["before"], res[0]["after"]) and np.abs(res[0]["before"]).max() > 0
 
 
 @pytest.mark.parametrize("backend", ["gloo", "ipc", "p2p", "p2p-two-phase"])
