@@ -114,6 +114,56 @@ def rec_algorithmic(hidden):
     return 44.0 * units, 64.0 * units, fl
 
 
+def gemm_products(wl, precision):
+    """The N-wide products of one training step, per class, as (name, flop per frame, algorithmic HBM bytes per frame): what a
+    product must move when every operand is read once and every output written once (weights, read once per launch, are noise
+    beside N = 15 000 frames and left out).  `e` = bytes of an operand element, outputs that the NEXT kernel consumes as fp32
+    (gate pre-activations, outputErrors, logits) are 4 bytes.  Call sites: LstmLayer.cu:774-785 (K1), :996-1006 (K8),
+    :1038-1043 (K9), FeedForwardLayer.cu:148-206."""
+    e = 2.0 if precision == "bf16" else 4.0
+    wide, grad = [], []
+    prev, first = wl["P"], True
+    for i, (t, size) in enumerate(wl["hidden"]):
+        dirs = 2 if t == "blstm" else 1
+        H = size // dirs
+        R = dirs * 4 * H
+        wide.append(("L%d.K1 x->preacts" % (i + 1), 2.0 * R * prev, e * prev + 4.0 * R))
+        if not first:
+            wide.append(("L%d.K8 delta->err" % (i + 1), 2.0 * R * prev, e * R + 4.0 * prev))
+        grad.append(("L%d.K9 dWin" % (i + 1), 2.0 * R * prev, e * (R + prev)))
+        grad.append(("L%d.K9 dWrec" % (i + 1), 2.0 * R * H, e * (R + size)))
+        prev, first = size, False
+    C = wl["C"]
+    wide.append(("out.fwd", 2.0 * C * prev, e * prev + 4.0 * C))
+    wide.append(("out.K8", 2.0 * C * prev, e * C + 4.0 * prev))
+    grad.append(("out.dW", 2.0 * C * prev, e * (C + prev)))
+    return {"gemm_wide": wide, "gemm_grad": grad}
+
+
+def gemm_roofline(wl, precision, tm, frames, steps):
+    """`roofline_gemm`: per GEMM class the device time of the event-timed pass against the class's ATTAINABLE time, the sum over
+    its products of max(flop / MFMA peak, algorithmic bytes / HBM peak) -- the gate GEMMs of these nets are bound by their fp32
+    outputs, not by the matrix cores, so flop / 2.5 PF alone reads 7 % for ever."""
+    peak_fl = PEAK_MFMA_TFLOPS.get(precision, 2500.0 / 3) * 1e12
+    out = {}
+    for cls, prods in gemm_products(wl, precision).items():
+        ms = tm[cls][0]
+        if not ms:
+            continue
+        roof_s, fl, by, hbm_bound = 0.0, 0.0, 0.0, 0
+        worst = None
+        for name, f, b in prods:
+            t_f, t_b = f * frames / peak_fl, b * frames / (PEAK_HBM_GBS * 1e9)
+            roof_s += max(t_f, t_b); fl += f * frames; by += b * frames
+            hbm_bound += t_b >= t_f
+        out[cls] = {"achieved_ms_per_step": ms / steps, "roof_ms_per_step": 1e3 * roof_s / steps, "frac": 1e3 * roof_s / ms,
+                    "tflops": fl / (ms * 1e-3) / 1e12, "algorithmic_GBps": by / (ms * 1e-3) / 1e9,
+                    "products": len(prods), "products_hbm_bound": int(hbm_bound), "launches": tm[cls][1]}
+    out["note"] = ("roof = sum over the class's products of max(flop / %.0f TFLOP/s, algorithmic bytes / %.0f GB/s); frac = roof / achieved device "
+                   "time (hipEvents on the launching stream); gemm_grad runs on side streams beside the recurrent kernels" % (peak_fl / 1e12, PEAK_HBM_GBS))
+    return out
+
+
 def spawn_ranks(n, argv):
     """One process per GPU through torch.distributed.run on 127.0.0.1; returns the launcher's exit code."""
     import socket
@@ -190,6 +240,7 @@ def roofline_records(res, wl, workload, PS, precision, value):
                             "recurrent_tflops": fl_rec * 2 * fr / (pair_ms * 1e-3) / 1e12 if pair_ms else None,
                             "whole_step_tflops": fpf * value / 1e12, "peak": PEAK_MFMA_TFLOPS.get(precision, 2500.0 / 3),
                             "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
+    out["roofline_gemm"] = gemm_roofline(wl, precision, tm, fr, res["timing_steps"])
     return out
 
 
@@ -312,7 +363,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return [float(x) for x in t]
 
-    def run_workload(name, steps, warmup, precision, roofline_pass=False, host_pass=False, min_seconds=0.5):
+    def run_workload(name, steps, warmup, precision, roofline_pass=False, host_pass=False, min_seconds=0.5, deterministic=None):
         """-> (result dict, workload): `steps` timed steps per repetition (median of enough repetitions for min_seconds)"""
         wl = WORKLOADS[name]
         PS = args.parallel_sequences if name == args.workload else wl.get("PS", 50)
@@ -325,7 +376,8 @@ def main():
         nfrac = 4
         fracs = [synth_fraction(pkg, rng, PS, P, C, tmin, tmax) for _ in range(nfrac)]
         # (the library runs on a stream of its own; net.torch_stream() is that stream for torch ordering)
-        net = pkg.NeuralNetwork(layers, weights, PS, tmax, precision=PRECISIONS[precision], device=device_index)
+        net = pkg.NeuralNetwork(layers, weights, PS, tmax, precision=PRECISIONS[precision], device=device_index, deterministic=deterministic)
+        det_on = bool(net.get_option("deterministic"))
         if native_comm:
             uid = [net.comm_unique_id() if rank == 0 else None]
             if world > 1:
@@ -399,7 +451,7 @@ def main():
         res = {"frames": allsum([float(frames)])[0], "seconds": float(np.median(dts)), "repeats": reps,
                "seconds_min": float(min(dts)), "seconds_max": float(max(dts)), "timed_total_s": float(sum(dts)),
                "weights": int(count), "PS": PS, "tmin": tmin, "tmax": tmax,
-               "kernels": (net.recurrent_kernel(False), net.recurrent_kernel(True))}
+               "kernels": (net.recurrent_kernel(False), net.recurrent_kernel(True)), "deterministic": det_on}
         # epoch sums: over all ranks through the library's communicator when it is bound (cn_loss_read_global), so that the
         # record compares with a single-process run over the union of the ranks' fractions
         err_sum, correct = net.loss_read_global() if native_comm else net.loss_read()
@@ -453,21 +505,28 @@ def main():
                      + ["timit_3x250_blstm_H125:f32"])
         # BASELINE.json configs[3] and configs[4] as written (one GPU's share of the 8-GPU configs: PS per GPU as in WORKLOADS)
         also_spec += ["lvcsr_4x512_blstm_8000", "longutt_5x1024_blstm"]
+        # ... and at fp32 tolerance (every config carries an at-tolerance figure beside its bf16 one)
+        if "bf16x3" in PRECISIONS:
+            also_spec += ["lvcsr_4x512_blstm_8000:bf16x3", "longutt_5x1024_blstm:bf16x3"]
+        # the headline with the gradient sums in a fixed order (option "deterministic", off by default in bf16): what reproducible costs
+        also_spec += ["timit_3x250_blstm_H125:bf16:det"]
     also = {}
     for spec in also_spec:
         name, _, pr = spec.partition(":")
+        pr, _, opt = pr.partition(":")
         pr = pr or args.precision
         big = name in ("lvcsr_4x512_blstm_8000", "longutt_5x1024_blstm")
         st2, wu2 = (min(args.steps, 5), min(args.warmup, 2)) if big else (args.steps, args.warmup)
-        roof2 = big or spec == "timit_3x500_blstm_H250"      # (reading B: the other reading of the headline config gets its roofline too)
-        r2, wl2 = run_workload(name, st2, wu2, pr, roofline_pass=roof2, min_seconds=0 if big else min(min_seconds, 0.25))
+        roof2 = (big and pr == args.precision) or spec == "timit_3x500_blstm_H250"      # (reading B: the other reading of the headline config gets its roofline too)
+        r2, wl2 = run_workload(name, st2, wu2, pr, roofline_pass=roof2, min_seconds=0 if big else min(min_seconds, 0.25),
+                               deterministic=True if opt == "det" else None)
         v2 = r2["frames"] / r2["seconds"]
         also[spec] = {"value": v2, "unit": "frames/s", "dtype": pr, "ms_per_step": 1e3 * r2["seconds"] / st2, "steps": st2, "repeats": r2["repeats"],
-                      "parallel_sequences": r2["PS"], "seq_len": "U[%d,%d]" % (r2["tmin"], r2["tmax"])}
+                      "parallel_sequences": r2["PS"], "seq_len": "U[%d,%d]" % (r2["tmin"], r2["tmax"]), "deterministic": r2["deterministic"]}
         if roof2 and "timing" in r2:
             rr = roofline_records(r2, wl2, name, r2["PS"], pr, v2)
             also[spec].update({"roofline": rr["roofline"], "roofline_other": rr["roofline_other"], "roofline_pair": rr["roofline_pair"],
-                               "roofline_mfma": rr["roofline_mfma"]})
+                               "roofline_mfma": rr["roofline_mfma"], "roofline_gemm": rr["roofline_gemm"]})
 
     if rank == 0:
         exch = "none"
@@ -491,6 +550,12 @@ def main():
                        "ms_per_step_min": 1e3 * res["seconds_min"] / args.steps, "ms_per_step_max": 1e3 * res["seconds_max"] / args.steps,
                        "timed_total_s": res["timed_total_s"]},
         }
+        out["config"]["deterministic_sums"] = res["deterministic"]
+        if "timit_3x250_blstm_H125:bf16:det" in also and args.precision == "bf16":
+            dv = also["timit_3x250_blstm_H125:bf16:det"]["value"]
+            out["deterministic"] = {"headline_default": res["deterministic"], "value_with_fixed_order_sums": dv, "cost": 1.0 - dv / value,
+                                    "note": "option \"deterministic\" (cn_ctx_set_option): gradient sums in a fixed order, bit-identical runs; default on in "
+                                            "f32 / bf16x3, opt-in for bf16 (this line: the same bf16 steps with it on)"}
         out["check"] = {"error_sum": res["error_sum"], "update_l2": res["update_l2"], "update_sum": res["update_sum"],
                         **({"replicas_identical": res["replicas_identical"]} if "replicas_identical" in res else {}), "allreduce": exch}
         if use_comm:

@@ -39,6 +39,7 @@ const char *Configuration::usage()
     return "Usage: currennt_hip [options] [options-file]\n"
            "  common:   --network F --parallel_sequences N --random_seed N --cuda B(ignored) --list_devices B\n"
            "            --precision f32|bf16|bf16x3 --device N\n"
+           "            --deterministic B (gradient sums in a fixed order: bit-identical runs; default true for f32 / bf16x3)\n"
            "            --gpus N (training only: data-parallel over N GPUs of this node, devices --device .. --device+N-1;\n"
            "                      parallel_sequences is per GPU; gradients are summed with RCCL)\n"
            "  training: --train B --stochastic B (= --hybrid_online_batch) --shuffle_fractions B --shuffle_sequences B\n"
@@ -102,6 +103,7 @@ void Configuration::apply(const std::string &key, const std::string &v)
         else if (v == "bf16x3") m_precision = CN_PREC_BF16X3;
         else throw std::runtime_error("Error while parsing the command line and/or options file: unknown precision '" + v + "'");
     }
+    else if (key == "deterministic") m_deterministic = toBool(key, v) ? 1 : 0;
     else if (key == "device") m_device = atoi(v.c_str());
     else if (key == "gpus") { m_gpus = atoi(v.c_str()); if (m_gpus < 1) throw std::runtime_error("Error while parsing the command line and/or options file: --gpus must be >= 1"); }
     else if (key == "dp_rank") m_dpRank = atoi(v.c_str());

@@ -53,6 +53,8 @@ public:
     const std::vector<std::string> &feedForwardInputFiles() const { return m_feedForwardInputFiles; }
     cn_precision precision() const { return m_precision; }
     int device() const { return m_device; }
+    // -1: the library's default (on for f32 / bf16x3, off for bf16); the library's "deterministic" option (cn_ctx_set_option)
+    int deterministic() const { return m_deterministic; }
     // data-parallel training over `gpus` devices of this node, one process per GPU (no counterpart in the reference,
     // which drives one device: main.cpp:526-541); dpRank/dpWorld: shard of a host-only --dump_fractions run
     int gpus() const { return m_gpus; }
@@ -93,6 +95,7 @@ private:
     std::string m_networkFile = "network.jsn", m_trainedNetwork = "trained_network.jsn", m_feedForwardOutputFile = "ff_output.csv";
     std::vector<std::string> m_trainingFiles, m_validationFiles, m_testFiles, m_feedForwardInputFiles;
     cn_precision m_precision = CN_PREC_F32;
+    int m_deterministic = -1;
 
     void apply(const std::string &key, const std::string &value);
 };

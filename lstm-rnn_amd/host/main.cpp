@@ -259,6 +259,7 @@ int trainerMain(const Configuration &config, const DataParallel &dp = DataParall
         // CN_COMM_BACKEND=ipc): every rank on --device
         const bool sameDevice = dp.active && testHook("CN_DP_SAME_DEVICE") != 0;
         NeuralNetwork neuralNetwork(netDoc, config.parallelSequences(), maxSeqLength, inputSize, config.precision(), config.device() + (sameDevice ? 0 : dp.rank), &wi);
+        if (config.deterministic() >= 0) hipCheck(cn_ctx_set_option(neuralNetwork.context(), "deterministic", config.deterministic()), neuralNetwork.context());
         if (dp.active) {
             // rendezvous: rank 0 draws the id and hands it to the other ranks through their pipes, then every rank joins
             char id[CN_COMM_ID_BYTES];

@@ -334,14 +334,15 @@ def test_all_dummy_fraction_contributes_nothing(pkg):
                 assert np.all(lay.weight_updates() == 0.0), lay.name
 
 
-@pytest.mark.parametrize("mode,post_bound,w_bound", [("f32", 2.5e-4, 2.5e-4), ("bf16x3", 8e-3, 8e-3)])
+@pytest.mark.parametrize("mode,post_bound,w_bound", [("f32", 1e-4, 1e-4), ("bf16x3", 8e-3, 8e-3)])
 def test_config1_drift_through_training_stays_inside_the_measured_bound(pkg, orc, mode, post_bound, w_bound):
     """The real 39 -> 3 x blstm250 -> softmax183 net trained for 20 momentum-SGD updates (lr 1e-2, momentum 0.9) on a learnable
-    task, HIP path against the oracle doing the same.  Single-pass parity is < 1e-4 in both modes (test_gpu_parity.py); what
-    a training run ADDS is measured by bench.py's `parity_vs_cpu` after 40 updates: f32 0.7-1.1e-4 on the posteriors (fp32
-    summation order + split-K atomics, amplified by the updates), bf16x3 3.3-4.3e-3 (2^-16 per product term).  This test pins
-    those measured levels with a margin of ~2x so that a regression of either mode is caught; it is NOT the north-star
-    bound, which is a single-pass statement."""
+    task, HIP path against the oracle doing the same.  Single-pass parity is < 1e-4 in both modes (test_gpu_parity.py).  Through
+    training the f32 mode now holds the NORTH-STAR bound itself, 1e-4 on the posteriors and on the weights: its gradient sums
+    run in a fixed order (option "deterministic", on by default in this mode; round 6), so what the updates amplify is fp32
+    summation ORDER against the oracle's serial sums only, the same every run -- with split-K atomics it was 0.7-2.1e-4 and
+    different every run (BENCH_r05: 1.3e-4, the profiled run 2.1e-4; this test allowed 2.5e-4).  bf16x3: 3.3-4.3e-3
+    (2^-16 per product term), pinned with a margin of ~2x."""
     rng = np.random.RandomState(77)
     P, C, nseq, tlen = 39, 183, 6, 40
     layers = net_desc(P, [("blstm", 250)] * 3, C)
@@ -387,9 +388,13 @@ def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
            the fp32-tolerance mode -- which is what (ii) looks at);
       (ii) lr 3e-5, 60 epochs -- training to ~40 %: the three runs decorrelate like any three SGD runs (from epoch ~12 on the
            class error of ONE mode moves by +-3 % from epoch to epoch, and one mode differs from itself by 2-3 % between runs),
-           so what is looked at is the best epoch (what early stopping keeps) and the mean of the last ten, and what is asserted
-           is that every mode gets into the same region (one run: best 38.8 / 37.5 / 39.1, last ten 41.8 / 40.3 / 40.9 for
-           f32 / bf16x3 / bf16; the spread over runs is in the comment at the assertion)."""
+           so what is looked at is the best epoch (what early stopping keeps) and the mean of the last ten.  Round 6: every
+           mode runs with its gradient sums in a fixed order (`--deterministic true`; tools/chime_convergence.py), so a run is
+           REPRODUCIBLE BIT FOR BIT -- asserted: the bf16 run twice gives the same table -- and the difference between two modes
+           is a number, not noise: best / last ten = 38.83 / 43.04 (f32), 37.91 / 42.57 (bf16x3), 38.40 / 41.04 (bf16), i.e.
+           the bf16 "penalty" on this task is -0.4 % / -2.0 % absolute (bf16 ends BETTER; three trajectories of a chaotic
+           regime, each exactly repeatable).  Asserted one-sided: bf16 and bf16x3 end no more than 1.5 % absolute above f32
+           on either figure."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
@@ -404,12 +409,16 @@ def test_config2_real_data_convergence_of_the_three_arithmetic_modes(tmp_path):
         assert abs(a["train_err"] - b["train_err"]) <= 5e-3 * a["train_err"], (a, b)
         assert abs(a["val_class_err"] - c["val_class_err"]) <= 0.5 and abs(a["val_err"] - c["val_err"]) <= 5e-3 * a["val_err"], (a, c)
     far = cc.run(str(tmp_path), epochs=60, ps=10, lr=3e-5)
+    again = cc.run(str(tmp_path), epochs=60, ps=10, lr=3e-5, modes=("bf16",))
+    assert again["modes"]["bf16"] == far["modes"]["bf16"]        # run-to-run spread = 0: the same table, every digit the driver prints
     stat = {}
     for mode, rows in far["modes"].items():
         ce = [r["val_class_err"] for r in rows]
         stat[mode] = (min(ce), float(np.mean(ce[-10:])))
-    # The noisy regime is not reproducible run to run even in ONE mode (the gradients' split-K atomics reorder): over eight runs of
-    # this test best / last-ten of f32 were 38.0-41.3 / 41.1-43.8 %, of bf16 39.1-42.7 / 40.9-45.6, of bf16x3 39.6 / 41.4-41.7.
-    # Differences between modes are therefore noise of +-3 %; what is asserted is that EVERY mode gets from 91 % into that region.
+    # With atomics (rounds 4-5) ONE mode differed from itself by 2-3 % between runs: best / last-ten of f32 38.0-41.3 / 41.1-43.8 %,
+    # of bf16 39.1-42.7 / 40.9-45.6 over eight runs, and the mode-to-mode bound had to go.  With fixed-order sums the figures are
+    # exact (docstring); a mode's penalty against f32 is asserted one-sided, and every mode must get from 91 % into the region.
     for mode in ("f32", "bf16", "bf16x3"):
         assert stat[mode][0] < 46.0 and stat[mode][1] < 49.0, (mode, stat)
+    for mode in ("bf16", "bf16x3"):
+        assert stat[mode][0] <= stat["f32"][0] + 1.5 and stat[mode][1] <= stat["f32"][1] + 1.5, (mode, stat)

@@ -82,7 +82,9 @@ def parse_table(text):
     return rows
 
 
-def run(workdir, epochs=20, ps=10, lr=1e-4, momentum=0.9, n_train=90, modes=("f32", "bf16x3", "bf16"), extra=()):
+def run(workdir, epochs=20, ps=10, lr=1e-4, momentum=0.9, n_train=90, modes=("f32", "bf16x3", "bf16"), extra=("--deterministic", "true")):
+    """`extra`: further driver options; by default every mode sums its gradients in a fixed order (bf16 opts in), so a run is
+    reproducible bit for bit and a difference between two modes is the arithmetic's, not the atomics'."""
     xs, ts, tags, num_labels = read_sequences()
     train, val = os.path.join(workdir, "train.nc"), os.path.join(workdir, "val.nc")
     write_nc(train, xs[:n_train], ts[:n_train], tags[:n_train], num_labels)
