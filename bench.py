@@ -699,19 +699,21 @@ def cpu_baseline(pkg, wl, args, precisions):
     tlen = int(max(6, min(60, 90e9 / 41 / fpf / nseq)))                        # <= ~90 GFLOP of oracle work for the 41 passes
     orc.set_threads(min(8, len(os.sched_getaffinity(0))))                      # checker, not the timed baseline: bit-identical for any thread count
     proj = rng.randn(2 * P, C).astype(np.float32)
-    fracs = []
+    fracs, fracs_rev = [], []
     for _ in range(2):
         xs = [rng.randn(tlen - (i % 3), P).astype(np.float32) for i in range(nseq)]
         ts = [np.argmax(np.hstack([x, np.vstack([np.zeros((1, P), np.float32), x[:-1]])]) @ proj, axis=1).astype(np.int32) for x in xs]
         fracs.append(pkg.make_fraction(xs, ts, nseq))
+        fracs_rev.append(pkg.make_fraction(xs[::-1], ts[::-1], nseq))          # the same sequences, slots in reverse order
     lr, mom, nupd = 1e-2, 0.9, 40
 
-    def train(net):
+    def train(net, fr=None):
+        fr = fr or fracs
         errs = []
         for k in range(nupd):
-            net.load_sequences(fracs[k % 2]); net.compute_forward_pass(); errs.append(net.calculate_error())
+            net.load_sequences(fr[k % 2]); net.compute_forward_pass(); errs.append(net.calculate_error())
             net.compute_backward_pass(); net.update_weights(lr, mom)
-        net.load_sequences(fracs[0]); net.compute_forward_pass()
+        net.load_sequences(fr[0]); net.compute_forward_pass()
         return errs
 
     def rel(a, b):
@@ -722,6 +724,20 @@ def cpu_baseline(pkg, wl, args, precisions):
     real = np.asarray(fracs[0]["patTypes"]).reshape(-1) != 0
     parity = {"task": "%d updates (lr %g, momentum %g) on 2 fractions of %d sequences x %d frames, learnable targets; oracle error %.1f -> %.1f, "
                       "largest posterior %.3f" % (nupd, lr, mom, nseq, tlen, eref[0], eref[-1], float(yr.reshape(-1, C)[real].max()))}
+    # What "after 40 updates" can mean in fp32 at all: the REFERENCE arithmetic itself (the oracle, bit-equal to oracle/_ref) trained
+    # on the same sequences with the slots of each fraction in reverse order -- the same gradient mathematically, its sum over the
+    # patterns taken in another order (LstmLayer.cu:502-510 walks the patterns in slot order) -- against its own first run.  A HIP
+    # figure at or below this one is at the noise floor of fp32 summation order under this many updates, not an arithmetic defect;
+    # the north-star 1e-4 is a single-pass bound (tests/test_gpu_parity.py) and holds through 20 updates (tests/test_gpu_configs.py).
+    ref2 = orc.OracleNetwork(layers, weights, nseq, tlen)
+    train(ref2, fracs_rev)
+    T0 = int(fracs[0]["T"])
+    y_a = yr.reshape(T0, nseq, C); y_b = ref2.outputs().reshape(T0, nseq, C)[:, ::-1, :]
+    real3 = real.reshape(T0, nseq)
+    parity["f32_reference_slot_order_noise"] = {
+        "posterior_max_abs": float(np.abs(y_a - y_b)[real3].max()),
+        "weights_max_abs": max(float(np.abs(ref2.layer(l["name"]).weights - ref.layer(l["name"]).weights).max()) for l in layers if l["type"] in ("lstm", "blstm", "softmax")),
+        "note": "oracle vs oracle: the same sequences with the slots of every fraction reversed (another fp32 summation order of the same gradient), same 40 updates"}
     for name in dict.fromkeys(["f32", "bf16x3", args.precision]):
         if name not in precisions:
             continue
