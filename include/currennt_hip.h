@@ -125,6 +125,12 @@ int  cn_ctx_synchronize(cn_ctx *ctx);                                   /* [sync
  *                    two runs on the same inputs give BIT-IDENTICAL gradients and weights, like the reference's serial
  *                    sums.  0: fp32 atomics in arrival order.  Default: 1 for CN_PREC_F32 / CN_PREC_BF16X3 (the parity
  *                    modes), 0 for CN_PREC_BF16; the environment variable CN_DETERMINISTIC=0/1 sets the default.
+ *   "overlap"        1 (default): weight-gradient products on side streams beside the recurrent kernels; 0: one stream.
+ *   A/B and test switches of the kernel selection (csrc/cn_internal.h, CN_OPTION_LIST; e.g. "no_s2_asm", "no_cluster",
+ *                    "no_big_tn", "tnbig_group_mink", "lazy_softmax"): every one of them was an environment variable read
+ *                    somewhere on a launch path until round 5.  Now the environment (CN_<NAME>) is read ONCE, at
+ *                    cn_ctx_create, into the context's options block; this call changes an entry afterwards; no launch path
+ *                    calls getenv.  Options that size allocations ("cluster4", "no_cluster") belong before the layers.
  * Unknown names fail with CN_ERR_BAD_ARG.  May be changed between fractions.                                       */
 int  cn_ctx_set_option(cn_ctx *ctx, const char *name, int value);
 int  cn_ctx_get_option(const cn_ctx *ctx, const char *name, int *value);

@@ -78,6 +78,7 @@ struct cn_ctx {
     // thread per weight, serial sum: LstmLayer.cu:289-512, FeedForwardLayer.cu:82-102).  On by default in the parity modes
     // (CN_PREC_F32, CN_PREC_BF16X3), opt-in for CN_PREC_BF16; CN_DETERMINISTIC=0/1 sets the default of new contexts.
     bool det = false;
+    Options opt;                               // A/B and test switches (cn_internal.h): the environment's at creation, cn_ctx_set_option afterwards
     int prec = P_F32;                          // arithmetic of the MFMA products: P_F32 / P_BF16 / P_X3 (cn_internal.h)
     int num_cus = 256;                         // hipDeviceProp_t::multiProcessorCount of the bound device
     std::string arch;
@@ -218,7 +219,50 @@ struct cn_layer {
     size_t maxN() const { return (size_t)PSp * maxT; }
 };
 
+// ---- options (cn_internal.h) -------------------------------------------------------------------
+namespace cn {
+static const Options &default_options() { static const Options o = options_from_env(); return o; }
+static thread_local const Options *t_opt = nullptr;
+const Options &opt() { return t_opt ? *t_opt : default_options(); }
+Options options_from_env()
+{
+    Options o;
+    auto env_name = [](const char *name) { std::string e = "CN_"; for (const char *p = name; *p; ++p) e += (char)toupper((unsigned char)*p); return e; };
+#define CN_OPT_FLAG(name) o.name = getenv(env_name(#name).c_str()) != nullptr;
+#define CN_OPT_NUM(name, dflt) if (const char *v = getenv(env_name(#name).c_str())) o.name = atol(v);
+    CN_OPTION_LIST(CN_OPT_FLAG, CN_OPT_NUM)
+#undef CN_OPT_FLAG
+#undef CN_OPT_NUM
+    return o;
+}
+bool option_set(Options &o, const char *name, long value)
+{
+#define CN_OPT_FLAG(n) if (!strcmp(name, #n)) { o.n = value != 0; return true; }
+#define CN_OPT_NUM(n, dflt) if (!strcmp(name, #n)) { o.n = value; return true; }
+    CN_OPTION_LIST(CN_OPT_FLAG, CN_OPT_NUM)
+#undef CN_OPT_FLAG
+#undef CN_OPT_NUM
+    return false;
+}
+bool option_get(const Options &o, const char *name, long *value)
+{
+#define CN_OPT_FLAG(n) if (!strcmp(name, #n)) { *value = o.n; return true; }
+#define CN_OPT_NUM(n, dflt) if (!strcmp(name, #n)) { *value = o.n; return true; }
+    CN_OPTION_LIST(CN_OPT_FLAG, CN_OPT_NUM)
+#undef CN_OPT_FLAG
+#undef CN_OPT_NUM
+    return false;
+}
+}  // namespace cn
+
 namespace {
+
+// every entry point that touches the device: bind it and make the context's options the ones the launch paths see
+void enter(cn_ctx *c)
+{
+    HIP_CHECK(hipSetDevice(c->device));
+    cn::t_opt = &c->opt;
+}
 
 void *dalloc(cn_layer *l, size_t bytes)
 {
@@ -284,7 +328,7 @@ struct Timed {
 // wide softmax rows of the bf16 throughput mode: v_exp_f32 + one reciprocal per row (cn_elementwise.hip, softmax_exp<FAST>)
 bool softmax_fast(cn_ctx *c)
 {
-    static const bool exact = getenv("CN_SOFTMAX_EXACT") != nullptr;      // A/B switch
+    const bool exact = opt().softmax_exact;      // A/B switch
     return c->prec == P_BF16 && !exact;
 }
 // fp32 outputs of a feed-forward / softmax layer for a reader other than the fused softmax backward kernel
@@ -403,7 +447,7 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     if (!c->overlap) { f(c->stream, nullptr); return; }
     // The first trainable layer's gradient work has nothing to run beside: only the weight update follows.  On the main
     // stream it saves the two cross-stream hand-offs (fork, join) in front of the update.
-    static const bool tail_on_main = getenv("CN_TAIL_ON_SIDE") == nullptr;
+    const bool tail_on_main = !opt().tail_on_side;
     if (tail_on_main && l->prev && !l->prev->trainable && !fork_attached) { f(c->stream, nullptr); return; }
     if (!l->ev_fork) { HIP_CHECK(hipEventCreateWithFlags(&l->ev_fork, hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming)); }
     if (!fork_attached) HIP_CHECK(hipEventRecord(l->ev_fork, c->stream));
@@ -413,7 +457,7 @@ template <typename F> void on_side(cn_layer *l, F &&f, bool fork_attached = fals
     // (LVCSR config: the softmax layer's 8000 x 1024 gradient took 2.0 ms on 80 CUs beside a 1.3 ms recurrent kernel and the
     // error product behind it 757 instead of 140 us; 13.3 -> 12.7 ms per fraction with the rule below)
     bool slow = c->side_slow && l->prev && l->prev->lstm;
-    static const bool side_rule = getenv("CN_NO_SIDE_RULE") == nullptr;
+    const bool side_rule = !opt().no_side_rule;
     // ~1.5 TFLOP/s per CU on the 64 x 64 tiles; the 256 x 256 kernel of the wide layers (cn_gemm_tn_big.hip) runs at ~3
     const bool big = c->prec == P_BF16 && c->N >= 4096 && (l->lstm ? l->Hp >= 256 && l->Pp >= 192 : l->Lp >= 512 && l->Pp >= 192);
     // CUs the recurrent kernel that follows on the main stream will occupy when it is a cluster launch (0: one-CU kernels)
@@ -592,7 +636,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     // a grid that no longer fits takes the streaming kernels, which make no residency assumption.  The one-CU kernels (s2, s2w,
     // 4-sequence) make none either and keep the full count, so that a data-parallel run picks the kernels of a one-GPU run.
     if (c->has_comm()) {
-        static const int margin = getenv("CN_COMM_CU_MARGIN") ? atoi(getenv("CN_COMM_CU_MARGIN")) : 32;
+        const int margin = (int)opt().comm_cu_margin;
         r.cluster_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
     }
     r.gpart = nullptr; r.gpart_slots = 0; r.det_grid = nullptr;
@@ -689,7 +733,7 @@ void lstm_backward(cn_layer *l)
         if (!launch_lstm_cluster(c->stream, c->prec, true, r, &c->xch_epoch)) {
             check_rec_lds(l, true);
             // no K8 behind this kernel (the preceding layer is the input layer): the side stream forks from it directly
-            static const bool tail_on_side = getenv("CN_TAIL_ON_SIDE") != nullptr;
+            const bool tail_on_side = opt().tail_on_side;
             hipEvent_t fork = (tail_on_side && !l->prev->trainable && !c->timing) ? fork_event(l) : nullptr;
             launch_lstm_backward(c->stream, c->prec, r, fork);
             fork_attached = fork != nullptr;
@@ -731,14 +775,11 @@ void lstm_backward(cn_layer *l)
                     gs[ng++] = r;
                 }
             }
-            launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus);      // the three products side by side in one launch
-            if (c->det) {
-                // the workgroups' bias / peephole sums, added in workgroup order (dbias and dpeep are neighbours, in the gradient
-                // block and in a slot alike)
-                const int slot = 7 * l->dirs * Hp;
-                const FoldItem f{l->dbias, l->gpart, (long)slot, det_grid, 1, slot, slot, 1, 1};
-                launch_fold(st, &f, 1);
-            }
+            // deterministic mode: the workgroups' bias / peephole sums, added in workgroup order (dbias and dpeep are neighbours, in
+            // the gradient block and in a slot alike), in the launch that adds the products' split partials
+            const int slot = 7 * l->dirs * Hp;
+            const FoldItem f{l->dbias, l->gpart, (long)slot, det_grid, 1, slot, slot, 1, 1};
+            launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus, c->det ? &f : nullptr);      // the three products side by side in one launch
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -773,8 +814,8 @@ void ff_forward(cn_layer *l)
         // its last forward pass (forward-only use, another loss than multiclass) runs the eager kernel.  Only where recomputing is
         // cheap (softmax_fast): with expf and a division per element the two lazy passes take longer than the eager ones
         // (probe/softmax_bench: 363 + 633 against 454 + 427 us).
-        const bool lazy_off = getenv("CN_NO_LAZY_SOFTMAX") != nullptr;           // (read per pass: tests switch them)
-        const bool lazy_force = getenv("CN_LAZY_SOFTMAX") != nullptr;            // the exact lazy kernels
+        const bool lazy_off = opt().no_lazy_softmax;
+        const bool lazy_force = opt().lazy_softmax;                              // the exact lazy kernels
         l->sm_lazy = stat && l->sm_stat && l->sm_lazy_next && !l->has_follower && !lazy_off && (softmax_fast(c) || lazy_force);
         l->sm_read = false;
         launch_softmax_fwd(c->stream, l->out_f32, c->d_pat, c->N, l->size, l->Lp, stat ? c->d_tcls : nullptr, stat ? c->d_rowstat : nullptr,
@@ -790,6 +831,7 @@ void ff_backward(cn_layer *l)
     const int N = c->N;
     repack(l);
     if (c->det) ensure_det(l);
+    FoldItem colfold{}; colfold.nparts = 0;       // deterministic mode: the column sums' fold rides on the gradient product's
     {
         Timed tm(c, KC_OTHER);
         if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
@@ -797,7 +839,7 @@ void ff_backward(cn_layer *l)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
                                    with_loss ? c->d_rowstat : nullptr, with_loss ? c->d_loss_acc : nullptr, c->d_loss + 6, l->sm_lazy ? l->sm_stat : nullptr,
-                                   softmax_fast(c), c->d_colpart, c->det ? l->det_colpart : nullptr);
+                                   softmax_fast(c), c->d_colpart, c->det ? l->det_colpart : nullptr, &colfold);
             l->sm_lazy_next = !l->sm_read;
             if (with_loss) c->loss_deferred = false;
             l->err_in_delta = !c->f32;
@@ -808,7 +850,7 @@ void ff_backward(cn_layer *l)
             if (l->mcc_pending) launch_mcc_backward(c->stream, y, c->d_tcls, N, l->size, l->Lp, l->err);
             if (l->kind == CN_LAYER_SOFTMAX) launch_softmax_bwd(c->stream, y, l->err, c->d_pat, N, l->size, l->Lp);
             launch_ff_delta(c->stream, c->f32, ff_act(l->kind), y, l->err, l->delta_op, N, l->size, l->Lp);
-            launch_colsum(c->stream, l->err, N, l->Lp, l->dbias, c->det ? l->det_colpart : nullptr);
+            launch_colsum(c->stream, l->err, N, l->Lp, l->dbias, c->det ? l->det_colpart : nullptr, &colfold);
         }
         l->mcc_pending = false;
     }
@@ -830,7 +872,7 @@ void ff_backward(cn_layer *l)
             g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
             if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; }
-            launch_gemm_tn(st, c->prec, g, c->tn_cus);
+            launch_gemm_tn(st, c->prec, g, c->tn_cus, colfold.nparts ? &colfold : nullptr);
         }
         {
             Timed tm(c, KC_OTHER, st);
@@ -905,6 +947,8 @@ int cn_ctx_create(int device_id, cn_precision precision, void *stream, cn_ctx **
             c->side_slow = masked_stream(device_id, ncu, prop.multiProcessorCount);
             c->side_cus = ncu;
         }
+        c->opt = options_from_env();            // the one place the switches' environment variables are read for this context
+        cn::t_opt = &c->opt;
         c->det = precision != CN_PREC_BF16;
         if (const char *e = getenv("CN_DETERMINISTIC")) c->det = atoi(e) != 0;
         if (const char *e = getenv("CN_NO_OVERLAP")) c->overlap = atoi(e) == 0;
@@ -958,6 +1002,7 @@ int cn_ctx_destroy(cn_ctx *ctx)
         hipFree(ctx->pf.pat_raw); hipFree(ctx->pf.tcls); hipFree(ctx->d_colpart);
         hipFree(ctx->d_pat_raw); hipFree(ctx->d_tcls); hipFree(ctx->d_loss); hipFree(ctx->arena); hipFree(ctx->acc); hipFree(ctx->d_rowstat); hipFree(ctx->d_xch); hipFree(ctx->d_fault);
         if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        if (cn::t_opt == &ctx->opt) cn::t_opt = nullptr;
         delete ctx;
     });
 }
@@ -967,6 +1012,8 @@ int cn_ctx_set_option(cn_ctx *ctx, const char *name, int value)
     if (!ctx || !name) { g_last_error = "cn_ctx_set_option: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         if (!strcmp(name, "deterministic")) { ctx->det = value != 0; return; }
+        if (!strcmp(name, "overlap")) { ctx->overlap = value != 0; return; }
+        if (option_set(ctx->opt, name, value)) return;
         throw cn_error(CN_ERR_BAD_ARG, std::string("cn_ctx_set_option: unknown option \"") + name + "\"");
     });
 }
@@ -976,6 +1023,9 @@ int cn_ctx_get_option(const cn_ctx *ctx, const char *name, int *value)
     if (!ctx || !name || !value) { g_last_error = "cn_ctx_get_option: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         if (!strcmp(name, "deterministic")) { *value = ctx->det ? 1 : 0; return; }
+        if (!strcmp(name, "overlap")) { *value = ctx->overlap ? 1 : 0; return; }
+        long v = 0;
+        if (option_get(ctx->opt, name, &v)) { *value = (int)v; return; }
         throw cn_error(CN_ERR_BAD_ARG, std::string("cn_ctx_get_option: unknown option \"") + name + "\"");
     });
 }
@@ -984,7 +1034,7 @@ int cn_ctx_synchronize(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_ctx_synchronize: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         join_side(ctx);
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         HIP_CHECK(hipGetLastError());
@@ -995,7 +1045,7 @@ int cn_ctx_synchronize(cn_ctx *ctx)
 int cn_ctx_join(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_ctx_join: ctx is NULL"; return CN_ERR_BAD_ARG; }
-    return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); join_side(ctx); });
+    return guarded([&] { enter(ctx); join_side(ctx); });
 }
 
 int cn_layer_join(cn_layer *layer)
@@ -1003,7 +1053,7 @@ int cn_layer_join(cn_layer *layer)
     if (!layer) { g_last_error = "cn_layer_join: layer is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         for (size_t i = 0; i < c->pending_joins.size(); ++i)
             if (c->pending_joins[i] == layer->ev_join) {
                 HIP_CHECK(hipStreamWaitEvent(c->stream, layer->ev_join, 0));
@@ -1019,7 +1069,7 @@ int cn_layer_join_stream(cn_layer *layer, void *stream)
 {
     if (!layer || !stream) { g_last_error = "cn_layer_join_stream: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(layer->ctx->device));
+        enter(layer->ctx);
         stream_wait_layer(layer, (hipStream_t)stream);
     });
 }
@@ -1045,7 +1095,7 @@ int cn_comm_init(cn_ctx *ctx, const char *id, int rank, int world)
     return guarded([&] {
         if (world < 1 || rank < 0 || rank >= world) throw cn_error(CN_ERR_BAD_ARG, "cn_comm_init: rank " + std::to_string(rank) + " outside world of " + std::to_string(world));
         if (ctx->has_comm()) throw cn_error(CN_ERR_STATE, "cn_comm_init: this context already has a communicator");
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         if (!ctx->comm_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_comm, hipEventDisableTiming));
@@ -1092,7 +1142,7 @@ int cn_comm_destroy(cn_ctx *ctx)
     if (!ctx) { g_last_error = "cn_comm_destroy: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         if (!ctx->has_comm()) return;
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         HIP_CHECK(hipStreamSynchronize(ctx->comm_stream));
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         std::string failure;
@@ -1143,13 +1193,13 @@ int cn_allreduce_grads(cn_ctx *ctx, cn_layer *const *layers, int n)
     if (!ctx || n < 0 || (n > 0 && !layers)) { g_last_error = "cn_allreduce_grads: bad argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         require_comm(ctx, "cn_allreduce_grads");
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         finalize(ctx);
         // CN_COMM_TEST_DOUBLE (tests/test_gpu_parallel.py): the collective is replaced by a kernel on the communication stream
         // that doubles the gradient -- what a two-rank all-reduce of equal shards does --, so that the ORDER of gradient work,
         // exchange and update can be checked on a one-GPU box: a reduction that starts early or an update that does not wait
         // shows in the trained weights
-        const bool test_double = getenv("CN_COMM_TEST_DOUBLE") != nullptr;
+        const bool test_double = opt().comm_test_double;
         if (test_double && ctx->comm_world > 1)
             throw cn_error(CN_ERR_STATE, "cn_allreduce_grads: CN_COMM_TEST_DOUBLE is set in a job of more than one rank (it replaces the "
                                          "gradient exchange by a stand-in and is for one-rank ordering tests only)");
@@ -1193,7 +1243,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
     *out = nullptr;
     cn_layer *l = nullptr;
     int rc = guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         if (size <= 0) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: layer size must be positive");
         if (kind == CN_LAYER_INPUT) {
             if (preceding) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_create: the input layer has no preceding layer");
@@ -1346,7 +1396,7 @@ int cn_layer_destroy(cn_layer *layer)
     if (!layer) return CN_OK;
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         join_side(c);                                   // side-stream work of this layer may still be in flight
         HIP_CHECK(hipStreamSynchronize(c->stream));
         if (c->side) HIP_CHECK(hipStreamSynchronize(c->side));      // (operand copies being rebuilt: ev_pack_last may be this layer's)
@@ -1398,7 +1448,7 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
     if (!ctx || !input || !f) { g_last_error = "cn_fraction_load: NULL argument"; return CN_ERR_BAD_ARG; }
     const hipMemcpyKind kind = resident ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         check_fraction(ctx, input, post_output, f);
         const int T = f->max_seq_length;
         finalize(ctx);
@@ -1522,7 +1572,7 @@ int cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_o
 {
     if (!ctx || !input || !f) { g_last_error = "cn_fraction_prefetch_resident: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         check_fraction(ctx, input, post_output, f);
         const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
         if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_prefetch_resident: target_classes missing");
@@ -1564,7 +1614,7 @@ int cn_layer_forward(cn_layer *layer)
 {
     if (!layer) { g_last_error = "cn_layer_forward: layer is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(layer->ctx->device));
+        enter(layer->ctx);
         require_loaded(layer->ctx);
         finalize(layer->ctx);
         join_side(layer->ctx);
@@ -1579,7 +1629,7 @@ int cn_layer_backward(cn_layer *layer)
     if (!layer) { g_last_error = "cn_layer_backward: layer is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         require_loaded(c);
         finalize(c);
         if (layer->trainable && layer->updated)
@@ -1602,7 +1652,7 @@ int cn_loss_eval(cn_layer *post, float *error, int *correct)
     if (!post || !error) { g_last_error = "cn_loss_eval: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = post->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         if (!post->post) throw cn_error(CN_ERR_BAD_ARG, "cn_loss_eval: not a post output layer");
         require_loaded(c);
         cn_layer *o = post->prev;
@@ -1637,14 +1687,14 @@ int cn_loss_accumulate(cn_layer *post)
     if (!post) { g_last_error = "cn_loss_accumulate: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = post->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         if (!post->post) throw cn_error(CN_ERR_BAD_ARG, "cn_loss_accumulate: not a post output layer");
         require_loaded(c);
         cn_layer *o = post->prev;
         flush_loss(c);
         // Training: the backward pass of the output layer follows; its launch (softmax_mcc_bwd_kernel) takes the sum along in one
         // extra workgroup, so nothing is enqueued here.  Whoever needs the sums or overwrites the rows first flushes (flush_loss).
-        static const bool defer_off = getenv("CN_NO_LOSS_DEFER") != nullptr;
+        const bool defer_off = opt().no_loss_defer;
         if (post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION && c->rowstat_of == o && !c->timing && !defer_off && softmax_mcc_bwd_takes_loss(o->Lp)) {
             c->loss_deferred = true;
             return;
@@ -1666,7 +1716,7 @@ int cn_loss_read(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int reset)
 {
     if (!ctx) { g_last_error = "cn_loss_read: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         flush_loss(ctx);
         float h[2];
         HIP_CHECK(hipMemcpyAsync(h, ctx->d_loss_acc, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
@@ -1683,7 +1733,7 @@ int cn_loss_read_global(cn_ctx *ctx, float *error_sum, int64_t *correct_sum, int
     if (!ctx) { g_last_error = "cn_loss_read_global: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         require_comm(ctx, "cn_loss_read_global");
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         flush_loss(ctx);
         float *g = ctx->d_loss + 4, h[2];
         if (ctx->ipc) {
@@ -1719,7 +1769,7 @@ int cn_layer_set_weights(cn_layer *layer, const float *host, int count)
     if (!layer || !host) { g_last_error = "cn_layer_set_weights: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_set_weights: layer has no weights");
         if (count != layer->nw)
             throw cn_error(CN_ERR_SHAPE, "Invalid number of weights: " + std::to_string(count) + " given, " + std::to_string(layer->nw) + " expected");
@@ -1736,7 +1786,7 @@ int cn_layer_upload(cn_layer *layer, cn_buffer which, const float *host, size_t 
     if (which == CN_BUF_WEIGHTS) return cn_layer_set_weights(layer, host, (int)count);
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_upload: layer has no weights");
         if (which != CN_BUF_WEIGHT_UPDATES && which != CN_BUF_WEIGHT_DELTAS) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_upload: not a parameter vector");
         if (count != (size_t)layer->nw) throw cn_error(CN_ERR_SHAPE, "cn_layer_upload: count != weight count");
@@ -1752,7 +1802,7 @@ int cn_layer_write_output_errors(cn_layer *layer, const float *host, size_t coun
     if (!layer || !host) { g_last_error = "cn_layer_write_output_errors: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         require_loaded(c);
         if (!layer->err) throw cn_error(CN_ERR_BAD_ARG, "cn_layer_write_output_errors: layer has no outputErrors");
         if (count != (size_t)c->Next * layer->size) throw cn_error(CN_ERR_SHAPE, "cn_layer_write_output_errors: count != T*PS*size");
@@ -1773,7 +1823,7 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
     if (!layer || !host) { g_last_error = "cn_layer_read: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         finalize(c);
         join_side(c);
         const size_t e = c->esz();
@@ -1842,7 +1892,7 @@ int cn_layer_read(cn_layer *layer, cn_buffer which, int dir, float *host, size_t
 void *cn_layer_device_ptr(cn_layer *layer, cn_buffer which)
 {
     if (!layer || !layer->trainable) return nullptr;
-    if (guarded([&] { HIP_CHECK(hipSetDevice(layer->ctx->device)); finalize(layer->ctx); }) != CN_OK) return nullptr;
+    if (guarded([&] { enter(layer->ctx); finalize(layer->ctx); }) != CN_OK) return nullptr;
     switch (which) {
     case CN_BUF_WEIGHTS: return layer->w;
     case CN_BUF_WEIGHT_UPDATES: return layer->wu;
@@ -1855,7 +1905,7 @@ int cn_ctx_param_arena(cn_ctx *ctx, void **weights, void **weight_updates, void 
 {
     if (!ctx) { g_last_error = "cn_ctx_param_arena: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         finalize(ctx);
         if (weights) *weights = ctx->arena;
         if (weight_updates) *weight_updates = ctx->arena + ctx->total;
@@ -1886,7 +1936,7 @@ int cn_sgd_update(cn_layer *layer, float learning_rate, float momentum)
     if (!layer) { g_last_error = "cn_sgd_update: layer is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         cn_ctx *c = layer->ctx;
-        HIP_CHECK(hipSetDevice(c->device));
+        enter(c);
         if (!layer->trainable) throw cn_error(CN_ERR_BAD_ARG, "cn_sgd_update: layer has no weights");
         comm_check_fast(c);
         finalize(c);
@@ -1911,7 +1961,7 @@ int cn_ctx_accumulate_updates(cn_ctx *ctx, int first)
 {
     if (!ctx) { g_last_error = "cn_ctx_accumulate_updates: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         finalize(ctx);
         if (ctx->armed) throw cn_error(CN_ERR_STATE, "cn_ctx_accumulate_updates: an armed per-fraction update is pending (batch learning sums first, cn_ctx_arm_update is not for it)");
         if (!first && !ctx->acc_valid) throw cn_error(CN_ERR_STATE, "cn_ctx_accumulate_updates: nothing accumulated yet (the first fraction of an epoch passes first != 0)");
@@ -1927,7 +1977,7 @@ int cn_ctx_take_accumulated(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_ctx_take_accumulated: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         finalize(ctx);
         if (!ctx->acc_valid) throw cn_error(CN_ERR_STATE, "cn_ctx_take_accumulated: nothing accumulated (cn_ctx_accumulate_updates)");
         join_side(ctx);
@@ -1948,7 +1998,7 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
 {
     if (!ctx) { g_last_error = "cn_sgd_update_all: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         comm_check_fast(ctx);
         finalize(ctx);
         join_side(ctx);
@@ -1972,14 +2022,14 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
         // The operand copies of the new weights are rebuilt right away, all layers in ONE launch on this stream
         // (pack_group_kernel): it costs about as much as the first layer's copy alone did, which was on the critical
         // path anyway, and the other layers' copies no longer need a fork event, the side stream and a wait.
-        static const bool group_off = getenv("CN_NO_PACK_GROUP") != nullptr;
+        const bool group_off = opt().no_pack_group;
         const bool grouped = ctx->overlap && !group_off && ntrain <= PACK_GROUP_MAX;
         const bool attach = ctx->overlap && !grouped && ctx->attach_forks && !ctx->timing;
         if (ctx->overlap && !grouped && !ctx->ev_sgd) HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_sgd, hipEventDisableTiming));
         bool own_rates = false;
         for (cn_layer *l : ctx->layers) own_rates = own_rates || (l->trainable && l->own_lr >= 0.f);
         // grouped: the update itself rides on the pack launch (pack_fetch): one kernel instead of two behind the last gradient
-        static const bool fuse_off = getenv("CN_NO_SGD_FUSE") != nullptr;
+        const bool fuse_off = opt().no_sgd_fuse;
         const bool fused = grouped && !fuse_off;
         if (fused) {
         } else if (!own_rates) {
@@ -2040,13 +2090,13 @@ int cn_sgd_update_all(cn_ctx *ctx, float learning_rate, float momentum)
 int cn_ctx_timing_enable(cn_ctx *ctx, int enable)
 {
     if (!ctx) { g_last_error = "cn_ctx_timing_enable: ctx is NULL"; return CN_ERR_BAD_ARG; }
-    return guarded([&] { HIP_CHECK(hipSetDevice(ctx->device)); timing_collect(ctx); ctx->timing = enable != 0; });
+    return guarded([&] { enter(ctx); timing_collect(ctx); ctx->timing = enable != 0; });
 }
 int cn_ctx_timing_read(cn_ctx *ctx, int kernel_class, double *total_ms, int64_t *launches)
 {
     if (!ctx || kernel_class < 0 || kernel_class >= KC_COUNT) { g_last_error = "cn_ctx_timing_read: bad argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         timing_collect(ctx);
         if (total_ms) *total_ms = ctx->acc_ms[kernel_class];
         if (launches) *launches = ctx->acc_n[kernel_class];
@@ -2056,7 +2106,7 @@ int cn_ctx_timing_reset(cn_ctx *ctx)
 {
     if (!ctx) { g_last_error = "cn_ctx_timing_reset: ctx is NULL"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         timing_collect(ctx);
         for (int k = 0; k < KC_COUNT; ++k) { ctx->acc_ms[k] = 0; ctx->acc_n[k] = 0; }
     });
@@ -2076,7 +2126,7 @@ int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
 {
     if (!ctx || !A || !B || !C) { g_last_error = "cn_dbg_gemm_nt: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         if (K % 8 || N % 32) throw cn_error(CN_ERR_SHAPE, "cn_dbg_gemm_nt: K must be a multiple of 8 and N of 32");
         const size_t e = ctx->esz();
         float *dA, *dB, *dC, *dbias = nullptr; void *oA, *oB;
@@ -2113,7 +2163,7 @@ int cn_dbg_gemm_tn(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
 {
     if (!ctx || !A || !B || !C) { g_last_error = "cn_dbg_gemm_tn: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
-        HIP_CHECK(hipSetDevice(ctx->device));
+        enter(ctx);
         if (M % 32 || N % 32) throw cn_error(CN_ERR_SHAPE, "cn_dbg_gemm_tn: M and N must be multiples of 32");
         const size_t e = ctx->esz();
         float *dA, *dB, *dC; void *oA, *oB;

@@ -456,12 +456,17 @@ __global__ void colsum_kernel(const float *err, int N, int Lp, float *colsum, fl
         __syncthreads();
     }
 }
-void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part)
+static void fold_now_or_later(hipStream_t s, const FoldItem &f, FoldItem *fold_out)
 {
+    if (fold_out) *fold_out = f; else launch_fold(s, &f, 1);
+}
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part, FoldItem *fold_out)
+{
+    if (fold_out) fold_out->nparts = 0;
     if (N <= 0) return;
     int blocks = (N + 63) / 64; if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, s, err, N, Lp, colsum, det_part);
-    if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
+    if (det_part) fold_now_or_later(s, FoldItem{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}, fold_out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1102,8 +1107,9 @@ bool softmax_mcc_bwd_takes_loss(int Lp) { return Lp <= 256; }
 size_t softmax_mcc_bwd_colpart_floats() { return MCC_COL_REPL * 256 + 1; }
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum, const float *rowstat, float *loss2, float *loss_part, const float *smstat, bool fast,
-                            float *colpart, float *det_part)
+                            float *colpart, float *det_part, FoldItem *fold_out)
 {
+    if (fold_out) fold_out->nparts = 0;
     if (N <= 0) return;
     if (Lp > 256) {
         int blocks = N < 1536 ? N : 1536;      // (two to three workgroups per CU are resident, 170 VGPRs: 512 ... 2048 measured)
@@ -1112,7 +1118,7 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
         if (f32) { if (!sm) CN_BWD_WIDE(true, 0); else if (fast) CN_BWD_WIDE(true, 2); else CN_BWD_WIDE(true, 1); }
         else     { if (!sm) CN_BWD_WIDE(false, 0); else if (fast) CN_BWD_WIDE(false, 2); else CN_BWD_WIDE(false, 1); }
 #undef CN_BWD_WIDE
-        if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
+        if (det_part) fold_now_or_later(s, FoldItem{colsum, det_part, (long)Lp, blocks, 1, Lp, Lp, 1, 0}, fold_out);
         return;
     }
     int blocks = (N + 15) / 16; if (blocks > 256) blocks = 256;
@@ -1121,7 +1127,7 @@ void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *
     if (loss2) blocks += MCC_LOSS_WGS;
     if (f32) hipLaunchKernelGGL(softmax_mcc_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart, det_part);
     else     hipLaunchKernelGGL(softmax_mcc_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, y, tcls, pat, N, L, Lp, err, delta_op, colsum, (const float2 *)rowstat, loss2, loss_part, colpart, det_part);
-    if (det_part) { const FoldItem f{colsum, det_part, (long)Lp, nwg, 1, Lp, Lp, 1, 0}; launch_fold(s, &f, 1); }
+    if (det_part) fold_now_or_later(s, FoldItem{colsum, det_part, (long)Lp, nwg, 1, Lp, Lp, 1, 0}, fold_out);
 }
 size_t det_colsum_part_floats(int Lp) { return (size_t)1536 * Lp; }      // the most workgroups any of the column-sum producers launches
 

@@ -274,7 +274,7 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
     // fixed costs dominate).  tools/probe/gemm_bench, 128 -> 64 rows: error to the preceding layer 22.2 -> 20.7 us, softmax
     // products 10.1 / 9.7 -> 9.0 / 8.8, input projections 16.2 / 23.3 -> 14.7 / 22.7; long-K products with 400+ tiles lose
     // (N = 512, K = 2048: 48.6 -> 57.0 us) and keep 128 rows.  CN_NT_BM64_BELOW=<tiles> overrides the first threshold.
-    static const long below = getenv("CN_NT_BM64_BELOW") ? atol(getenv("CN_NT_BM64_BELOW")) : 400;
+    const long below = opt().nt_bm64_below;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + NT_BN - 1) / NT_BN);
     const int elt = prec == P_BF16 ? 2 : 4;
     const bool small = tiles128 < below || ((long)g.K * elt <= 4 * NT_ROWB && tiles128 < 1100);
@@ -492,11 +492,11 @@ __global__ __launch_bounds__(tn_threads(BM)) void gemm_tn_kernel(GemmTNGroup grp
 }
 
 template <int PREC, int BM, int BN>
-static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
+static void launch_tn(hipStream_t s, const GemmTN *gs, int n, const FoldItem *extra)
 {
     using G = TnGeom<PREC, BM, BN>;
     GemmTNGroup grp{};
-    FoldItem fold[TN_GROUP]; int nfold = 0;
+    FoldItem fold[TN_GROUP + 1]; int nfold = 0;
     int blocks = 0;
     long all_tiles = 0;
     for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + BM - 1) / BM) * ((gs[i].N + BN - 1) / BN);
@@ -511,7 +511,7 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         // (a group shares the workgroup budget: its products run side by side, and their atomics add up)
         long cap_atomic = (32L << 20) / ((long)g.M * g.N * 4);
         // 576 four-wave workgroups swept best (256..2048) on the headline step for the 64 x 64 tiles
-        static const int target_env = getenv("CN_TN_BLOCKS") ? atoi(getenv("CN_TN_BLOCKS")) : 0;
+        const int target_env = (int)opt().tn_blocks;
         const int target = target_env ? target_env : 576;
         int splits = (int)((target + all_tiles - 1) / all_tiles);
         int maxsplit = (g.K + 4 * G::BK - 1) / (4 * G::BK);
@@ -526,7 +526,8 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n)
         if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
     }
     grp.first_block[TN_GROUP] = blocks;
-    if (blocks == 0) return;
+    if (extra) fold[nfold++] = *extra;
+    if (blocks == 0) { if (nfold) launch_fold(s, fold, nfold); return; }
     auto kern = gemm_tn_kernel<PREC, BM, BN>;
     constexpr int lds = G::LDS;
     static DeviceOnce attr_once;
@@ -553,13 +554,13 @@ static TnShape tn_shape(const GemmTN *gs, int n)
     return TN_64;
 }
 
-static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n)
+static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n, const FoldItem *extra)
 {
     const TnShape sh = tn_shape(gs, n);
 #define CN_TN_DISPATCH(P)                                                      \
     switch (sh) {                                                              \
-    case TN_64:      launch_tn<P, 64, 64>(s, gs, n); break;                    \
-    case TN_128:     launch_tn<P, 128, 128>(s, gs, n); break;                  \
+    case TN_64:      launch_tn<P, 64, 64>(s, gs, n, extra); break;             \
+    case TN_128:     launch_tn<P, 128, 128>(s, gs, n, extra); break;           \
     }
     if (prec == P_F32) { CN_TN_DISPATCH(P_F32) }
     else if (prec == P_X3) { CN_TN_DISPATCH(P_X3) }
@@ -567,14 +568,14 @@ static void launch_tn_any(hipStream_t s, int prec, const GemmTN *gs, int n)
 #undef CN_TN_DISPATCH
 }
 
-void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget)
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget, const FoldItem *extra)
 {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return;
-    if (gemm_tn_big_applies(prec, g)) { launch_gemm_tn_big_group(s, &g, 1, cu_budget); return; }
-    launch_tn_any(s, prec, &g, 1);
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) { if (extra) launch_fold(s, extra, 1); return; }
+    if (gemm_tn_big_applies(prec, g)) { launch_gemm_tn_big_group(s, &g, 1, cu_budget, extra); return; }
+    launch_tn_any(s, prec, &g, 1, extra);
 }
 
-void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget)
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget, const FoldItem *extra)
 {
     GemmTN grp[TN_GROUP], big[TN_GROUP]; int ng = 0, nb = 0;
     bool any_big = false;
@@ -583,8 +584,7 @@ void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int 
         // nothing in it is large enough on its own, but it is the exposed tail of the step, and over many frames the pair does better
         // on the 256 x 256 kernel -- tools/probe/gemm_bench, group alone, us small tiles / pair on the large kernel + dW_in behind it:
         // K = 15 600 67.2 / 84.9, K = 35 200 142.5 / 121.0, K = 51 200 230.7 / 146.6.  From half a million outputs and 28 000 frames on.
-        const char *gk = getenv("CN_TNBIG_GROUP_MINK");                       // (read per launch: the tests switch it)
-        const long gmink = gk ? atol(gk) : 28000;
+        const long gmink = opt().tnbig_group_mink;
         long outs = 0, kmin = 1L << 40;
         for (int i = 0; i < n; ++i)
             if (gs[i].M > 0 && gs[i].N > 0 && gs[i].K > 0 && gemm_tn_big_can(prec, gs[i])) { outs += (long)gs[i].M * gs[i].N; kmin = std::min<long>(kmin, gs[i].K); }
@@ -598,8 +598,10 @@ void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int 
         if (huge || ng == TN_GROUP) launch_gemm_tn(s, prec, gs[i]);      // (not grouped)
         else grp[ng++] = gs[i];
     }
-    if (nb) launch_gemm_tn_big_group(s, big, nb, cu_budget);
-    if (ng) launch_tn_any(s, prec, grp, ng);
+    // (the extra fold rides on the last launch of the call)
+    if (nb) launch_gemm_tn_big_group(s, big, nb, cu_budget, ng ? nullptr : extra);
+    if (ng) launch_tn_any(s, prec, grp, ng, extra);
+    else if (!nb && extra) launch_fold(s, extra, 1);
 }
 
 }  // namespace cn

@@ -523,7 +523,7 @@ bool gemm_nt_big_applies(int prec, const GemmNT &g)
     // kernel with three bf16 MFMAs per product (3/16): until round 5 the mode's large products came here and ran at a third of the
     // speed they have there (reading B at tolerance: gemm_wide 7.89 -> 5.03 ms per six fractions, 3.07 -> 3.41 M frames/s)
     if (prec == P_X3) return false;
-    static const bool off = getenv("CN_NO_BIG_GEMM") != nullptr;
+    const bool off = opt().no_big_gemm;
     const int KB = BG_ROWB / (f32 ? 4 : 2);
     if (off || g.K % KB != 0 || g.K < 4 * KB) return false;
     const long tiles = (long)((g.M + BG_BM - 1) / BG_BM) * ((g.N + BG_BN - 1) / BG_BN);
@@ -553,14 +553,13 @@ void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t don
         int dev = 0; (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
-    static const bool no8 = getenv("CN_NO_BIG8") != nullptr;
+    const bool no8 = opt().no_big8;
     // the persistent kernel: 32-bit byte offsets into every operand, whole 16-byte stores, and at least a dozen k-tiles per tile
-    // (a seam costs about five k-tiles of time; CN_BIG8_MIN_K, read per launch, lets the tests run it on short K)
+    // (a seam costs about five k-tiles of time; option big8_min_k lets the tests run it on short K)
     // ... or eight, when the launch is many tiles per CU long (>= 1000 tiles: the LVCSR layer and output products at K = 512 --
     // tools/probe/gemm_bench, us non-persistent / persistent: 51 200 x 2048 203.4 / 193.8, 35 200 x 2048 138.8 / 134.9,
     // 51 200 x 8000 710.8 / 652.7; reading B's 15 600 x 2048, 488 tiles: 51.5 / 54.7 and stays)
-    const char *mk = getenv("CN_BIG8_MIN_K");
-    const int min_k = mk ? atoi(mk) : (nwg >= 1000 ? 8 * 64 : 12 * 64);
+    const int min_k = opt().big8_min_k > 0 ? (int)opt().big8_min_k : (nwg >= 1000 ? 8 * 64 : 12 * 64);
     const bool fits = (unsigned long long)g.M * g.lda * 2 < 0xfffffff0ull && (unsigned long long)g.N * g.ldb * 2 < 0xfffffff0ull &&
                       (!g.C || ((unsigned long long)g.M * g.ldc * 4 < 0xfffffff0ull && g.ldc % 4 == 0 && (uintptr_t)g.C % 16 == 0)) &&
                       (!g.C2 || ((unsigned long long)g.M * g.ldc2 * 2 < 0xfffffff0ull && g.ldc2 % 4 == 0 && (uintptr_t)g.C2 % 8 == 0)) &&

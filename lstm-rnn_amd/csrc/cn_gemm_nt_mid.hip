@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_mid_kernel(GemmNT p, int tiles
 // products, N = 2048: 133 against 142 us at M = 35200, 205 against 208 us at M = 51200 -- profiles/r05c_gemm_nt_mid.md)
 bool gemm_nt_mid_applies(int prec, const GemmNT &g)
 {
-    static const bool off = getenv("CN_NO_NT_MID") != nullptr;
+    const bool off = opt().no_nt_mid;
     if (off || prec != P_BF16) return false;
     if (g.K % NM_BK != 0 || g.K < 4 * NM_BK || g.K >= 768 || g.N > 4096) return false;
     if (g.N % 4 != 0 || (g.C && (g.ldc % 4 || (uintptr_t)g.C % 16)) || (g.C2 && (g.ldc2 % 4 || (uintptr_t)g.C2 % 8)) || (uintptr_t)g.A % 16 || (uintptr_t)g.B % 16 || (g.bias && (uintptr_t)g.bias % 16) || !(g.C || g.C2) || g.lda % 8 || g.ldb % 8) return false;

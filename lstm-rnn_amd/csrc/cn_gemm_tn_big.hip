@@ -221,7 +221,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnBigGroup grp)
 // for the operands to be a fill-path problem at all.
 bool gemm_tn_big_can(int prec, const GemmTN &g)
 {
-    static const bool off = getenv("CN_NO_BIG_TN") != nullptr;
+    const bool off = opt().no_big_tn;
     if (off || prec != P_BF16) return false;
     if (g.lda % 8 || g.ldb % 8 || g.M % 8 || g.N % 8 || (uintptr_t)g.A % 16 || (uintptr_t)g.B % 16) return false;
     if (g.K < 4096 || g.M < 512) return false;
@@ -238,9 +238,9 @@ bool gemm_tn_big_applies(int prec, const GemmTN &g)
     return gemm_tn_big_can(prec, g) && (long)g.M * g.N >= (1L << 20);
 }
 
-void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget)
+void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget, const FoldItem *extra)
 {
-    if (n <= 0) return;
+    if (n <= 0) { if (extra) launch_fold(s, extra, 1); return; }
     static DeviceOnce attr_once;
     static int cus = 256;
     if (attr_once.first()) {
@@ -249,7 +249,7 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     }
     TnBigGroup grp{};
-    FoldItem fold[TB_GROUP]; int nfold = 0;
+    FoldItem fold[TB_GROUP + 1]; int nfold = 0;
     long all_tiles = 0;
     for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + TB_BM - 1) / TB_BM) * ((gs[i].N + TB_BN - 1) / TB_BN);
     int blocks = 0;
@@ -260,7 +260,7 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
         const int tiles_m = (g.M + TB_BM - 1) / TB_BM, tiles_n = (g.N + TB_BN - 1) / TB_BN, ntiles = tiles_m * tiles_n;
         // one workgroup per CU (128 KB of LDS): splits so that the group fills the chip once; every split ends in M*N fp32
         // atomics (~1.3 TB/s chip-wide): at most 64 MB of them per product, and at least 16 k-tiles per split
-        static const int target_env = getenv("CN_TNBIG_BLOCKS") ? atoi(getenv("CN_TNBIG_BLOCKS")) : 0;
+        const int target_env = (int)opt().tnbig_blocks;
         const int target = target_env ? target_env : (cu_budget > 0 ? std::min(cu_budget, cus) : cus);
         int splits = (int)std::max(1L, target / all_tiles);
         const long cap_atomic = std::max(1L, (64L << 20) / ((long)g.M * g.N * 4));
@@ -275,6 +275,7 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
     }
     grp.first_block[TB_GROUP] = blocks;
     hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(blocks), dim3(512), TB_LDS, s, grp);
+    if (extra) fold[nfold++] = *extra;
     if (nfold) launch_fold(s, fold, nfold);
 }
 

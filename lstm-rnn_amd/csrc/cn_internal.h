@@ -29,6 +29,37 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 //           of the bf16 rate -- the parity mode that is fast (CN_PREC_BF16X3)
 enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
 
+// ---- options -----------------------------------------------------------------------------------
+// ONE block of A/B and test switches per context instead of environment look-ups scattered over the launch paths (round 6).  A context
+// copies the process defaults -- read ONCE from the environment, variable CN_<NAME IN CAPITALS> -- at cn_ctx_create; after that
+// only cn_ctx_set_option(ctx, "<name>", value) changes them, and no launch path reads the environment.  FLAG: set by the mere
+// presence of the variable (as before); NUM: its integer value.  Options that size allocations (cluster4, no_cluster, rpl) must be
+// set before the layers are created.  cn_layer_recurrent_kernel keeps reporting which kernel actually ran.
+#define CN_OPTION_LIST(FLAG, NUM)                                                                                                  \
+    /* GEMM selection */                                                                                                          \
+    FLAG(no_big_gemm) FLAG(no_big8) NUM(big8_min_k, 0) FLAG(no_nt_mid) FLAG(no_big_tn) NUM(nt_bm64_below, 400) NUM(tn_blocks, 0) \
+    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000)                                                                             \
+    /* recurrent kernel selection */                                                                                              \
+    FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
+    FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \
+    FLAG(no_s2) FLAG(no_s2w) FLAG(no_s2w_asm)                                                                                     \
+    /* step structure */                                                                                                          \
+    FLAG(softmax_exact) FLAG(tail_on_side) FLAG(no_side_rule) FLAG(no_lazy_softmax) FLAG(lazy_softmax) FLAG(comm_test_double)     \
+    FLAG(no_loss_defer) FLAG(no_pack_group) FLAG(no_sgd_fuse) NUM(comm_cu_margin, 32)
+struct Options {
+#define CN_OPT_FIELD(name) int name = 0;
+#define CN_OPT_FIELD_NUM(name, dflt) long name = dflt;
+    CN_OPTION_LIST(CN_OPT_FIELD, CN_OPT_FIELD_NUM)
+#undef CN_OPT_FIELD
+#undef CN_OPT_FIELD_NUM
+};
+Options options_from_env();                              // (the environment is read here and nowhere else on the compute path)
+bool option_set(Options &o, const char *name, long value);  // false: no such option
+bool option_get(const Options &o, const char *name, long *value);
+// the options of the context whose call is running on this thread (set by every entry point of the ABI that touches the
+// device); the process defaults outside of one
+const Options &opt();
+
 // hipFuncSetAttribute (the > 64 KB dynamic LDS opt-in) is per device: a process may drive several GPUs
 struct DeviceOnce {
     std::atomic<unsigned long long> seen{0};
@@ -78,13 +109,15 @@ void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t don
 bool gemm_nt_mid_applies(int prec, const GemmNT &g);
 void launch_gemm_nt_mid(hipStream_t s, const GemmNT &g, hipEvent_t done = nullptr);
 // cu_budget: CUs the launch may fill with its one-per-CU workgroups when it goes to the 256 x 256 kernel (0 = the chip)
-void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget = 0);
+// `extra` (deterministic mode, nullable): one more fold that rides on the launch that adds this product's split partials (the
+// layer's bias / peephole / column partial sums): one launch behind the product instead of two
+void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget = 0, const FoldItem *extra = nullptr);
 // 256 x 256 LDS-DMA variant for the products whose operands do not fit the caches (cn_gemm_tn_big.hip); launch_gemm_tn /
 // launch_gemm_tn_group dispatch to it
 bool gemm_tn_big_applies(int prec, const GemmTN &g);    // on its own
 bool gemm_tn_big_can(int prec, const GemmTN &g);        // beside a product that applies (one grouped launch)
-void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget = 0);   // n <= 3
-void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget = 0);      // up to 3 small products in one launch
+void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget = 0, const FoldItem *extra = nullptr);   // n <= 3
+void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget = 0, const FoldItem *extra = nullptr);      // up to 3 small products in one launch
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------
 struct LstmRec {
@@ -185,7 +218,9 @@ void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *er
 // column sums of delta over the N slots (FeedForwardLayer.cu:82-102): colsum[j] += sum_n err[n][j]
 // det_part (nullable; deterministic mode): det_colsum_part_floats(Lp) floats; the workgroups store their partial sums there and a
 // second launch adds them in workgroup order
-void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part = nullptr);
+// fold_out (nullable): the fold is not launched but described there (nparts = 0: nothing to fold) for the caller to attach to
+// the layer's gradient product (launch_gemm_tn's `extra`)
+void launch_colsum(hipStream_t s, const float *err, int N, int Lp, float *colsum, float *det_part = nullptr, FoldItem *fold_out = nullptr);
 size_t det_colsum_part_floats(int Lp);
 // softmax rows in place (SoftmaxLayer.cu:250-315), dummies skipped
 // optional: tcls + rowstat[N][2] = {log p_target, argmax == target} for the multiclass loss
@@ -208,7 +243,7 @@ void launch_classes_to_targets(hipStream_t s, const int *tcls, float *tgt, int N
 // `loss_part`: 16 x {float sum, int count} + one arrival counter (zero between launches) for the sixteen reduction workgroups
 void launch_softmax_mcc_bwd(hipStream_t s, bool f32, const float *y, const int *tcls, const char *pat, int N, int L, int Lp,
                             float *err, void *delta_op, float *colsum, const float *rowstat = nullptr, float *loss2 = nullptr, float *loss_part = nullptr,
-                            const float *smstat = nullptr, bool fast = false, float *colpart = nullptr, float *det_part = nullptr);
+                            const float *smstat = nullptr, bool fast = false, float *colpart = nullptr, float *det_part = nullptr, FoldItem *fold_out = nullptr);
 bool softmax_mcc_bwd_takes_loss(int Lp);
 // `colpart` (nullable; narrow rows): softmax_mcc_bwd_colpart_floats() zeroed floats the launch spreads its column-sum atomics over
 // (replicas folded into colsum by the last workgroup; zero again when the launch ends)

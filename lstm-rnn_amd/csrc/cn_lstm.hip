@@ -906,7 +906,7 @@ static void launch_one(hipStream_t s, const LstmRec &p, int nwaves, hipEvent_t d
     // it: sharing its SIMDs' issue slots with GEMM waves cost the latency-bound recurrent kernel 27 % (291 vs
     // 229 us per backward launch in the step timeline); the GEMMs lose 26 of 256 CUs instead.
     size_t lds_claim = lds;
-    if (p.dirs * nsg <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    if (p.dirs * nsg <= 128 && !opt().no_lds_claim) lds_claim = 160 * 1024 - 1024;
     lstm_note_grid(p, p.dirs * nsg);
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * nsg), dim3(64 * nwaves), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_kernel<%d,%d,%d,%d>", BWD ? "bwd" : "fwd", PREC, HP, UG, RPL);
@@ -942,8 +942,8 @@ static void launch_rec(hipStream_t s, const LstmRec &p, hipEvent_t done = nullpt
         // 16 x 4Hp delta tile) used to win by 4 %; since the stage copies removed the latch stall it loses:
         // 0.64 vs 0.56 us per step (CN_BWD_UG2 keeps it selectable)
         if constexpr (PREC == P_BF16) {
-            if (BWD && getenv("CN_BWD_UG2")) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }
-            if (!BWD && getenv("CN_FWD_UG2")) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }   // measured slower: 0.63 vs 0.47 us per step
+            if (BWD && opt().bwd_ug2) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }
+            if (!BWD && opt().fwd_ug2) { launch_rpl<PREC, BWD, 128, 2>(s, p, 4, done); return; }   // measured slower: 0.63 vs 0.47 us per step
         }
         launch_rpl<PREC, BWD, 128, 1>(s, p, 8, done);
         return;

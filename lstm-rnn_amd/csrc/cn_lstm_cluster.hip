@@ -1414,7 +1414,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
         // of a step is the same as with the delta exchange (delta -> LDS -> barrier -> MFMAs -> hop, in another order) and the
         // kernel measures 3-4 % SLOWER (2-CU and 8-CU shapes alike), so bf16 keeps the delta exchange.
         // CN_BWD_PSUM=1 / CN_NO_BWD_PSUM=1 force either one (A/B, tests).
-        const bool psum = getenv("CN_BWD_PSUM") ? true : (getenv("CN_NO_BWD_PSUM") ? false : PREC == P_X3);
+        const bool psum = opt().bwd_psum ? true : (opt().no_bwd_psum ? false : PREC == P_X3);
         if (psum) {
             auto kp = lstm_bwd_cluster_psum_kernel<PREC, HP, UPC>;
             static DeviceOnce attr_once_p;
@@ -1437,7 +1437,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
     // is still longer than the half step hipcc's latch copies leave a prefetch there) -- so only the 8-CU shape gets them.
     // CN_CLUSTER_HELPERS=1 / CN_NO_CLUSTER_HELPERS=1 force either way (A/B, tests).
     int helpers = 0;
-    const bool want = getenv("CN_CLUSTER_HELPERS") ? true : (getenv("CN_NO_CLUSTER_HELPERS") ? false : CS == 8);
+    const bool want = opt().cluster_helpers ? true : (opt().no_cluster_helpers ? false : CS == 8);
     if (BWD && want && grid + (nclusters + 7) / 8 * 8 <= p.cluster_cus) helpers = (nclusters + 7) / 8 * 8;
     lstm_note_grid(p, grid);                       // (the helper workgroups form no sums)
     hipLaunchKernelGGL(kern, dim3(grid + helpers), dim3(NT), lds, s, p);
@@ -1452,7 +1452,7 @@ static void launch_cluster(hipStream_t s, const LstmRec &p)
 // layers stream W_rec in that mode
 static int cluster_size(int prec, int Hp)
 {
-    static const bool four = getenv("CN_CLUSTER4") != nullptr;
+    const bool four = opt().cluster4;
     if (prec == P_X3) return Hp == 256 ? 4 : 0;
     if (prec != P_BF16) return 0;
     return Hp == 256 ? (four ? 4 : 2) : (Hp == 512 ? 8 : 0);
@@ -1462,7 +1462,7 @@ static int cluster_size(int prec, int Hp)
 int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
 {
     const int CS = cluster_size(prec, Hp);
-    if (CS == 0 || rpl > 2 || getenv("CN_NO_CLUSTER")) return 0;
+    if (CS == 0 || rpl > 2 || opt().no_cluster) return 0;
     const int nclusters = dirs * (PS / (4 * rpl));
     if ((nclusters + 7) / 8 * 8 * CS > num_cus) return 0;      // every member must be resident (one workgroup per CU)
     return CS;
@@ -1513,7 +1513,7 @@ bool launch_lstm_cluster(hipStream_t s, int prec, bool bwd, LstmRec &p, unsigned
     *epoch += (unsigned)p.T + 1;
     ClusterGate &gate = cluster_gate();
     std::lock_guard<std::mutex> lock(gate.mu);
-    if (getenv("CN_CLUSTER_GATE_OFF")) {          // probe only (tools/split_probe.py): two resident grids that together fit the chip
+    if (opt().cluster_gate_off) {          // probe only (tools/split_probe.py): two resident grids that together fit the chip
         launch_cluster_shape(s, prec, bwd, p);
         return true;
     }
@@ -1544,10 +1544,10 @@ static bool s2c_applies(int prec, bool bwd, const LstmRec &p)
     // (the COMPILED kernel of the cut measures 25 % slower per step than the 8-wave cluster kernel -- reading B 2.77 -> 3.05 ms, LVCSR
     // 9.88 -> 10.68 ms per fraction: 154 AGPR copies per step and one wave per SIMD to issue them --; it is the twin the
     // hand-written loop is held against, selected with CN_S2C=1.  CN_NO_S2C=1: the 8-wave kernel.)
-    if (!bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2 || getenv("CN_NO_S2C") || getenv("CN_BWD_PSUM")) return false;
+    if (!bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2 || opt().no_s2c || opt().bwd_psum) return false;
     // the hand-written loop addresses activations with 32-bit byte offsets that run 8 steps ahead (as the other hand-written loops);
     // its compiled twin (CN_S2C=1) has no such limit but loses to the 8-wave kernel
-    if (!getenv("CN_S2C") && (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 >= 0xF0000000ull) return false;
+    if (!opt().s2c && (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 >= 0xF0000000ull) return false;
     const int nclusters = p.dirs * (p.PS / 2);
     return (nclusters + 7) / 8 * 8 * 2 <= p.cluster_cus;
 }
@@ -1561,9 +1561,9 @@ static void launch_s2c(hipStream_t s, const LstmRec &p)
         (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)lstm_bwd_s2c_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    const bool hand = !getenv("CN_S2C");
+    const bool hand = !opt().s2c;
     // (one workgroup per CU: each claims the CU's whole LDS so that no gradient-GEMM workgroup is placed beside it, cn_lstm.hip)
-    size_t lds_claim = getenv("CN_NO_LDS_CLAIM") ? lds : (size_t)(160 * 1024 - 1024);
+    size_t lds_claim = opt().no_lds_claim ? lds : (size_t)(160 * 1024 - 1024);
     lstm_note_grid(p, grid);
     hipLaunchKernelGGL(hand ? lstm_bwd_s2c_asm_kernel : lstm_bwd_s2c_kernel, dim3(grid), dim3(256), lds_claim < lds ? lds : lds_claim, s, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, hand ? "lstm_bwd_s2c_asm_kernel" : "lstm_bwd_s2c_kernel");

@@ -1771,9 +1771,9 @@ static size_t s2_lds_bytes(int prec, bool bwd, int Hp, int T)
 // bf16 forward loop (its tail copies), and activations addressable with 32-bit byte offsets
 static bool s2_asm_applies(int prec, bool bwd, const LstmRec &p)
 {
-    if (getenv("CN_NO_S2_ASM") || prec == P_F32 || p.Hp != 128) return false;
+    if (opt().no_s2_asm || prec == P_F32 || p.Hp != 128) return false;
     if (prec == P_BF16 && !bwd && p.T < 4) return false;
-    if (bwd && getenv("CN_NO_S2_ASM_BWD")) return false;
+    if (bwd && opt().no_s2_asm_bwd) return false;
     return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // (+16: offsets run 8 steps ahead)
 }
 
@@ -1785,8 +1785,8 @@ bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
     // split-bf16: only where the hand-written loops exist (Hp = 128).  The mode is bound by the MFMA pipe (32 MFMAs per SIMD and
     // step), which this cut does not relieve, while it takes away the second wave that hides the first one's VALU work: the
     // COMPILED kernels of the cut lose to the 8-wave kernels (CN_S2_X3=1 selects them anyway, for the tests).
-    if (prec == P_X3 && !getenv("CN_S2_X3") && !s2_asm_applies(prec, bwd, p)) return false;
-    if (getenv("CN_NO_S2") || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
+    if (prec == P_X3 && !opt().s2_x3 && !s2_asm_applies(prec, bwd, p)) return false;
+    if (opt().no_s2 || prec == P_F32 || p.rpl != 1 || (p.Hp != 64 && p.Hp != 128) || p.PS % 2) return false;
     if (p.dirs * (p.PS / 2) > p.num_cus) return false;
     return s2_lds_bytes(prec, bwd, p.Hp, p.T) <= 160 * 1024;
 }
@@ -1794,7 +1794,7 @@ bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd)
 // Hp = 256 on one CU (forward pass, bf16): before the 2-CU cluster kernels wherever every pair of sequences gets a CU
 bool lstm_s2w_applies(int prec, const LstmRec &p, bool bwd)
 {
-    if (getenv("CN_NO_S2W") || bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2) return false;
+    if (opt().no_s2w || bwd || prec != P_BF16 || p.Hp != 256 || p.rpl != 1 || p.PS % 2) return false;
     if (p.dirs * (p.PS / 2) > p.num_cus) return false;
     return (unsigned long long)(p.T + 16) * p.PS * p.dirs * 4 * p.Hp * 4 < 0xF0000000ull;     // 32-bit byte offsets, 8 steps ahead
 }
@@ -1806,7 +1806,7 @@ void launch_lstm_s2w(hipStream_t s, bool bwd, const LstmRec &p, hipEvent_t done)
         (void)hipFuncSetAttribute((const void *)lstm_fwd_s2w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)lstm_fwd_s2w_asm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    const bool hand = !getenv("CN_NO_S2W_ASM");
+    const bool hand = !opt().no_s2w_asm;
     const size_t lds = 2 * 5 * (size_t)lds_pitch(256) + 64 + 4 * (size_t)(hand ? S2W_STREAM_COUNT * 2048 : 32768);
     lstm_note_grid(p, p.dirs * (p.PS / 2));
     hipExtLaunchKernelGGL(hand ? lstm_fwd_s2w_asm_kernel : lstm_fwd_s2w_kernel, dim3(p.dirs * (p.PS / 2)), dim3(256), lds, s, nullptr, done, 0, p);
@@ -1824,7 +1824,7 @@ static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
             if (once.first()) (void)hipFuncSetAttribute((const void *)akern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
             size_t lds_claim = lds;
-            if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+            if (p.dirs * (p.PS / 2) <= 128 && !opt().no_lds_claim) lds_claim = 160 * 1024 - 1024;
             lstm_note_grid(p, p.dirs * (p.PS / 2));
             hipExtLaunchKernelGGL(akern, dim3(p.dirs * (p.PS / 2)), dim3(256), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
             if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2%s_asm_kernel", BWD ? "bwd" : "fwd", PREC == P_X3 ? "_x3" : "");
@@ -1837,7 +1837,7 @@ static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
     const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
     // claim the CU's whole LDS so that no workgroup of a concurrently running kernel is placed beside it (cn_lstm.hip)
     size_t lds_claim = lds;
-    if (p.dirs * (p.PS / 2) <= 128 && !getenv("CN_NO_LDS_CLAIM")) lds_claim = 160 * 1024 - 1024;
+    if (p.dirs * (p.PS / 2) <= 128 && !opt().no_lds_claim) lds_claim = 160 * 1024 - 1024;
     lstm_note_grid(p, p.dirs * (p.PS / 2));
     hipExtLaunchKernelGGL(kern, dim3(p.dirs * (p.PS / 2)), dim3(HP * 2), lds_claim < lds ? lds : lds_claim, s, nullptr, done, 0, p);
     if (p.kname) snprintf(p.kname, CN_KNAME_LEN, "lstm_%s_s2_kernel<%d,%d>", BWD ? "bwd" : "fwd", PREC, HP);

@@ -198,6 +198,23 @@ def test_last_arriver_hand_offs_drain_their_memory_operations_before_they_are_co
         assert any("s_waitcnt vmcnt(0)" in body[k] for k in range(adds[-1], barrier)), body[adds[-1]:barrier + 1]
 
 
+def test_no_launch_path_reads_the_environment():
+    """One options block per context (cn_internal.h: CN_OPTION_LIST, filled from the environment once in cn_ctx_create, changed by
+    cn_ctx_set_option): no kernel source file calls getenv any more, and cn_api.cpp / cn_comm_ipc.cpp only where a context or a
+    communicator is CREATED (46 switches were read on launch paths until round 5)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "lstm-rnn_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".inc", ".h")):
+            assert "getenv(" not in open(os.path.join(csrc, name)).read(), name
+    api = open(os.path.join(csrc, "cn_api.cpp")).read()
+    # options_from_env (two macro lines), the RCCL library name, and the four context-level defaults inside cn_ctx_create
+    lines = [l for l in api.splitlines() if "getenv(" in l]
+    assert len(lines) == 8, lines
+    create = api[api.index("int cn_ctx_create("):api.index("int cn_ctx_destroy(")]
+    assert sum("getenv(" in l for l in create.splitlines()) == 5
+
+
 def test_p2p_exchange_drains_every_wave_before_each_flag_store(tmp_path):
     """p2p_allreduce_kernel (cn_comm_p2p.hip) hands staged gradients to its peers through flag words in THEIR regions: READY
     (my staging half is written), REDUCED (my slice of it holds the sums), DONE (my reads of the peers' halves have returned).
