@@ -79,6 +79,17 @@ typedef float real_t;
 static int g_opround = 0;
 void orc_set_operand_rounding(int mode) { g_opround = mode ? 1 : 0; }
 int orc_get_operand_rounding(void) { return g_opround; }
+/*
+ * orc_set_preact_rounding(1) (round 6; only looked at in operand-rounding mode, by the NEXT orc_lstm_forward calls): the gate
+ * pre-activations of the input projection (LstmLayer.cu:771-786) are kept in bf16 WITH the bias term the product's epilogue adds
+ * (x W_in + bias w_b, rounded to nearest even) -- what CN_PREC_BF16 stores between its input-projection GEMM and the recurrent
+ * kernels of the layers that take them in that form (cn_layer_recurrent_kernel: the "_s2_" forward kernels).  The functor
+ * (block_output) keeps adding bias w_b itself, so the model subtracts it again behind the rounding: (bf16(a + b) - b) + b differs
+ * from bf16(a + b) by an fp32 rounding at most, far inside the pinned tolerances.
+ */
+static int g_preround = 0;
+void orc_set_preact_rounding(int on) { g_preround = on ? 1 : 0; }
+int orc_get_preact_rounding(void) { return g_preround; }
 
 static real_t bf16_rne(real_t v)
 {
@@ -376,6 +387,16 @@ void orc_lstm_forward(int P, int L, int bidir, real_t bias, int PS, int maxT, in
     for (int d = 0; d < l.dirs; ++d)
         for (int g = 0; g < 4; ++g)
             mm_tn(l.dir[d][actBuf[g]], w_input(&l, w, g, d), P, H, x, P, N, 0);
+    if (g_opround && g_preround)               /* model only: pre-activations (bias term included) stored in bf16 */
+        for (int d = 0; d < l.dirs; ++d)
+            for (int g = 0; g < 4; ++g) {
+                real_t *a = l.dir[d][actBuf[g]];
+                const real_t *wb = w_bias(&l, w, g, d);
+                for (int i = 0; i < N * H; ++i) {
+                    real_t b = l.bias * wb[i % H];
+                    a[i] = bf16_rne(a[i] + b) - b;
+                }
+            }
 
     /* :812-829 forward states */
     for (int t = 0; t < T; ++t) {

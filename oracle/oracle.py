@@ -71,6 +71,8 @@ def lib():
     L.orc_set_threads.argtypes = [ci]
     L.orc_set_operand_rounding.argtypes = [ci]
     L.orc_get_operand_rounding.restype = ci
+    L.orc_set_preact_rounding.argtypes = [ci]
+    L.orc_get_preact_rounding.restype = ci
     L.orc_get_threads.restype = ci
     L.orc_set_threads(int(os.environ.get("ORACLE_THREADS", "1")))
     _lib = L
@@ -260,9 +262,18 @@ class OracleNetwork:
         for lay in self.layers[1:-1]:
             P, x = lay.prev.size, lay.prev.outputs
             if lay.type in ("lstm", "blstm"):
-                L.orc_lstm_forward(P, lay.size, int(lay.bidir), lay.bias, self.PS, self.maxT,
-                                   self.T, self.Tmin, self.patTypes, lay.weights, x,
-                                   lay.outputs, lay.bufs)
+                # model switch of the operand-rounding mode (C restatement only): this layer's input-projection pre-activations
+                # are stored in bf16 (layer attribute round_preacts, set by the tests from the kernel the HIP path reports)
+                pre = bool(getattr(lay, "round_preacts", False))
+                if pre:
+                    lib().orc_set_preact_rounding(1)
+                try:
+                    L.orc_lstm_forward(P, lay.size, int(lay.bidir), lay.bias, self.PS, self.maxT,
+                                       self.T, self.Tmin, self.patTypes, lay.weights, x,
+                                       lay.outputs, lay.bufs)
+                finally:
+                    if pre:
+                        lib().orc_set_preact_rounding(0)
             elif lay.type == "softmax":
                 L.orc_softmax_forward(P, lay.size, lay.bias, self.N, self.patTypes,
                                       lay.weights, x, lay.outputs, lay.patTmp)

@@ -346,7 +346,7 @@ def test_per_layer_exchange_is_ordered_between_gradient_and_update(pkg):
 def test_library_exchange_is_ordered_between_gradient_and_update(pkg, monkeypatch, net_kind):
     """The same ordering check for the LIBRARY's own exchange (compute_backward_pass_dp = cn_layer_backward + cn_allreduce_grads
     per layer on the library's communication stream, then the fused update): a one-rank communicator is bound and
-    CN_COMM_TEST_DOUBLE replaces ncclAllReduce by a kernel that doubles the layer's weightUpdates on that stream.  Three
+    option comm_test_double (CN_COMM_TEST_DOUBLE) replaces ncclAllReduce by a kernel that doubles the layer's weightUpdates on that stream.  Three
     momentum-SGD steps must equal the plain path at twice the learning rate -- on the headline kernels (hand-written s2
     loops) and on a network of 8-CU cluster kernels (blstm1024: spin-wait hand-off between CUs running beside the
     communication stream's work and the gradient GEMMs of the side stream)."""
@@ -363,7 +363,7 @@ def test_library_exchange_is_ordered_between_gradient_and_update(pkg, monkeypatc
     for mode, lr in (("plain", 2e-4), ("exchange", 1e-4)):
         with pkg.NeuralNetwork(layers, weights, PS, T, precision=pkg.PREC_BF16) as net:
             if mode == "exchange":
-                monkeypatch.setenv("CN_COMM_TEST_DOUBLE", "1")
+                net.set_option("comm_test_double", 1)      # (the context exists: its options no longer follow the environment)
                 net.comm_init(net.comm_unique_id(), 0, 1)
             for _ in range(3):
                 net.load_sequences(frac); net.compute_forward_pass()
