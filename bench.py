@@ -755,6 +755,10 @@ def cpu_baseline(pkg, wl, args, precisions):
         # weights the model reached after the 40 updates, i.e. with peaked posteriors; (ii) the same 40 updates in both.
         with orc.operand_rounding("bf16"):
             refq = orc.OracleNetwork(layers, weights, nseq, tlen)
+            with pkg.NeuralNetwork(layers, weights, nseq, tlen, precision=precisions["bf16"]) as hip:
+                hip.load_sequences(fracs[0]); hip.compute_forward_pass()
+                for name in hip.bf16_preactivation_layers():       # (the model rounds the pre-activations the HIP path keeps in bf16)
+                    refq.layer(name).round_preacts = True
             eq = train(refq)
             yq = refq.outputs().copy()
             refq.calculate_error(); refq.compute_backward_pass()

@@ -184,6 +184,7 @@ struct cn_layer {
 
     // lstm internals
     float *acts = nullptr, *cell = nullptr, *th = nullptr;
+    void *pre16 = nullptr;                // bf16 mode: the input projection's pre-activations as bf16 (LstmRec::pre16), where the forward kernel takes them
     bool err_in_delta = false;            // ff/softmax, bf16 mode: outputErrors of the last backward pass exist only as the bf16 operand copy
     void *delta_op = nullptr;
 
@@ -625,6 +626,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.H = l->H; r.Hp = l->Hp; r.dirs = l->dirs; r.PS = c->PSp; r.T = c->T; r.Tmin = c->Tmin;
     r.pat = c->d_pat;
     r.acts = l->acts; r.cell = l->cell; r.th = l->th; r.y_op = l->out_op; r.Wrec = l->Wrec; r.peep = l->peep_p;
+    r.pre16 = nullptr;
     r.err = l->err; r.delta_op = l->delta_op; r.WrecT = l->WrecT; r.dbias = l->dbias; r.dpeep = l->dpeep;
     r.bias = l->bias;
     r.rpl = c->rpl;
@@ -700,17 +702,26 @@ void lstm_forward(cn_layer *l)
     cn_ctx *c = l->ctx;
     const int R = l->dirs * 4 * l->Hp;
     repack(l);
+    // bf16 mode, two-sequence forward kernels: the pre-activations leave the product as bf16 (8 instead of 16 bytes per unit and
+    // frame -- the product is bound by that store: 72 of the 88 MB a headline launch moved) and the recurrent kernel widens them
+    bool pre16 = false;
+    if (l->pre16) {
+        LstmRec probe; lstm_rec_args(l, probe);
+        pre16 = lstm_cluster_size(c->prec, l->Hp, l->dirs, c->PSp, c->rpl, probe.cluster_cus) == 0 && lstm_fwd_takes_pre16(c->prec, probe);
+    }
     {   // K1: gate pre-activations of all frames, 4 gates x dirs packed into one N = R product
         Timed tm(c, KC_GEMM_WIDE);
         GemmNT g{};
         g.A = l->prev->out_op; g.lda = l->Pp; g.B = l->Win; g.ldb = l->Pp;
         g.C = l->acts; g.ldc = R; g.C2 = nullptr; g.ldc2 = 0; g.bias = l->bias_p; g.act = ACT_IDENTITY;
+        if (pre16) { g.C = nullptr; g.C2 = l->pre16; g.ldc2 = R; }
         g.M = c->N; g.N = R; g.K = l->Pp;
         launch_gemm_nt(c->stream, c->prec, g);
     }
     {   // K2+K3+K4: the whole time loop
         Timed tm(c, KC_REC_FWD);
         LstmRec r; lstm_rec_args(l, r); r.kname = l->kname[0];
+        if (pre16) r.pre16 = l->pre16;
         if (!launch_lstm_cluster(c->stream, c->prec, false, r, &c->xch_epoch)) { check_rec_lds(l, false); launch_lstm_forward(c->stream, c->prec, r); }
         HIP_CHECK(hipGetLastError());
     }
@@ -1315,6 +1326,7 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             l->out_op = dalloc(l, maxN * l->Lp * e);
             l->err = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
             l->acts = (float *)dalloc_guarded(l, maxN * R * sizeof(float), (size_t)ctx->PSp * R * sizeof(float));
+            if (ctx->prec == P_BF16) l->pre16 = dalloc_guarded(l, maxN * R * 2, (size_t)ctx->PSp * R * 2);
             l->cell = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
             l->th = (float *)dalloc_guarded(l, maxN * l->Lp * sizeof(float), (size_t)ctx->PSp * l->Lp * sizeof(float));
             l->delta_op = dalloc(l, maxN * R * e);

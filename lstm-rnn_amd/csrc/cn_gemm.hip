@@ -575,6 +575,11 @@ void launch_gemm_tn(hipStream_t s, int prec, const GemmTN &g, int cu_budget, con
     launch_tn_any(s, prec, &g, 1, extra);
 }
 
+void launch_gemm_tn_small_group(hipStream_t s, int prec, const GemmTN *gs, int n, const FoldItem *extra)
+{
+    launch_tn_any(s, prec, gs, n, extra);
+}
+
 void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget, const FoldItem *extra)
 {
     GemmTN grp[TN_GROUP], big[TN_GROUP]; int ng = 0, nb = 0;

@@ -252,6 +252,11 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
     FoldItem fold[TB_GROUP + 1]; int nfold = 0;
     long all_tiles = 0;
     for (int i = 0; i < n; ++i) all_tiles += (long)((gs[i].M + TB_BM - 1) / TB_BM) * ((gs[i].N + TB_BN - 1) / TB_BN);
+    // The budget is a promise to the recurrent kernel beside this launch (cn_api.cpp: on_side): its cluster grid must find its CUs
+    // free, and a 128 KB-LDS workgroup of this kernel owns a CU.  Splits are cut to the budget below; a group whose TILES alone
+    // exceed it would still put a workgroup on every CU of the chip, so it runs on the small tiles instead (several per CU, no
+    // whole-CU claim).  (Does not happen for the shipped workloads: 24 / 64 tiles against budgets of 100+.)
+    if (cu_budget > 0 && all_tiles > std::min(cu_budget, cus)) { launch_gemm_tn_small_group(s, P_BF16, gs, n, extra); return; }
     int blocks = 0;
     for (int i = 0; i < TB_GROUP; ++i) {
         grp.first_block[i] = blocks;

@@ -42,7 +42,7 @@ enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
     /* recurrent kernel selection */                                                                                              \
     FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
     FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \
-    FLAG(no_s2) FLAG(no_s2w) FLAG(no_s2w_asm)                                                                                     \
+    FLAG(no_s2) FLAG(no_s2w) FLAG(no_s2w_asm) FLAG(no_pre16)                                                                      \
     /* step structure */                                                                                                          \
     FLAG(softmax_exact) FLAG(tail_on_side) FLAG(no_side_rule) FLAG(no_lazy_softmax) FLAG(lazy_softmax) FLAG(comm_test_double)     \
     FLAG(no_loss_defer) FLAG(no_pack_group) FLAG(no_sgd_fuse) NUM(comm_cu_margin, 32)
@@ -118,6 +118,7 @@ bool gemm_tn_big_applies(int prec, const GemmTN &g);    // on its own
 bool gemm_tn_big_can(int prec, const GemmTN &g);        // beside a product that applies (one grouped launch)
 void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_budget = 0, const FoldItem *extra = nullptr);   // n <= 3
 void launch_gemm_tn_group(hipStream_t s, int prec, const GemmTN *gs, int n, int cu_budget = 0, const FoldItem *extra = nullptr);      // up to 3 small products in one launch
+void launch_gemm_tn_small_group(hipStream_t s, int prec, const GemmTN *gs, int n, const FoldItem *extra = nullptr);   // ... on the 64 x 64 / 128 x 128 tiles whatever their size
 
 // ---- recurrent LSTM kernels --------------------------------------------------------------------
 struct LstmRec {
@@ -125,6 +126,8 @@ struct LstmRec {
     const char *pat;              // [T*PS]
     // forward
     float *acts;                  // [N][dirs][Hp][4] fp32: pre-activations in, n/i/f/o activations out (gate innermost)
+    const void *pre16;            // nullable: the pre-activations as bf16 in the same [N][dirs][Hp][4] order (8 bytes per unit and frame);
+                                  // the forward kernel then takes them from here and `acts` is output only (lstm_fwd_takes_pre16)
     float *cell;                  // [N][dirs][Hp]    fp32
     float *th;                    // [N][dirs][Hp]    fp32 tanh(cell state), kept by the forward pass for the backward pass
     void  *y_op;                  // [N][dirs*Hp]     op  (layer output, GEMM operand)
@@ -162,6 +165,9 @@ constexpr int CN_GUARD_STEPS = 6;
 size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T);        // dynamic LDS per workgroup of the single-CU kernels
 bool lstm_rec_resident(int prec, int Hp);                                      // W_rec fragments register resident (single-CU kernels)
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p);
+// does the forward kernel launch_lstm_forward would pick for this shape read bf16 pre-activations (LstmRec::pre16)?  The input
+// projection then writes 8 instead of 16 bytes per unit and frame -- the N-wide product is bound by that store (round 6).
+bool lstm_fwd_takes_pre16(int prec, const LstmRec &p);
 // "s2" shape (cn_lstm_s2.hip): two sequences per workgroup, one wave per SIMD, 32 units per wave; launch_lstm_forward /
 // launch_lstm_backward dispatch to it when it applies
 bool lstm_s2_applies(int prec, const LstmRec &p, bool bwd);

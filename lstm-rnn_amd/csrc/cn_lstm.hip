@@ -981,6 +981,12 @@ size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T)
     return 2 * (size_t)PLANES * (resident ? 16 : 4 * rpl + 1) * pitch + (bwd ? (((size_t)T * 4 * rpl + 15) & ~(size_t)15) : 0);
 }
 
+bool lstm_fwd_takes_pre16(int prec, const LstmRec &p)
+{
+    // the two-sequence kernels of cn_lstm_s2.hip (hand-written loop and its compiled twin), bf16 mode
+    return prec == P_BF16 && !opt().no_pre16 && !lstm_s2w_applies(prec, p, false) && lstm_s2_applies(prec, p, false);
+}
+
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p)
 {
     if (lstm_s2w_applies(prec, p, false)) { launch_lstm_s2w(s, false, p); return; }

@@ -102,7 +102,10 @@ __global__ __launch_bounds__(HP * 2) void lstm_fwd_s2_kernel(LstmRec p)
     auto prefetch = [&](int t, f32x4 &pre, int &pt) {
         t = t < 0 ? 0 : (t >= T ? T - 1 : t);
         pt = (int)at32<unsigned char>(p.pat + (long)t * PS, oP);
-        pre = *(const f32x4 *)&at32<float>(p.acts + t * stepA, oA);
+        if (!X3 && p.pre16) {          // bf16 pre-activations: {n, i} and {f, o} as two dwords, widened by shift / mask like the hand-written loop
+            const uint2 w = *(const uint2 *)((const char *)p.pre16 + ((long)t * stepA + oA) * 2);
+            pre = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+        } else pre = *(const f32x4 *)&at32<float>(p.acts + t * stepA, oA);
     };
 
     // accumulators live across steps (the sparse MFMA accumulates in place): register 0 = even tile row, seeded with the
@@ -245,34 +248,36 @@ __device__ unsigned cn_s2_stamp_buf_f[4][8];
 #ifdef CN_S2_DIAG_HOT
 #define S2A_PF(PX, PT) \
     "global_load_ubyte %[" PT "], %[oT], %[pat]\n\t" \
-    "global_load_dwordx4 " PX ", %[oT], %[acts]\n\t"
+    "global_load_dwordx2 " PX ", %[oT], %[pre]\n\t"
 #else
+// the stage of step t + 2: pattern type and the four bf16 pre-activations (8 bytes: half the fp32 offset; x6 is free here)
 #define S2A_PF(PX, PT) \
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
-    "global_load_dwordx4 " PX ", %[oA], %[actspf]\n\t"
+    "v_lshrrev_b32 %[x6], 1, %[oA]\n\t" \
+    "global_load_dwordx2 " PX ", %[x6], %[prepf]\n\t"
 #endif
 #define S2A_NOPF "s_nop 1\n\t"
-// PX0..PX3: the stage's registers; PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of the tile
+// PX0, PX1: the stage's registers ({n, i} and {f, o} as bf16 pairs, widened into the accumulators by shift / mask); PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of the tile
 // read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
-#define S2A_STEP(PX0, PX1, PX2, PX3, PT, R0, R1, WO, VM, PFCODE) \
+#define S2A_STEP(PX0, PX1, PT, R0, R1, WO, VM, PFCODE) \
     "s_waitcnt vmcnt(" VM ")\n\t" \
     S2A_ST(0) \
     "ds_read_b128 %[a0], %[av0] offset:" R0 "\n\t" \
     "ds_read_b128 %[a1], %[av1] offset:" R0 "\n\t" \
     "ds_read_b128 %[a2], %[av0] offset:" R1 "\n\t" \
     "ds_read_b128 %[a3], %[av1] offset:" R1 "\n\t" \
-    "v_mov_b32 v224, " PX0 "\n\t" \
+    "v_lshlrev_b32 v224, 16, " PX0 "\n\t" \
     "v_mov_b32 v225, 0\n\t" \
-    "v_mov_b32 v228, " PX1 "\n\t" \
+    "v_and_b32 v228, 0xffff0000, " PX0 "\n\t" \
     "v_mov_b32 v229, 0\n\t" \
     "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
     "s_waitcnt lgkmcnt(3)\n\t" \
     S2A_MF("v[224:227]", "a0", "w0n0") \
-    "v_mov_b32 v232, " PX2 "\n\t" \
+    "v_lshlrev_b32 v232, 16, " PX1 "\n\t" \
     "v_mov_b32 v233, 0\n\t" \
     "s_waitcnt lgkmcnt(2)\n\t" \
     S2A_MF("v[224:227]", "a1", "w1n0") \
-    "v_mov_b32 v236, " PX3 "\n\t" \
+    "v_and_b32 v236, 0xffff0000, " PX1 "\n\t" \
     "v_mov_b32 v237, 0\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t" \
     S2A_MF("v[224:227]", "a2", "w0n1") \
@@ -344,8 +349,8 @@ __device__ unsigned cn_s2_stamp_buf_f[4][8];
     S2A_ST(4) \
     "s_barrier\n\t" \
     S2A_ST(5)
-#define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "v242", "v243", "ptA", R0, R1, WO, VM, PFCODE)
-#define S2A_STEP_B(R0, R1, WO, VM, PFCODE) S2A_STEP("v244", "v245", "v246", "v247", "ptB", R0, R1, WO, VM, PFCODE)
+#define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "ptA", R0, R1, WO, VM, PFCODE)
+#define S2A_STEP_B(R0, R1, WO, VM, PFCODE) S2A_STEP("v244", "v245", "ptB", R0, R1, WO, VM, PFCODE)
 
 __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
 {
@@ -393,7 +398,9 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
     unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4, oY = (unsigned)((t0 + BIAS) * stepC * 2) + lC * 2;
     unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
     const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sY = (unsigned)(dt * stepC * 2), sP = (unsigned)(dt * PS);
-    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *actspf = acts + 2 * dt * stepA * 4, *acts1 = acts - dt * stepA * 4;
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *acts1 = acts - dt * stepA * 4;      // (activations out: fp32, one step back)
+    // pre-activations in: bf16, 8 bytes per unit and frame -- the fp32 offsets halved (launch_lstm_s2 requires p.pre16 for this kernel)
+    const char *pre = (const char *)p.pre16 - BIAS * stepA * 2, *prepf = pre + 2 * dt * stepA * 2;
     const char *pat = p.pat - BIAS * PS, *patpf = pat + 2 * dt * PS;
     const char *cell1 = (const char *)p.cell - (BIAS + dt) * stepC * 4, *th1 = (const char *)p.th - (BIAS + dt) * stepC * 4;
     const char *yop1 = (const char *)p.y_op - (BIAS + dt) * stepC * 2;
@@ -417,21 +424,23 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
         "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t"
         // stages of the first two steps
         "global_load_ubyte %[ptA], %[oP], %[pat]\n\t"
-        "global_load_dwordx4 v[240:243], %[oA], %[acts]\n\t"
+        "v_lshrrev_b32 %[x2], 1, %[oA]\n\t"
+        "global_load_dwordx2 v[240:241], %[x2], %[pre]\n\t"
         "v_add_u32 %[x0], %[oP], %[sP]\n\t"
         "v_add_u32 %[x1], %[oA], %[sA]\n\t"
         "global_load_ubyte %[ptB], %[x0], %[pat]\n\t"
-        "global_load_dwordx4 v[244:247], %[x1], %[acts]\n\t"
+        "v_lshrrev_b32 %[x1], 1, %[x1]\n\t"
+        "global_load_dwordx2 v[244:245], %[x1], %[pre]\n\t"
         "s_waitcnt vmcnt(0)\n\t"
         "1:\n\t"
-        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:243]", "ptA"))
-        S2A_STEP_B("800", "864", "0", "10", S2A_PF("v[244:247]", "ptB"))
+        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:241]", "ptA"))
+        S2A_STEP_B("800", "864", "0", "10", S2A_PF("v[244:245]", "ptB"))
         "s_sub_u32 %[np], %[np], 1\n\t"
         "s_cmp_lg_u32 %[np], 0\n\t"
         "s_cbranch_scc1 1b\n\t"
         "s_cmp_eq_u32 %[rem], 3\n\t"
         "s_cbranch_scc0 2f\n\t"
-        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:243]", "ptA"))
+        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:241]", "ptA"))
         S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
         S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
         "s_branch 3f\n\t"
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
           [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]),
           [w0o0] "v"(w[0][3][0]), [w0o1] "v"(w[0][3][1]), [w1o0] "v"(w[1][3][0]), [w1o1] "v"(w[1][3][1]),
           [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
-          [acts] "s"(acts), [actspf] "s"(actspf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
+          [pre] "s"(pre), [prepf] "s"(prepf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
           [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem)
         : "memory", "vcc", "scc",
           "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
@@ -1817,7 +1826,8 @@ template <int PREC, bool BWD, int HP>
 static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
 {
     if constexpr (HP == 128) {
-        if (s2_asm_applies(PREC, BWD, p)) {
+        // (the hand-written bf16 forward loop takes its pre-activations as bf16 only: LstmRec::pre16; without them the compiled twin runs)
+        if (s2_asm_applies(PREC, BWD, p) && (BWD || PREC == P_X3 || p.pre16)) {
             void (*akern)(LstmRec) = PREC == P_X3 ? (BWD ? lstm_bwd_s2_x3_asm_kernel : lstm_fwd_s2_x3_asm_kernel)
                                                   : (BWD ? lstm_bwd_s2_asm_kernel : lstm_fwd_s2_asm_kernel);
             static DeviceOnce once;

@@ -340,6 +340,20 @@ class NeuralNetwork:
                 return self.lib.cn_layer_recurrent_kernel(lay.handle, 1 if backward else 0).decode()
         return ""
 
+    def bf16_preactivation_layers(self):
+        """Names of the LSTM layers whose input projection hands its pre-activations to the recurrent kernel as bf16
+        (CN_PREC_BF16, the two-sequence forward kernels; LstmRec::pre16) -- as of the LAST forward pass, read off the kernel the
+        library reports per layer.  The tests tell the oracle's bf16 model to round exactly those (layer.round_preacts)."""
+        out = []
+        if self.precision != B.PREC_BF16:
+            return out
+        for lay in self.layers:
+            if lay.type in ("lstm", "blstm"):
+                k = self.lib.cn_layer_recurrent_kernel(lay.handle, 0).decode()
+                if "_s2_" in k and self.get_option("no_pre16") == 0:
+                    out.append(lay.name)
+        return out
+
     def _loss(self):
         err, cor = C.c_float(), C.c_int()
         B.check(self.lib.cn_loss_eval(self.layers[-1].handle, C.byref(err), C.byref(cor)), self.ctx)

@@ -27,23 +27,30 @@ ERR_TOL_BF16_PINNED = 5e-3
 
 
 def check_pinned(pkg, orc, layers, weights, frac, PS, kernels=None, post_tol=POSTERIOR_TOL_BF16_PINNED, grad_tol=GRAD_TOL_BF16_PINNED,
-                 internals=False):
+                 internals=False, options=None):
     """HIP bf16 mode against the operand-rounding oracle: posteriors, error, #correct, every gradient, every propagated error
     vector, LSTM layer outputs (bf16 values on both sides)."""
-    threads = orc.get_threads()
-    orc.set_threads(max(threads, 8))
-    try:
-        with orc.operand_rounding("bf16"):
-            ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
-            ref.load_sequences(frac); ref.compute_forward_pass()
-            e_ref = ref.calculate_error(); c_ref = ref.count_correct_classifications()
-            ref.compute_backward_pass()
-    finally:
-        orc.set_threads(threads)
     report = {}
     with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+        for k, v in (options or {}).items():
+            net.set_option(k, v)
         net.load_sequences(frac); net.compute_forward_pass()
         e, c = net.error_and_correct()
+        report["pre16_layers"] = float(len(net.bf16_preactivation_layers()))
+        # the oracle's model of this run: operands of every product in bf16, and the input-projection pre-activations of the layers
+        # whose forward kernel takes them as bf16 (round 6) rounded too
+        threads = orc.get_threads()
+        orc.set_threads(max(threads, 8))
+        try:
+            with orc.operand_rounding("bf16"):
+                ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+                for name in net.bf16_preactivation_layers():
+                    ref.layer(name).round_preacts = True
+                ref.load_sequences(frac); ref.compute_forward_pass()
+                e_ref = ref.calculate_error(); c_ref = ref.count_correct_classifications()
+                ref.compute_backward_pass()
+        finally:
+            orc.set_threads(threads)
         net.compute_backward_pass()
         if kernels:
             assert net.recurrent_kernel(False) == kernels[0], net.recurrent_kernel(False)
@@ -104,6 +111,18 @@ def test_headline_net_hand_written_loops(pkg, orc, T):
     layers, weights, frac, PS = headline_case(pkg, T)
     rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel"))
     print("bf16 pinned, T = %d:" % T, {k: float("%.3g" % v) for k, v in rep.items()})
+
+
+@pytest.mark.parametrize("no_pre16", [0, 1])
+def test_headline_net_with_and_without_bf16_preactivations(pkg, orc, no_pre16):
+    """Round 6: the input projection of the layers that run the two-sequence forward kernels hands its pre-activations over as
+    bf16 (8 instead of 16 bytes per unit and frame; option no_pre16 = 1 keeps fp32 and the compiled kernel).  Both forms are pinned
+    at the same 2e-4 / 2e-3 against the oracle's model of THEIR arithmetic (layer.round_preacts on or off), i.e. the model says what
+    the kernels do; the distance of either form to the fp32 reference stays inside the bf16 mode's 3e-2 (test_gpu_parity.py)."""
+    layers, weights, frac, PS = headline_case(pkg, 67)
+    kern = ("lstm_fwd_s2_kernel<0,128>" if no_pre16 else "lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel")
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=kern, options={"no_pre16": no_pre16})
+    assert rep["pre16_layers"] == (0 if no_pre16 else 3)
 
 
 def test_single_layer_internals_hand_written_loops(pkg, orc):
@@ -241,5 +260,8 @@ def test_peaked_posteriors(pkg, orc):
     print("bf16 pinned, peaked:", {k: float("%.3g" % v) for k, v in rep.items()})
     with orc.operand_rounding("bf16"):
         ref = orc.OracleNetwork(layers, weights, PS, frac["T"])
+        for lay in ref.layers:
+            if lay.type == "blstm":
+                lay.round_preacts = True
         ref.load_sequences(frac); ref.compute_forward_pass()
         assert ref.outputs().reshape(-1, C)[real_mask(frac)].max() > 0.3           # (the case is what it says)
