@@ -55,6 +55,27 @@ def pmc_bytes_per_launch(kernel):
 PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 
 
+def mfma_busy_records(workload):
+    """MFMA-busy per kernel from the newest committed SQ-counter summary (profiles/*_sq.md, made by tools/pmc_sq6.sh from separate
+    rocprofv3 --pmc passes of this bench's command): {kernel: {"chip": share of all SIMD cycles of the chip with an MFMA in the
+    pipe while the kernel runs, "active_cus": the same over the CUs that hold a wave of the kernel}}.  None without a summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.md")))
+    if not files:
+        return None, None
+    out, on = {}, False
+    for line in open(files[-1]):
+        if line.startswith("## "):
+            on = line[3:].strip() == workload
+        elif on and line.startswith("| `"):
+            c = [x.strip() for x in line.strip().strip("|").split("|")]
+            try:
+                out[c[0].strip("`")] = {"chip": float(c[-3]), "active_cus": float(c[-1])}
+            except ValueError:
+                pass
+    return (out or None), os.path.basename(files[-1])
+
+
 def net_desc(P, hidden, C):
     layers = [{"name": "input", "type": "input", "size": P}]
     for i, (t, s) in enumerate(hidden):
@@ -240,6 +261,11 @@ def roofline_records(res, wl, workload, PS, precision, value):
                             "recurrent_tflops": fl_rec * 2 * fr / (pair_ms * 1e-3) / 1e12 if pair_ms else None,
                             "whole_step_tflops": fpf * value / 1e12, "peak": PEAK_MFMA_TFLOPS.get(precision, 2500.0 / 3),
                             "flop_per_frame": fpf, "event_pass_total_ms": total_ms}
+    if precision == "bf16":
+        busy, src = mfma_busy_records(workload)
+        if busy:
+            out["roofline_mfma"]["mfma_busy"] = busy
+            out["roofline_mfma"]["mfma_busy_source"] = src + " (SQ_VALU_MFMA_BUSY_CYCLES / (4 x 32 x GRBM_GUI_ACTIVE) and / (4 x SQ_BUSY_CU_CYCLES))"
     out["roofline_gemm"] = gemm_roofline(wl, precision, tm, fr, res["timing_steps"])
     return out
 
