@@ -679,7 +679,8 @@ void check_rec_lds(const cn_layer *l, bool bwd)
 
 // One layer's weight update + operand copies as one launch of the grouped pack kernel on `st`.
 // mode 1: gradient from the flat weightUpdates; mode 2: from the packed accumulators (unpack fused in, cn_elementwise.hip)
-void launch_layer_update(hipStream_t st, cn_layer *l, int mode, float lr, float mom, hipEvent_t done)
+// folds (mode 2, deterministic mode; nullable): f_in, f_rec[0], f_rec[1], f_bias -- the partial sums the launch adds itself
+void launch_layer_update(hipStream_t st, cn_layer *l, int mode, float lr, float mom, hipEvent_t done, const PackFold *folds = nullptr)
 {
     cn_ctx *c = l->ctx;
     PackGroup grp{};
@@ -691,6 +692,7 @@ void launch_layer_update(hipStream_t st, cn_layer *l, int mode, float lr, float 
     it.update = mode; it.w_rw = l->w; it.wu = l->wu; it.wd = l->wd; it.wu_rw = l->wu;
     it.lr = l->own_lr >= 0.f ? l->own_lr : lr; it.mom = mom;
     it.g_in = l->dWin; it.g_rec = l->dWrec; it.g_bias = l->dbias; it.g_peep = l->dpeep;
+    if (folds) { it.update = 3; it.f_in = folds[0]; it.f_rec[0] = folds[1]; it.f_rec[1] = folds[2]; it.f_bias = folds[3]; }
     launch_pack_group(st, c->f32, grp, done);
     l->dirty = false; l->pack_pending = false; l->updated = true;
 }
@@ -764,13 +766,18 @@ void lstm_backward(cn_layer *l)
     // K9 runs on the side stream: it only feeds weightUpdates, forked AFTER K8 so the critical-path GEMM has the chip to itself, and running beside the
     // preceding layer's recurrent kernel (which occupies ~10 % of the CUs)
     on_side(l, [&](hipStream_t st, hipEvent_t join) {
+        // deterministic mode with the armed, fused update behind the products: that launch adds the partial sums itself (no fold
+        // launch at all); otherwise one fold launch rides behind the grouped product
+        const bool fused = armed_fused(l);
+        const bool defer = c->det && fused;
+        int used_in = 0, used_rec[2] = {0, 0};
         {   // K9 input weights: dWin[r][i] = sum_n delta[n][r] x[n][i]
             Timed tm(c, KC_GEMM_GRAD, st);
             GemmTN gs[3]; int ng = 0;
             GemmTN g{};
             g.A = l->delta_op; g.lda = R; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = R; g.N = l->Pp; g.K = N;
-            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; }
+            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; g.ws_used = defer ? &used_in : nullptr; }
             gs[ng++] = g;
             // K9 recurrent weights: dWrec[(j,g)][i] = sum_t delta[t][(j,g)] y[prev(t)][i]
             if (N > PS) {
@@ -782,7 +789,7 @@ void lstm_backward(cn_layer *l)
                     else        { r.A = dl; r.B = y + (size_t)PS * l->Lp * e; }                   // skipLastPattern,  :428-431
                     r.lda = R; r.ldb = l->Lp;
                     r.C = l->dWrec + (size_t)d * 4 * Hp * Hp; r.ldc = Hp; r.M = 4 * Hp; r.N = Hp; r.K = N - PS;
-                    if (c->det) { r.ws = l->det_ws + (size_t)DET_MAX_SPLITS * ((size_t)R * l->Pp + (size_t)d * 4 * Hp * Hp); r.ws_splits = DET_MAX_SPLITS; }
+                    if (c->det) { r.ws = l->det_ws + (size_t)DET_MAX_SPLITS * ((size_t)R * l->Pp + (size_t)d * 4 * Hp * Hp); r.ws_splits = DET_MAX_SPLITS; r.ws_used = defer ? &used_rec[d] : nullptr; }
                     gs[ng++] = r;
                 }
             }
@@ -790,12 +797,19 @@ void lstm_backward(cn_layer *l)
             // the gradient block and in a slot alike), in the launch that adds the products' split partials
             const int slot = 7 * l->dirs * Hp;
             const FoldItem f{l->dbias, l->gpart, (long)slot, det_grid, 1, slot, slot, 1, 1};
-            launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus, c->det ? &f : nullptr);      // the three products side by side in one launch
+            launch_gemm_tn_group(st, c->prec, gs, ng, c->tn_cus, (c->det && !defer) ? &f : nullptr);      // the three products side by side in one launch
         }
         {
             Timed tm(c, KC_OTHER, st);
-            if (armed_fused(l)) launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join);
-            else launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu, join);
+            if (fused) {
+                const int slot = 7 * l->dirs * Hp;
+                const PackFold folds[4] = {
+                    {l->det_ws, (long)R * l->Pp, used_in, 0},
+                    {l->det_ws ? l->det_ws + (size_t)DET_MAX_SPLITS * (size_t)R * l->Pp : nullptr, 4L * Hp * Hp, used_rec[0], 0},
+                    {l->det_ws ? l->det_ws + (size_t)DET_MAX_SPLITS * ((size_t)R * l->Pp + (size_t)4 * Hp * Hp) : nullptr, 4L * Hp * Hp, used_rec[1], 0},
+                    {l->gpart, (long)slot, det_grid, 1}};
+                launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join, defer ? folds : nullptr);
+            } else launch_lstm_unpack_grads(st, lstm_geom(l), l->dWin, l->dWrec, l->dbias, l->dpeep, l->wu, join);
         }
         return join != nullptr;
     }, fork_attached);
@@ -877,18 +891,25 @@ void ff_backward(cn_layer *l)
         fork_attached = fork != nullptr;
     }
     on_side(l, [&](hipStream_t st, hipEvent_t join) {
+        const bool fused = armed_fused(l);
+        const bool defer = c->det && fused;
+        int used_in = 0;
         {   // FeedForwardLayer.cu:200-207
             Timed tm(c, KC_GEMM_GRAD, st);
             GemmTN g{};
             g.A = l->delta_op; g.lda = l->Lp; g.B = l->prev->out_op; g.ldb = l->Pp;
             g.C = l->dWin; g.ldc = l->Pp; g.M = l->Lp; g.N = l->Pp; g.K = N;
-            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; }
-            launch_gemm_tn(st, c->prec, g, c->tn_cus, colfold.nparts ? &colfold : nullptr);
+            if (c->det) { g.ws = l->det_ws; g.ws_splits = DET_MAX_SPLITS; g.ws_used = defer ? &used_in : nullptr; }
+            launch_gemm_tn(st, c->prec, g, c->tn_cus, (colfold.nparts && !defer) ? &colfold : nullptr);
         }
         {
             Timed tm(c, KC_OTHER, st);
-            if (armed_fused(l)) launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join);
-            else launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu, join);
+            if (fused) {
+                // (the column sums' partial rows: colfold describes them; its target, the packed bias gradient, stays zero)
+                const PackFold folds[4] = {{l->det_ws, (long)l->Lp * l->Pp, used_in, 0}, {nullptr, 0, 0, 0}, {nullptr, 0, 0, 0},
+                                           {colfold.part, colfold.stride, colfold.nparts, 0}};
+                launch_layer_update(st, l, 2, c->arm_lr, c->arm_mom, join, defer ? folds : nullptr);
+            } else launch_ff_unpack_grads(st, ff_geom(l), l->bias, l->dWin, l->dbias, l->wu, join);
         }
         return join != nullptr;
     }, fork_attached);

@@ -48,12 +48,40 @@ __device__ __forceinline__ int pad_col(int i, int prevH, int prevHp)
 // feed-forward layer is bias * column sum, FeedForwardLayer.cu:94-100): it is read, cleared for the next backward pass and
 // written to the flat weightUpdates on the way (what lstm_unpack_kernel / ff_unpack_kernel do in the unfused sequence).
 struct PackUpd { float *w_rw; const float *wu; float *wd; float lr, mom; float *wu_rw; };
+// deterministic mode: the partial sums of this entry, added in order -- ((p0 + p1) + p2) + ..., exactly fold_kernel's sum
+// (sixteen loads in flight per batch: the bias / peephole sums have one partial per backward workgroup -- 52 on the headline --
+// and four at a time made the launch 11 us longer, a chain of thirteen L2 round trips per thread)
+__device__ __forceinline__ float pack_fold(const PackFold &f, long off)
+{
+    float *p = f.part + off;
+    float t = 0.f;
+    for (int s = 0; s < f.nparts; s += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = s + k < f.nparts ? p[(long)k * f.stride] : 0.f;
+        if (f.clear) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) if (s + k < f.nparts) p[(long)k * f.stride] = 0.f;
+        }
+        if (s == 0) t = v[0]; else t += v[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) if (s + k < f.nparts) t += v[k];      // (never adds a padding zero: -0 + 0 would change the sign)
+        p += 16 * f.stride;
+    }
+    return t;
+}
 template <int UPD>
-__device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, long fi, float *gp = nullptr, float gscale = 1.0f)
+__device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, long fi, float *gp = nullptr, float gscale = 1.0f,
+                                            const PackFold *fold = nullptr, long foff = 0)
 {
     if constexpr (UPD != 0) {
         float g;
-        if constexpr (UPD == 2) { g = *gp; *gp = 0.f; if (gscale != 1.0f) g = __fmul_rn(gscale, g); u.wu_rw[fi] = g; }
+        if constexpr (UPD == 3) {          // deterministic mode: this launch adds the stored partial sums itself (a variant of its own:
+            if (fold->nparts) g = pack_fold(*fold, foff);        // with the loop inside the UPD = 2 code every launch of the default mode
+            else { g = *gp; *gp = 0.f; }                          // paid ~11 us for it); the packed accumulator itself was never written
+            if (gscale != 1.0f) g = __fmul_rn(gscale, g);
+            u.wu_rw[fi] = g;
+        } else if constexpr (UPD == 2) { g = *gp; *gp = 0.f; if (gscale != 1.0f) g = __fmul_rn(gscale, g); u.wu_rw[fi] = g; }
         else g = u.wu[fi];
         const float dl = __fsub_rn(__fmul_rn(u.mom, u.wd[fi]), __fmul_rn(u.lr, g));          // SteepestDescentOptimizer.cu:51
         u.wd[fi] = dl;
@@ -62,7 +90,7 @@ __device__ __forceinline__ float pack_fetch(const float *w, const PackUpd &u, lo
         return v;
     } else return w[fi];
 }
-struct PackGrad { float *g_in, *g_rec, *g_bias, *g_peep; };
+struct PackGrad { float *g_in, *g_rec, *g_bias, *g_peep; PackFold f_in, f_rec[2], f_bias; };
 
 // (first / count: the workgroups [first, first + count) of the launch work on this layer: pack_group_kernel)
 template <bool F32, int UPD = 0>
@@ -82,7 +110,8 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             const int d = r / (4 * Hp), j = (r / 4) % Hp, gg = r % 4;
             const int i = unpad_col(pc, P, g.prevH, g.prevHp, g.prevDirs);
             float v = 0.f;
-            if (j < H && i >= 0) v = pack_fetch<UPD>(w, upd, (long)gg * L * P + (long)d * H * P + (long)j * P + i, pg.g_in + (long)r * Pp + pc);   // dWin[r][pc]
+            if (j < H && i >= 0) v = pack_fetch<UPD>(w, upd, (long)gg * L * P + (long)d * H * P + (long)j * P + i, pg.g_in + (long)r * Pp + pc, 1.0f,
+                                                     &pg.f_in, (long)r * Pp + pc);   // dWin[r][pc]
             st_op<F32>(Win, (long)r * Pp + pc, v);
             st_op<F32>(WinT, (long)pc * R + r, v);
         } else if (idx < nIn + nRec) {
@@ -92,17 +121,19 @@ __device__ __forceinline__ void lstm_pack_body(const LstmGeom &g, float bias, co
             float v = 0.f;
             if (j < H && i < H)
                 v = pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + (long)gg * L * H + (long)d * H * H + (long)j * H + i,
-                                    pg.g_rec + ((long)d * 4 * Hp + 4 * j + gg) * Hp + i);                                    // dWrec[d][4j + g][i]
+                                    pg.g_rec + ((long)d * 4 * Hp + 4 * j + gg) * Hp + i, 1.0f,
+                                    &pg.f_rec[d & 1], (long)(4 * j + gg) * Hp + i);                                          // dWrec[d][4j + g][i]
             st_op<F32>(Wrec, ((long)d * 4 * Hp + gg * Hp + j) * Hp + i, v);
             st_op<F32>(WrecT, ((long)d * Hp + i) * 4 * Hp + 4 * j + gg, v);
         } else if (idx < nIn + nRec + nB) {
             const int k = idx - nIn - nRec;
             const int d = k / (4 * Hp), j = (k / 4) % Hp, gg = k % 4;
-            bias_p[k] = (j < H) ? bias * pack_fetch<UPD>(w, upd, 4L * L * P + gg * L + d * H + j, pg.g_bias + k) : 0.f;   // LstmLayer.cu:97-100
+            bias_p[k] = (j < H) ? bias * pack_fetch<UPD>(w, upd, 4L * L * P + gg * L + d * H + j, pg.g_bias + k, 1.0f, &pg.f_bias, k) : 0.f;   // LstmLayer.cu:97-100
         } else {
             const int k = idx - nIn - nRec - nB;
             const int d = k / (3 * Hp), pp = (k / Hp) % 3, j = k % Hp;
-            peep_p[k] = (j < H) ? pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j, pg.g_peep + k) : 0.f;
+            peep_p[k] = (j < H) ? pack_fetch<UPD>(w, upd, 4L * L * (P + 1) + 4L * L * H + pp * L + d * H + j, pg.g_peep + k, 1.0f,
+                                                  &pg.f_bias, nB + k) : 0.f;      // (a slot: the bias sums, then the peephole sums)
         }
     }
 }
@@ -176,12 +207,12 @@ __device__ __forceinline__ void ff_pack_body(const FfGeom &g, float bias, const 
         if (idx < nW) {
             const int j = idx / g.Pp, pc = idx % g.Pp;
             const int i = unpad_col(pc, g.P, g.prevH, g.prevHp, g.prevDirs);
-            float v = (j < g.L && i >= 0) ? pack_fetch<UPD>(w, upd, (long)j * g.P + i, pg.g_in + (long)j * g.Pp + pc) : 0.f;
+            float v = (j < g.L && i >= 0) ? pack_fetch<UPD>(w, upd, (long)j * g.P + i, pg.g_in + (long)j * g.Pp + pc, 1.0f, &pg.f_in, (long)j * g.Pp + pc) : 0.f;
             st_op<F32>(W, (long)j * g.Pp + pc, v);
             st_op<F32>(WT, (long)pc * g.Lp + j, v);
         } else {
             const int j = idx - nW;
-            bias_p[j] = (j < g.L) ? bias * pack_fetch<UPD>(w, upd, (long)g.L * g.P + j, pg.g_bias + j, bias) : 0.f;            // FeedForwardLayer.cu:59
+            bias_p[j] = (j < g.L) ? bias * pack_fetch<UPD>(w, upd, (long)g.L * g.P + j, pg.g_bias + j, bias, &pg.f_bias, j) : 0.f;            // FeedForwardLayer.cu:59
         }
     }
 }
@@ -204,9 +235,15 @@ __global__ void pack_group_kernel(PackGroup grp)
     if (it.update) {      // cn_sgd_update_all: the weight update rides on the pack (one launch instead of two on the critical tail)
         const PackUpd upd{it.w_rw, it.wu, it.wd, it.lr, it.mom, it.wu_rw};
         if (it.update == 2) {   // armed update: ... and so does the unpacking of the gradient
-            const PackGrad pg{it.g_in, it.g_rec, it.g_bias, it.g_peep};
+            const PackGrad pg{it.g_in, it.g_rec, it.g_bias, it.g_peep, {}, {{}, {}}, {}};
             if (it.lstm) lstm_pack_body<F32, 2>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd, pg);
             else         ff_pack_body<F32, 2>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd, pg);
+            return;
+        }
+        if (it.update == 3) {   // ... in deterministic mode, from the partial sums the producers stored (PackFold)
+            const PackGrad pg{it.g_in, it.g_rec, it.g_bias, it.g_peep, it.f_in, {it.f_rec[0], it.f_rec[1]}, it.f_bias};
+            if (it.lstm) lstm_pack_body<F32, 3>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd, pg);
+            else         ff_pack_body<F32, 3>(it.fg, it.bias, it.w, it.Win, it.WinT, it.bias_p, grp.first[i], count, upd, pg);
             return;
         }
         if (it.lstm) lstm_pack_body<F32, 1>(it.lg, it.bias, it.w, it.Win, it.WinT, it.Wrec, it.WrecT, it.bias_p, it.peep_p, grp.first[i], count, upd);

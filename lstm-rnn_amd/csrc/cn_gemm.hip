@@ -523,7 +523,8 @@ static void launch_tn(hipStream_t s, const GemmTN *gs, int n, const FoldItem *ex
         splits = (g.K + kchunk - 1) / kchunk;
         grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk;
         blocks += ntiles * splits;
-        if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
+        if (g.ws && g.ws_used) *g.ws_used = splits;        // (the caller's consumer adds the partials itself)
+        else if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
     }
     grp.first_block[TN_GROUP] = blocks;
     if (extra) fold[nfold++] = *extra;

@@ -276,7 +276,8 @@ void launch_gemm_tn_big_group(hipStream_t s, const GemmTN *gs, int n, int cu_bud
         splits = (g.K + kchunk - 1) / kchunk;
         grp.p[i] = g; grp.tiles_n[i] = tiles_n; grp.ntiles[i] = ntiles; grp.kchunk[i] = kchunk; grp.splits[i] = splits;
         blocks += 8 * ((ntiles * splits + 7) / 8);
-        if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
+        if (g.ws && g.ws_used) *g.ws_used = splits;
+        else if (g.ws) fold[nfold++] = FoldItem{g.C, g.ws, (long)g.M * g.ldc, splits, g.M, g.N, (int)g.ldc, 0, 0};
     }
     grp.first_block[TB_GROUP] = blocks;
     hipLaunchKernelGGL(gemm_tn_big_kernel, dim3(blocks), dim3(512), TB_LDS, s, grp);

@@ -92,6 +92,9 @@ struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), f
     // C) and a second launch adds the partials IN SPLIT ORDER into C -- the sum over the frames no longer depends on the order in
     // which workgroups retire (ComputeWeightUpdateFn, LstmLayer.cu:289-512, is one serial sum per weight).  nullptr: fp32 atomics.
     float *ws; int ws_splits;     // workspace of ws_splits * M * ldc floats; the launcher never cuts K into more splits than that
+    // ws_used (host pointer, nullable): the launcher writes the number of splits it cut there and does NOT launch the fold -- the
+    // caller's consumer adds the partials itself (pack_group_kernel in its update = 2 form: no extra launch behind the product)
+    int *ws_used;
 };
 constexpr int DET_MAX_SPLITS = 8;
 // dst[r][c] (+)= part[0][r][c] + part[1][r][c] + ... in that order, r < rows, c < cols (partials share dst's pitch `ld`, one every
@@ -198,6 +201,9 @@ void launch_lstm_unpack_grads(hipStream_t s, const LstmGeom &g, float *dWin, flo
 struct FfGeom { int P, Pp, L, Lp; int prevH, prevHp, prevDirs; };
 // all trainable layers' operand copies in one launch
 constexpr int PACK_GROUP_MAX = 8;
+// deterministic mode, update == 2: where the partial sums of one packed gradient array lie (nparts == 0: read the packed
+// accumulator itself).  The consumer adds part[0], part[stride], ... in that order -- the sum launch_fold would have formed.
+struct PackFold { float *part; long stride; int nparts, clear; };
 struct PackItem {
     int lstm; LstmGeom lg; FfGeom fg; float bias; const float *w;
     void *Win, *WinT, *Wrec, *WrecT; float *bias_p, *peep_p;
@@ -208,6 +214,9 @@ struct PackItem {
     // GEMMs / recurrent kernel summed into (every packed position is visited by exactly one thread, which also clears it and
     // writes the flat weightUpdates entry): unpack + update + operand copies in ONE launch behind the layer's gradient GEMMs
     float *wu_rw; float *g_in, *g_rec, *g_bias, *g_peep;      // lstm: dWin, dWrec, dbias, dpeep; ff: dW (g_in), colsum (g_bias)
+    // update == 3: ... in deterministic mode from the partial sums their producers stored (PackFold): dWin's splits, dWrec's per direction,
+    // the backward workgroups' bias / peephole slots (peephole entries R floats into a slot) or the column-sum rows
+    PackFold f_in, f_rec[2], f_bias;
 };
 struct PackGroup { PackItem item[PACK_GROUP_MAX]; int first[PACK_GROUP_MAX]; int n; };
 void launch_pack_group(hipStream_t s, bool f32, PackGroup &grp, hipEvent_t done = nullptr);

@@ -29,11 +29,13 @@ def _learnable(pkg, rng, P, C, nseq, tlen, nfrac=2):
     return fracs
 
 
-def _train(pkg, layers, weights, fracs, PS, T, prec, det, updates, lr=5e-4):
+def _train(pkg, layers, weights, fracs, PS, T, prec, det, updates, lr=5e-4, armed=False):
     with pkg.NeuralNetwork(layers, weights, PS, T, precision=prec, deterministic=det) as net:
         errs = []
         for k in range(updates):
             net.load_sequences(fracs[k % len(fracs)]); net.compute_forward_pass(); errs.append(net.calculate_error())
+            if armed:
+                net.arm_update(lr, 0.9)        # every layer's update rides on the launch behind its gradient products (bench.py's step)
             net.compute_backward_pass(); net.update_weights_fused(lr, 0.9)
         g = [l.weight_updates().copy() for l in net.trainable_layers()]
         w = [l.weights().copy() for l in net.trainable_layers()]
@@ -59,6 +61,26 @@ def test_headline_net_trains_to_the_same_bits_twice(pkg, mode):
         assert np.array_equal(a, b), (mode, float(np.abs(a - b).max()))
     for a, b in zip(w0, w1):
         assert np.array_equal(a, b), (mode, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_armed_update_adds_the_partials_itself_and_gets_the_same_bits(pkg, mode):
+    """With cn_ctx_arm_update the launch that unpacks a layer's gradient, applies the momentum step and rebuilds the operand copies
+    (pack_group_kernel, update = 2) ALSO adds the stored partial sums (PackFold) -- no fold launch at all on bench.py's step.  It
+    forms the same sums in the same order as the fold launch of the unarmed path: 12 updates either way end in the same bits, and
+    the armed run repeats itself."""
+    rng = np.random.RandomState(92)
+    P, C, PS, T = 39, 183, 50, 48
+    layers = net_desc(P, [("blstm", 250)] * 2, C)
+    weights = random_weights(layers, rng, 0.1)
+    fracs = _learnable(pkg, rng, P, C, PS, T)
+    prec = {"f32": pkg.PREC_F32, "bf16": pkg.PREC_BF16}[mode]
+    plain = _train(pkg, layers, weights, fracs, PS, T, prec, True, 12)
+    armed = [_train(pkg, layers, weights, fracs, PS, T, prec, True, 12, armed=True) for _ in range(2)]
+    for run in armed:
+        assert run[0] == plain[0], mode
+        for a, b in zip(run[1] + run[2], plain[1] + plain[2]):
+            assert np.array_equal(a, b), (mode, float(np.abs(a - b).max()))
 
 
 def test_option_default_and_switch(pkg):
