@@ -277,7 +277,7 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
     const long below = opt().nt_bm64_below;
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + NT_BN - 1) / NT_BN);
     const int elt = prec == P_BF16 ? 2 : 4;
-    const bool small = tiles128 < below || ((long)g.K * elt <= 4 * NT_ROWB && tiles128 < 1100);
+    const bool small = tiles128 < below || ((long)g.K * elt <= 4 * NT_ROWB && tiles128 < opt().nt_bm64_shortk_tiles);
 #define CN_NT_DISPATCH(P) { if (small) launch_nt<P, 64>(s, g, done); else launch_nt<P, 128>(s, g, done); }
     if (prec == P_F32) CN_NT_DISPATCH(P_F32)
     else if (prec == P_X3) CN_NT_DISPATCH(P_X3)

@@ -215,7 +215,7 @@ bool gemm_nt_mid_applies(int prec, const GemmNT &g)
     if ((unsigned long long)g.M * g.lda * 2 >= 0xfffffff0ull || (unsigned long long)g.N * g.ldb * 2 >= 0xfffffff0ull) return false;
     // (from 1000 tiles on and K >= 512 the persistent 256 x 256 kernel takes the product: launch_gemm_nt_big)
     const long tiles = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
-    return tiles >= 384 && (tiles < 1000 || g.K < 512);
+    return tiles >= opt().nt_mid_min_tiles && (tiles < 1000 || g.K < 512);
 }
 
 void launch_gemm_nt_mid(hipStream_t s, const GemmNT &g, hipEvent_t done)

@@ -38,7 +38,7 @@ enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
 #define CN_OPTION_LIST(FLAG, NUM)                                                                                                  \
     /* GEMM selection */                                                                                                          \
     FLAG(no_big_gemm) FLAG(no_big8) NUM(big8_min_k, 0) FLAG(no_nt_mid) FLAG(no_big_tn) NUM(nt_bm64_below, 400) NUM(tn_blocks, 0) \
-    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000)                                                                             \
+    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000) NUM(nt_mid_min_tiles, 384) NUM(nt_bm64_shortk_tiles, 1100)                                                                           \
     /* recurrent kernel selection */                                                                                              \
     FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
     FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \

@@ -343,7 +343,7 @@ class NeuralNetwork:
     def bf16_preactivation_layers(self):
         """Names of the LSTM layers whose input projection hands its pre-activations to the recurrent kernel as bf16
         (CN_PREC_BF16, the two-sequence forward kernels; LstmRec::pre16) -- as of the LAST forward pass, read off the kernel the
-        library reports per layer.  The tests tell the oracle's bf16 model to round exactly those (layer.round_preacts)."""
+        library reports per layer.  (The parity tests model the rounding of exactly those layers.)"""
         out = []
         if self.precision != B.PREC_BF16:
             return out
