@@ -245,10 +245,17 @@ def roofline_records(res, wl, workload, PS, precision, value):
                 "share_of_device_time": ms / total_ms}
 
     out = {}
-    bwd_dom = tm["rec_bwd"][0] >= tm["rec_fwd"][0]        # the larger share, whichever it is
+    # the larger share of device time, whichever it is; two shares within 1.5 % of each other are a tie inside the run-to-run spread
+    # of the event times (headline: 116.5 against 116.2 us per launch) -- then the backward kernel, which moves the more bytes
+    # (64 against 44 B per unit-frame) and is the one every earlier round reported, so the series stays comparable and the record
+    # does not flip between 0.25 and 0.18 on a coin toss; `roofline_other` carries the other kernel either way
+    tie = abs(tm["rec_bwd"][0] - tm["rec_fwd"][0]) <= 0.015 * max(tm["rec_bwd"][0], tm["rec_fwd"][0])
+    bwd_dom = tie or tm["rec_bwd"][0] >= tm["rec_fwd"][0]
     out["roofline"] = roof(bwd_dom)
-    out["roofline"]["note"] = ("latency-bound persistent kernel (T sequential steps); per-class device time [ms] "
-                               "over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items()))
+    out["roofline"]["note"] = ("latency-bound persistent kernel (T sequential steps); " +
+                               ("forward and backward kernel tie in device time (within 1.5 %): the backward kernel is reported, the forward one "
+                                "is `roofline_other`; " if tie else "") +
+                               "per-class device time [ms] over the event-timed pass: " + ", ".join("%s=%.2f" % (k, v[0]) for k, v in tm.items()))
     out["roofline_other"] = roof(not bwd_dom)
     pair_ms = tm["rec_fwd"][0] + tm["rec_bwd"][0]
     pair_bytes = (b_fwd + b_bwd) * fr
