@@ -42,7 +42,7 @@ enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
     /* recurrent kernel selection */                                                                                              \
     FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
     FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \
-    FLAG(no_s2) FLAG(no_s2w) FLAG(no_s2w_asm) FLAG(no_pre16)                                                                      \
+    FLAG(no_s2) FLAG(no_s2w) FLAG(no_s2w_asm) FLAG(pre16)                                                                           \
     /* step structure */                                                                                                          \
     FLAG(softmax_exact) FLAG(tail_on_side) FLAG(no_side_rule) FLAG(no_lazy_softmax) FLAG(lazy_softmax) FLAG(comm_test_double)     \
     FLAG(no_loss_defer) FLAG(no_pack_group) FLAG(no_sgd_fuse) NUM(comm_cu_margin, 32)

@@ -984,7 +984,7 @@ size_t lstm_rec_lds_bytes(int prec, bool bwd, int Hp, int rpl, int T)
 bool lstm_fwd_takes_pre16(int prec, const LstmRec &p)
 {
     // the two-sequence kernels of cn_lstm_s2.hip (hand-written loop and its compiled twin), bf16 mode
-    return prec == P_BF16 && !opt().no_pre16 && !lstm_s2w_applies(prec, p, false) && lstm_s2_applies(prec, p, false);
+    return prec == P_BF16 && opt().pre16 && !lstm_s2w_applies(prec, p, false) && lstm_s2_applies(prec, p, false);
 }
 
 void launch_lstm_forward(hipStream_t s, int prec, const LstmRec &p)

@@ -245,39 +245,57 @@ __device__ unsigned cn_s2_stamp_buf_f[4][8];
 #define S2A_K1 "0xbfb8aa3b"     /* -log2(e)   */
 #define S2A_K2 "0xc038aa3b"     /* -2 log2(e) */
 #define S2A_MF(acc, a, w) "v_smfmac_f32_16x16x64_bf16 " acc ", %[" a "], %[" w "], %[spidx]\n\t"
+// Two forms of the loop text, one operand list (lstm_fwd_s2_asm_kernel<PRE16>):
+//   32: fp32 pre-activations (the default): the stage is four dwords, copied into the accumulators;
+//   16: bf16 pre-activations (option pre16, LstmRec::pre16): the stage is two dwords {n, i} / {f, o}, widened by the shift / mask
+//       that takes the place of the copy (no extra instruction); the load sits at half the fp32 offset (x6 is free there).
 #ifdef CN_S2_DIAG_HOT
-#define S2A_PF(PX, PT) \
+#define S2A_PF32(PX4, PX2, PT) \
     "global_load_ubyte %[" PT "], %[oT], %[pat]\n\t" \
-    "global_load_dwordx2 " PX ", %[oT], %[pre]\n\t"
+    "global_load_dwordx4 " PX4 ", %[oT], %[acts]\n\t"
+#define S2A_PF16(PX4, PX2, PT) \
+    "global_load_ubyte %[" PT "], %[oT], %[pat]\n\t" \
+    "global_load_dwordx2 " PX2 ", %[oT], %[pre]\n\t"
 #else
-// the stage of step t + 2: pattern type and the four bf16 pre-activations (8 bytes: half the fp32 offset; x6 is free here)
-#define S2A_PF(PX, PT) \
+#define S2A_PF32(PX4, PX2, PT) \
+    "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
+    "global_load_dwordx4 " PX4 ", %[oA], %[actspf]\n\t"
+#define S2A_PF16(PX4, PX2, PT) \
     "global_load_ubyte %[" PT "], %[oP], %[patpf]\n\t" \
     "v_lshrrev_b32 %[x6], 1, %[oA]\n\t" \
-    "global_load_dwordx2 " PX ", %[x6], %[prepf]\n\t"
+    "global_load_dwordx2 " PX2 ", %[x6], %[prepf]\n\t"
 #endif
+// the four accumulator seeds of a step (n, i, f, o) from its stage registers P0 .. P3 (form 16 uses P0, P1 only)
+#define S2A_SEED32_N(P0, P1, P2, P3) "v_mov_b32 v224, " P0 "\n\t"
+#define S2A_SEED32_I(P0, P1, P2, P3) "v_mov_b32 v228, " P1 "\n\t"
+#define S2A_SEED32_F(P0, P1, P2, P3) "v_mov_b32 v232, " P2 "\n\t"
+#define S2A_SEED32_O(P0, P1, P2, P3) "v_mov_b32 v236, " P3 "\n\t"
+#define S2A_SEED16_N(P0, P1, P2, P3) "v_lshlrev_b32 v224, 16, " P0 "\n\t"
+#define S2A_SEED16_I(P0, P1, P2, P3) "v_and_b32 v228, 0xffff0000, " P0 "\n\t"
+#define S2A_SEED16_F(P0, P1, P2, P3) "v_lshlrev_b32 v232, 16, " P1 "\n\t"
+#define S2A_SEED16_O(P0, P1, P2, P3) "v_and_b32 v236, 0xffff0000, " P1 "\n\t"
 #define S2A_NOPF "s_nop 1\n\t"
-// PX0, PX1: the stage's registers ({n, i} and {f, o} as bf16 pairs, widened into the accumulators by shift / mask); PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of the tile
-// read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
-#define S2A_STEP(PX0, PX1, PT, R0, R1, WO, VM, PFCODE) \
+// FORM: 32 / 16 (above); P0 .. P3: the stage's registers; PT: its pattern-type operand; R0 / R1: LDS byte offsets of K chunk 0 / 1 of
+// the tile read, WO: of the tile written; VM: outstanding vector-memory operations that may stay in flight at the top
+#define S2A_STEP(FORM, P0, P1, P2, P3, PT, R0, R1, WO, VM, PFCODE) \
     "s_waitcnt vmcnt(" VM ")\n\t" \
     S2A_ST(0) \
     "ds_read_b128 %[a0], %[av0] offset:" R0 "\n\t" \
     "ds_read_b128 %[a1], %[av1] offset:" R0 "\n\t" \
     "ds_read_b128 %[a2], %[av0] offset:" R1 "\n\t" \
     "ds_read_b128 %[a3], %[av1] offset:" R1 "\n\t" \
-    "v_lshlrev_b32 v224, 16, " PX0 "\n\t" \
+    S2A_SEED##FORM##_N(P0, P1, P2, P3) \
     "v_mov_b32 v225, 0\n\t" \
-    "v_and_b32 v228, 0xffff0000, " PX0 "\n\t" \
+    S2A_SEED##FORM##_I(P0, P1, P2, P3) \
     "v_mov_b32 v229, 0\n\t" \
     "v_cmp_eq_u32 vcc, 0, %[" PT "]\n\t" \
     "s_waitcnt lgkmcnt(3)\n\t" \
     S2A_MF("v[224:227]", "a0", "w0n0") \
-    "v_lshlrev_b32 v232, 16, " PX1 "\n\t" \
+    S2A_SEED##FORM##_F(P0, P1, P2, P3) \
     "v_mov_b32 v233, 0\n\t" \
     "s_waitcnt lgkmcnt(2)\n\t" \
     S2A_MF("v[224:227]", "a1", "w1n0") \
-    "v_and_b32 v236, 0xffff0000, " PX1 "\n\t" \
+    S2A_SEED##FORM##_O(P0, P1, P2, P3) \
     "v_mov_b32 v237, 0\n\t" \
     "s_waitcnt lgkmcnt(1)\n\t" \
     S2A_MF("v[224:227]", "a2", "w0n1") \
@@ -349,9 +367,51 @@ __device__ unsigned cn_s2_stamp_buf_f[4][8];
     S2A_ST(4) \
     "s_barrier\n\t" \
     S2A_ST(5)
-#define S2A_STEP_A(R0, R1, WO, VM, PFCODE) S2A_STEP("v240", "v241", "ptA", R0, R1, WO, VM, PFCODE)
-#define S2A_STEP_B(R0, R1, WO, VM, PFCODE) S2A_STEP("v244", "v245", "ptB", R0, R1, WO, VM, PFCODE)
+#define S2A_STEP_A(FORM, R0, R1, WO, VM, PFCODE) S2A_STEP(FORM, "v240", "v241", "v242", "v243", "ptA", R0, R1, WO, VM, PFCODE)
+#define S2A_STEP_B(FORM, R0, R1, WO, VM, PFCODE) S2A_STEP(FORM, "v244", "v245", "v246", "v247", "ptB", R0, R1, WO, VM, PFCODE)
+// first stages of the pass
+#define S2A_INIT32 \
+    "global_load_ubyte %[ptA], %[oP], %[pat]\n\t" \
+    "global_load_dwordx4 v[240:243], %[oA], %[acts]\n\t" \
+    "v_add_u32 %[x0], %[oP], %[sP]\n\t" \
+    "v_add_u32 %[x1], %[oA], %[sA]\n\t" \
+    "global_load_ubyte %[ptB], %[x0], %[pat]\n\t" \
+    "global_load_dwordx4 v[244:247], %[x1], %[acts]\n\t"
+#define S2A_INIT16 \
+    "global_load_ubyte %[ptA], %[oP], %[pat]\n\t" \
+    "v_lshrrev_b32 %[x2], 1, %[oA]\n\t" \
+    "global_load_dwordx2 v[240:241], %[x2], %[pre]\n\t" \
+    "v_add_u32 %[x0], %[oP], %[sP]\n\t" \
+    "v_add_u32 %[x1], %[oA], %[sA]\n\t" \
+    "global_load_ubyte %[ptB], %[x0], %[pat]\n\t" \
+    "v_lshrrev_b32 %[x1], 1, %[x1]\n\t" \
+    "global_load_dwordx2 v[244:245], %[x1], %[pre]\n\t"
+// the whole loop text in one of the two forms
+#define S2A_LOOP_TEXT(FORM) \
+        /* accumulator rows 2, 3 belong to rows of zeros in both views and stay 0 for the whole pass */ \
+        "v_mov_b32 v226, 0\n\tv_mov_b32 v227, 0\n\tv_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\t" \
+        "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t" \
+        S2A_INIT##FORM \
+        "s_waitcnt vmcnt(0)\n\t" \
+        "1:\n\t" \
+        S2A_STEP_A(FORM, "0", "64", "800", "10", S2A_PF##FORM("v[240:243]", "v[240:241]", "ptA")) \
+        S2A_STEP_B(FORM, "800", "864", "0", "10", S2A_PF##FORM("v[244:247]", "v[244:245]", "ptB")) \
+        "s_sub_u32 %[np], %[np], 1\n\t" \
+        "s_cmp_lg_u32 %[np], 0\n\t" \
+        "s_cbranch_scc1 1b\n\t" \
+        "s_cmp_eq_u32 %[rem], 3\n\t" \
+        "s_cbranch_scc0 2f\n\t" \
+        S2A_STEP_A(FORM, "0", "64", "800", "10", S2A_PF##FORM("v[240:243]", "v[240:241]", "ptA")) \
+        S2A_STEP_B(FORM, "800", "864", "0", "8", S2A_NOPF) \
+        S2A_STEP_A(FORM, "0", "64", "800", "8", S2A_NOPF) \
+        "s_branch 3f\n\t" \
+        "2:\n\t" \
+        S2A_STEP_A(FORM, "0", "64", "800", "8", S2A_NOPF) \
+        S2A_STEP_B(FORM, "800", "864", "0", "8", S2A_NOPF) \
+        "3:\n\t" \
+        "s_waitcnt vmcnt(0)\n\t"               /* (nothing the compiler does not know of may be in flight when the statement ends) */
 
+template <bool PRE16>
 __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -398,9 +458,10 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
     unsigned oA = (unsigned)((t0 + BIAS) * stepA * 4) + lC * 16, oC = (unsigned)((t0 + BIAS) * stepC * 4) + lC * 4, oY = (unsigned)((t0 + BIAS) * stepC * 2) + lC * 2;
     unsigned oP = (unsigned)((t0 + BIAS) * PS) + (unsigned)sv;
     const unsigned sA = (unsigned)(dt * stepA * 4), sC = (unsigned)(dt * stepC * 4), sY = (unsigned)(dt * stepC * 2), sP = (unsigned)(dt * PS);
-    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *acts1 = acts - dt * stepA * 4;      // (activations out: fp32, one step back)
-    // pre-activations in: bf16, 8 bytes per unit and frame -- the fp32 offsets halved (launch_lstm_s2 requires p.pre16 for this kernel)
-    const char *pre = (const char *)p.pre16 - BIAS * stepA * 2, *prepf = pre + 2 * dt * stepA * 2;
+    // pre-activations in: fp32 out of `acts` (stages two steps ahead; the activations overwrite them one step back), or -- PRE16 -- bf16
+    // out of p.pre16, 8 bytes per unit and frame: the fp32 offsets halved
+    const char *acts = (const char *)p.acts - BIAS * stepA * 4, *actspf = acts + 2 * dt * stepA * 4, *acts1 = acts - dt * stepA * 4;
+    const char *pre = PRE16 ? (const char *)p.pre16 - BIAS * stepA * 2 : acts, *prepf = pre + 2 * dt * stepA * 2;
     const char *pat = p.pat - BIAS * PS, *patpf = pat + 2 * dt * PS;
     const char *cell1 = (const char *)p.cell - (BIAS + dt) * stepC * 4, *th1 = (const char *)p.th - (BIAS + dt) * stepC * 4;
     const char *yop1 = (const char *)p.y_op - (BIAS + dt) * stepC * 2;
@@ -418,54 +479,31 @@ __global__ __launch_bounds__(256) void lstm_fwd_s2_asm_kernel(LstmRec p)
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     lds_barrier();
-    asm volatile(
-        // accumulator rows 2, 3 belong to rows of zeros in both views and stay 0 for the whole pass
-        "v_mov_b32 v226, 0\n\tv_mov_b32 v227, 0\n\tv_mov_b32 v230, 0\n\tv_mov_b32 v231, 0\n\t"
-        "v_mov_b32 v234, 0\n\tv_mov_b32 v235, 0\n\tv_mov_b32 v238, 0\n\tv_mov_b32 v239, 0\n\t"
-        // stages of the first two steps
-        "global_load_ubyte %[ptA], %[oP], %[pat]\n\t"
-        "v_lshrrev_b32 %[x2], 1, %[oA]\n\t"
-        "global_load_dwordx2 v[240:241], %[x2], %[pre]\n\t"
-        "v_add_u32 %[x0], %[oP], %[sP]\n\t"
-        "v_add_u32 %[x1], %[oA], %[sA]\n\t"
-        "global_load_ubyte %[ptB], %[x0], %[pat]\n\t"
-        "v_lshrrev_b32 %[x1], 1, %[x1]\n\t"
-        "global_load_dwordx2 v[244:245], %[x1], %[pre]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "1:\n\t"
-        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:241]", "ptA"))
-        S2A_STEP_B("800", "864", "0", "10", S2A_PF("v[244:245]", "ptB"))
-        "s_sub_u32 %[np], %[np], 1\n\t"
-        "s_cmp_lg_u32 %[np], 0\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_cmp_eq_u32 %[rem], 3\n\t"
-        "s_cbranch_scc0 2f\n\t"
-        S2A_STEP_A("0", "64", "800", "10", S2A_PF("v[240:241]", "ptA"))
-        S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
-        S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
-        "s_branch 3f\n\t"
-        "2:\n\t"
-        S2A_STEP_A("0", "64", "800", "8", S2A_NOPF)
-        S2A_STEP_B("800", "864", "0", "8", S2A_NOPF)
-        "3:\n\t"
-        "s_waitcnt vmcnt(0)\n\t"               // (nothing the compiler does not know of may be in flight when the statement ends)
-        : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [np] "+s"(np),
-          [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),
-          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6)
 #ifdef CN_S2_STAMP_F
-          , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]),
-          [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#define S2A_STAMP_OPS , [st0] "+s"(st[0]), [st1] "+s"(st[1]), [st2] "+s"(st[2]), [st3] "+s"(st[3]), [st4] "+s"(st[4]), [st5] "+s"(st[5]), [tq] "=&s"(tq), [tl] "+s"(tl), "={s[98:99]}"(tm)
+#else
+#define S2A_STAMP_OPS
 #endif
-        : [w0n0] "v"(w[0][0][0]), [w0n1] "v"(w[0][0][1]), [w1n0] "v"(w[1][0][0]), [w1n1] "v"(w[1][0][1]),
-          [w0i0] "v"(w[0][1][0]), [w0i1] "v"(w[0][1][1]), [w1i0] "v"(w[1][1][0]), [w1i1] "v"(w[1][1][1]),
-          [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]),
-          [w0o0] "v"(w[0][3][0]), [w0o1] "v"(w[0][3][1]), [w1o0] "v"(w[1][3][0]), [w1o1] "v"(w[1][3][1]),
-          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po),
-          [pre] "s"(pre), [prepf] "s"(prepf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1),
-          [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem)
-        : "memory", "vcc", "scc",
-          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
-          "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253");
+    // (one operand list for both forms of the text; an operand a form does not name is simply unused)
+#define S2A_OPERANDS \
+        : [cst] "+v"(cst), [oA] "+v"(oA), [oC] "+v"(oC), [oY] "+v"(oY), [oP] "+v"(oP), [np] "+s"(np), \
+          [ptA] "=&v"(ptA), [ptB] "=&v"(ptB), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), \
+          [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4), [x5] "=&v"(x5), [x6] "=&v"(x6) \
+          S2A_STAMP_OPS \
+        : [w0n0] "v"(w[0][0][0]), [w0n1] "v"(w[0][0][1]), [w1n0] "v"(w[1][0][0]), [w1n1] "v"(w[1][0][1]), \
+          [w0i0] "v"(w[0][1][0]), [w0i1] "v"(w[0][1][1]), [w1i0] "v"(w[1][1][0]), [w1i1] "v"(w[1][1][1]), \
+          [w0f0] "v"(w[0][2][0]), [w0f1] "v"(w[0][2][1]), [w1f0] "v"(w[1][2][0]), [w1f1] "v"(w[1][2][1]), \
+          [w0o0] "v"(w[0][3][0]), [w0o1] "v"(w[0][3][1]), [w1o0] "v"(w[1][3][0]), [w1o1] "v"(w[1][3][1]), \
+          [spidx] "v"(spidx), [av0] "v"(av0), [av1] "v"(av1), [oT] "v"(oT), [pi] "v"(pi), [pf] "v"(pf), [po] "v"(po), \
+          [acts] "s"(acts), [actspf] "s"(actspf), [pre] "s"(pre), [prepf] "s"(prepf), [acts1] "s"(acts1), [cell1] "s"(cell1), [th1] "s"(th1), [yop1] "s"(yop1), \
+          [pat] "s"(pat), [patpf] "s"(patpf), [sA] "s"(sA), [sC] "s"(sC), [sY] "s"(sY), [sP] "s"(sP), [rem] "s"(rem) \
+        : "memory", "vcc", "scc", \
+          "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", \
+          "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253"
+    if constexpr (PRE16) asm volatile(S2A_LOOP_TEXT(16) S2A_OPERANDS);
+    else                 asm volatile(S2A_LOOP_TEXT(32) S2A_OPERANDS);
+#undef S2A_OPERANDS
+#undef S2A_STAMP_OPS
 #ifdef CN_S2_STAMP_F
     if (blockIdx.x == 0 && lane == 0) {
         for (int i = 0; i < 6; ++i) cn_s2_stamp_buf_f[wave][i] = st[i];
@@ -1826,12 +1864,12 @@ template <int PREC, bool BWD, int HP>
 static void launch_s2(hipStream_t s, const LstmRec &p, hipEvent_t done)
 {
     if constexpr (HP == 128) {
-        // (the hand-written bf16 forward loop takes its pre-activations as bf16 only: LstmRec::pre16; without them the compiled twin runs)
-        if (s2_asm_applies(PREC, BWD, p) && (BWD || PREC == P_X3 || p.pre16)) {
+        if (s2_asm_applies(PREC, BWD, p)) {
+            // (the bf16 forward loop has two forms: fp32 pre-activations out of `acts`, or bf16 ones out of LstmRec::pre16)
             void (*akern)(LstmRec) = PREC == P_X3 ? (BWD ? lstm_bwd_s2_x3_asm_kernel : lstm_fwd_s2_x3_asm_kernel)
-                                                  : (BWD ? lstm_bwd_s2_asm_kernel : lstm_fwd_s2_asm_kernel);
-            static DeviceOnce once;
-            if (once.first()) (void)hipFuncSetAttribute((const void *)akern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                  : (BWD ? lstm_bwd_s2_asm_kernel : (p.pre16 ? lstm_fwd_s2_asm_kernel<true> : lstm_fwd_s2_asm_kernel<false>));
+            static DeviceOnce once[2];
+            if (once[p.pre16 ? 1 : 0].first()) (void)hipFuncSetAttribute((const void *)akern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             const size_t lds = s2_lds_bytes(PREC, BWD, HP, p.T);
             size_t lds_claim = lds;
             if (p.dirs * (p.PS / 2) <= 128 && !opt().no_lds_claim) lds_claim = 160 * 1024 - 1024;

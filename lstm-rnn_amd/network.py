@@ -342,7 +342,7 @@ class NeuralNetwork:
 
     def bf16_preactivation_layers(self):
         """Names of the LSTM layers whose input projection hands its pre-activations to the recurrent kernel as bf16
-        (CN_PREC_BF16, the two-sequence forward kernels; LstmRec::pre16) -- as of the LAST forward pass, read off the kernel the
+        (CN_PREC_BF16 with option pre16, the two-sequence forward kernels; LstmRec::pre16) -- as of the LAST forward pass, read off the kernel the
         library reports per layer.  (The parity tests model the rounding of exactly those layers.)"""
         out = []
         if self.precision != B.PREC_BF16:
@@ -350,7 +350,7 @@ class NeuralNetwork:
         for lay in self.layers:
             if lay.type in ("lstm", "blstm"):
                 k = self.lib.cn_layer_recurrent_kernel(lay.handle, 0).decode()
-                if "_s2_" in k and self.get_option("no_pre16") == 0:
+                if "_s2_" in k and self.get_option("pre16") == 1:
                     out.append(lay.name)
         return out
 

@@ -113,16 +113,18 @@ def test_headline_net_hand_written_loops(pkg, orc, T):
     print("bf16 pinned, T = %d:" % T, {k: float("%.3g" % v) for k, v in rep.items()})
 
 
-@pytest.mark.parametrize("no_pre16", [0, 1])
-def test_headline_net_with_and_without_bf16_preactivations(pkg, orc, no_pre16):
-    """Round 6: the input projection of the layers that run the two-sequence forward kernels hands its pre-activations over as
-    bf16 (8 instead of 16 bytes per unit and frame; option no_pre16 = 1 keeps fp32 and the compiled kernel).  Both forms are pinned
-    at the same 2e-4 / 2e-3 against the oracle's model of THEIR arithmetic (layer.round_preacts on or off), i.e. the model says what
-    the kernels do; the distance of either form to the fp32 reference stays inside the bf16 mode's 3e-2 (test_gpu_parity.py)."""
-    layers, weights, frac, PS = headline_case(pkg, 67)
-    kern = ("lstm_fwd_s2_kernel<0,128>" if no_pre16 else "lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel")
-    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=kern, options={"no_pre16": no_pre16})
-    assert rep["pre16_layers"] == (0 if no_pre16 else 3)
+@pytest.mark.parametrize("T", [5, 67, 300])
+@pytest.mark.parametrize("pre16", [0, 1])
+def test_headline_net_with_and_without_bf16_preactivations(pkg, orc, pre16, T):
+    """Round 6, option pre16 (off by default): the input projection of the layers that run the two-sequence forward kernels hands its
+    pre-activations over as bf16 (8 instead of 16 bytes per unit and frame) and the hand-written loop widens them with the shift /
+    mask that takes the place of its accumulator-seeding copies (the second form of its text, lstm_fwd_s2_asm_kernel<true>).  Both
+    forms are pinned at the same 2e-4 / 2e-3 against the oracle's model of THEIR arithmetic (layer.round_preacts on or off), i.e.
+    the model says what the kernels do.  (Measured: +0.3 % on the headline -- the product is latency-bound, not store-bound -- and
+    at trained, peaked posteriors the distance to the model doubles (bench.py parity_vs_cpu); hence an option, not the default.)"""
+    layers, weights, frac, PS = headline_case(pkg, T)
+    rep = check_pinned(pkg, orc, layers, weights, frac, PS, kernels=("lstm_fwd_s2_asm_kernel", "lstm_bwd_s2_asm_kernel"), options={"pre16": pre16})
+    assert rep["pre16_layers"] == (3 if pre16 else 0)
 
 
 def test_single_layer_internals_hand_written_loops(pkg, orc):

@@ -772,15 +772,18 @@ def test_destroy_deep_cluster_network(depth):
     assert out.returncode == 0 and "destroyed ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
 
 
+@pytest.mark.parametrize("pre16", [0, 1])
 @pytest.mark.parametrize("kind,size,T", [("blstm", 250, 1), ("blstm", 250, 2), ("blstm", 250, 3), ("blstm", 250, 4), ("blstm", 250, 5), ("blstm", 250, 6), ("lstm", 128, 9), ("blstm", 256, 37),
                                          ("blstm", 250, 7), ("blstm", 250, 64)])
-def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T):
+def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, monkeypatch, kind, size, T, pre16):
     """The hand-written (asm) time loops of cn_lstm_s2.hip against the C++ kernels of the same cut (CN_NO_S2_ASM): same
     operand order, same arithmetic, so EVERY value on a real slot must be bit-identical -- outputs, the four gate
     activations, cell states, all deltas, every weight gradient except the split-K atomics' last bits (compared at 1e-6).
     Loop shapes: T = 1 ... 7 (the backward loop leaves its four-step body after any step; the forward loop's pair count and
     tail length in every combination, T < 4: compiled forward kernel), longer odd / even passes, the pass as long as the
-    buffers (prefetch into the guard steps), ragged lengths, unused slots, one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this."""
+    buffers (prefetch into the guard steps), ragged lengths, unused slots, one- and two-directional.  A wrong wait count, a missed hazard or a misplaced operand cannot pass this.
+    pre16 = 1: the second form of the forward loop's text (bf16 pre-activations out of LstmRec::pre16, widened by shift / mask)
+    against the compiled kernel reading the same buffer."""
     rng = np.random.RandomState(500 + T)
     P, C, PS = 9, 7, 11                       # 11 slots -> padded to 12, the last group half filled
     layers = net_desc(P, [(kind, size), (kind, size)], C)
@@ -795,8 +798,10 @@ def test_hand_written_time_loops_equal_the_compiled_kernels_bit_for_bit(pkg, mon
         if mode == "cpp":
             monkeypatch.setenv("CN_NO_S2_ASM", "1")
         with pkg.NeuralNetwork(layers, weights, PS, frac["T"], precision=pkg.PREC_BF16) as net:
+            net.set_option("pre16", pre16)
             net.load_sequences(frac); net.compute_forward_pass()
             e, c = net.error_and_correct()
+            assert len(net.bf16_preactivation_layers()) == (2 if pre16 else 0)
             net.compute_backward_pass()
             names = (net.recurrent_kernel(False), net.recurrent_kernel(True))
             vals = {"error": np.float32(e), "out": net.outputs().reshape(-1, C)[real]}
