@@ -631,6 +631,7 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
     r.bias = l->bias;
     r.rpl = c->rpl;
     r.xch = c->d_xch; r.fault = c->d_fault; r.num_cus = r.cluster_cus = c->num_cus;
+    r.xch_packed = nullptr;
     // With a communicator bound, RCCL's persistent workgroups hold CUs on the communication stream while they wait for peer
     // ranks, beside the recurrent kernel of the layer below.  A cluster grid needs ALL its members resident (spin-wait
     // hand-off), so it must fit what RCCL leaves: the grid is sized against num_cus minus a margin for RCCL's channels
@@ -642,6 +643,10 @@ void lstm_rec_args(cn_layer *l, LstmRec &r)
         r.cluster_cus = c->num_cus - margin > 0 ? c->num_cus - margin : 1;
     }
     r.gpart = nullptr; r.gpart_slots = 0; r.det_grid = nullptr;
+    if (c->d_xch) {
+        const size_t off = lstm_cluster_xch_packed_offset(c->prec, l->Hp, l->dirs, c->PSp, c->rpl, c->num_cus);
+        if (off) r.xch_packed = (unsigned long long *)((char *)c->d_xch + off);
+    }
     r.kname = nullptr;
     // tag range of a cluster launch (cn_lstm_cluster.hip); cleared and restarted long before the 32-bit tags wrap
     if (c->d_xch && c->xch_epoch > 0xF0000000u) { HIP_CHECK(hipMemsetAsync(c->d_xch, 0, c->xch_bytes, c->stream)); c->xch_epoch = 0; }

@@ -151,6 +151,7 @@ struct LstmRec {
     int rpl;                      // sequences per lane (1/2/4); PS is a multiple of 4*rpl (padded slots are dummies)
     // multi-CU cluster kernels (cn_lstm_cluster.hip)
     unsigned long long *xch;      // exchange granules (nullable: cluster path off), zeroed at allocation
+    unsigned long long *xch_packed;   // ... the packed granules' region of the same buffer (lstm_cluster_xch_packed_offset)
     unsigned xch_epoch;           // tags of this launch are xch_epoch + 1 ... xch_epoch + T (launch_lstm_cluster sets it and advances the counter)
     int *fault;                   // set to 1 by a bounded spin that gave up
     int num_cus;                  // CUs of the device (the one-CU kernels' "does the grid fit the chip in one wave" rule)
@@ -182,6 +183,7 @@ void launch_lstm_backward(hipStream_t s, int prec, const LstmRec &p, hipEvent_t 
 // `num_cus`: the CU count of the device; the spin-wait hand-off needs every member workgroup resident, so a grid larger
 // than the device (a partitioned or CU-masked part) does not take the cluster path
 size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);
+size_t lstm_cluster_xch_packed_offset(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);   // bytes from the start of the buffer
 int lstm_cluster_size(int prec, int Hp, int dirs, int PS, int rpl, int num_cus);     // CUs per cluster, 0 = path does not apply
 // `epoch`: the context's granule-tag counter; the launcher hands tags epoch + 1 ... epoch + T to this launch and advances
 // the counter by T + 1, so no caller can forget to (stale granules of an earlier launch never match)

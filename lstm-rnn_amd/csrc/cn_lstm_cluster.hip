@@ -63,6 +63,12 @@
 #ifndef CN_POLL2_STAGGER
 #define CN_POLL2_STAGGER 4
 #endif
+#ifndef CN_PACKED_XCH
+#define CN_PACKED_XCH 1      // round 6: the 8-CU bf16 backward kernel exchanges ONE granule per lane and partner (four bf16 deltas with the tag in their spare exponent bits)
+#endif
+#ifndef CN_POLL_DELAY_PACKED
+#define CN_POLL_DELAY_PACKED 0     // swept on the long-utterance workload (ms per fraction, two rounds): 0 30.11 / 30.13, 1 30.24 / 30.31, 2 30.42 / 30.47
+#endif
 
 #include <cstdlib>
 #include <map>
@@ -182,6 +188,48 @@ __device__ __forceinline__ void consume_all(const u64 *const (&slot)[K], unsigne
         if (++spins > (1 << 21)) { *fault = 1; gaveup = true; break; }
         if (CN_POLL_SLEEP) __builtin_amdgcn_s_sleep(CN_POLL_SLEEP);
     }
+    }
+}
+
+// ---- packed granules (round 6; the 8-CU bf16 backward kernel) ------------------------------------------------------------------
+// A lane's four deltas are bf16 values clipped to [-1, 1] (ComputeBlockErrorsFn, LstmLayer.cu:281-285): bit 14 -- the top bit of
+// the exponent -- is 0 in every one of them.  Those four bits carry the tag, so the whole hand-off of a lane is ONE naturally
+// aligned 8-byte granule instead of two {32-bit tag, 32-bit value} ones: half the polled bytes and lines (14 -> 7 granules per
+// lane and step; the poll was 1 700-1 900 of the 4 100 cycles of a step and every extra sample cost more than it found: rec_bwd of
+// the long-utterance step 66.5 -> 60.1 ms per four fractions, the fraction 31.7 -> 30.1 ms).  The same for the FORWARD kernel --
+// y is below 1 too; the four lanes of a quad hand their values to the quad's first lane by DPP, which publishes and polls one
+// granule for the four -- was built, is correct and measured 30 % SLOWER (rec_fwd 50.2 -> 66 ms, whatever the first sample's
+// delay; no scratch): not kept.  Four
+// bits do not count launches: tags are 1 + (step mod 15) -- two consecutive writes of a slot (two steps apart) always differ --,
+// 0 is "nothing yet"; the packed slots live in a region of their own behind the 32-bit-tag schemes' (no other kernel ever
+// interprets them), every member zeroes ITS slots when the launch begins, drains, and the cluster meets once through ordinary
+// granules tagged with the launch's epoch (a value no step uses) before anybody reads a packed slot.
+__device__ __forceinline__ void packed_masks(unsigned tag, unsigned &lo, unsigned &hi)
+{
+    lo = ((tag & 1u) << 14) | (((tag >> 1) & 1u) << 30);
+    hi = (((tag >> 2) & 1u) << 14) | (((tag >> 3) & 1u) << 30);
+}
+template <int K, int DELAY>
+__device__ __forceinline__ void consume_all_packed(const u64 *const (&slot)[K], unsigned tag, int *fault, unsigned (&lo)[K], unsigned (&hi)[K], bool &gaveup)
+{
+    unsigned elo, ehi;
+    packed_masks(tag, elo, ehi);
+    int spins = gaveup ? (1 << 21) : 0;
+    // (the first sample waits DELAY x 64 cycles: one that leaves before the partners' granules are in L2 costs a whole round trip more)
+    if constexpr (DELAY > 0) __builtin_amdgcn_s_sleep(DELAY);
+    for (;;) {
+        u64 x[K];
+        sample_all<K>(slot, x);
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const unsigned l = (unsigned)x[i], h = (unsigned)(x[i] >> 32);
+            ok = ok && (l & 0x40004000u) == elo && (h & 0x40004000u) == ehi;
+            lo[i] = l & ~0x40004000u; hi[i] = h & ~0x40004000u;
+        }
+        if (ok) break;
+        if (++spins > (1 << 21)) { *fault = 1; gaveup = true; break; }
+        if (CN_POLL_SLEEP) __builtin_amdgcn_s_sleep(CN_POLL_SLEEP);
     }
 }
 
@@ -577,6 +625,8 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     // (Hp = 256) +35 %: that shape holds 128 VGPRs of W_rec per lane at two waves per SIMD and the three extra accumulators
     // push the time loop into scratch.  On for the 64-unit members only.
     constexpr bool KQS = !SP && RPL == 1 && UPC <= 64 && (KC / CS) % 4 == 0 && CN_KQ_STACK;
+    // packed granules (above): the 8-CU bf16 shape, where a lane polls 14 granules per step otherwise
+    constexpr bool PACK = CN_PACKED_XCH && !X3 && SP && CS == 8;
     constexpr int pitch = lds_pitch(SP ? (KHS ? 2 * HP : 4 * HP) : (KQS ? HP : 4 * HP) * 2);     // delta tile row: k = 4*unit + gate
     int cluster, member;
     cluster_of<CS>(cluster, member);
@@ -632,6 +682,25 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
     }
     const long stepA = (long)PS * arow, stepC = (long)PS * crow;
     u64 *xbase = p.xch + (long)cluster * 2 * CS * (RPL * G * NT);
+    [[maybe_unused]] u64 *xpack = PACK ? p.xch_packed + (long)cluster * 2 * CS * (RPL * NT) : nullptr;
+    if constexpr (PACK) {
+        // my packed slots of both parities say "nothing yet"; once that is acknowledged the cluster meets (granules of the ordinary
+        // kind in parity slot 1, tagged with the launch's epoch: no step of any launch uses that value), and only then is a packed
+        // slot of anybody read
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int r = 0; r < RPL; ++r)
+                __hip_atomic_store(xpack + (long)par * CS * (RPL * NT) + (long)member * (RPL * NT) + r * NT + tid, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        u64 *meet = xbase + (long)CS * (RPL * G * NT);
+        publish(meet + (long)member * (RPL * G * NT) + tid, p.xch_epoch, 0u);
+        const u64 *ms[CS - 1];
+#pragma unroll
+        for (int j = 0; j < CS - 1; ++j) ms[j] = meet + (long)((member + 1 + j) % CS) * (RPL * G * NT) + tid;
+        unsigned mv[CS - 1];
+        consume_all<CS - 1>(ms, p.xch_epoch, p.fault, mv, gaveup);
+    }
 
     float fgn[RPL], ecn[RPL], dign[RPL], dfgn[RPL], ccur[RPL];
     float sb[4] = {0.f, 0.f, 0.f, 0.f}, spi = 0.f, spf = 0.f, spo = 0.f;
@@ -673,6 +742,7 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 
         // the partners' deltas of the previous step: sampled first thing (EarlyPoll), looked at behind the own part of the product
         const u64 *slots[(CS - 1) * RPL * G];
+        [[maybe_unused]] const u64 *pslots[(CS - 1) * RPL];
         EarlyPoll<(CS - 1) * RPL * G> early;
         {
             u64 *xprev = xbase + (long)((it + 1) & 1) * CS * (RPL * G * NT);
@@ -683,9 +753,11 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
                     const u64 *theirs = xprev + (long)((member + 1 + j) % CS) * (RPL * G * NT) + (r * G) * NT + tid;
 #pragma unroll
                     for (int i = 0; i < G; ++i) slots[(j * RPL + r) * G + i] = theirs + i * NT;
+                    if constexpr (PACK)
+                        pslots[j * RPL + r] = xpack + (long)((it + 1) & 1) * CS * (RPL * NT) + (long)((member + 1 + j) % CS) * (RPL * NT) + r * NT + tid;
                 }
         }
-        if (it > 0) poll_early<0>(slots, early);
+        if (!PACK && it > 0) poll_early<0>(slots, early);
         f32x4 acc, a_[RPL];
         [[maybe_unused]] f32x4 accq[4];              // KQS: one accumulator per K-quarter
         [[maybe_unused]] f32x4 accs, acch;           // SP: the row-pair accumulator (KHS: first half) and the second half's
@@ -769,10 +841,10 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
 #pragma unroll
             for (int r = 0; r < RPL; ++r) accs[2 * r] = acc[r];
         }
-        if (it > 0) poll_early<1>(slots, early);
+        if (!PACK && it > 0) poll_early<1>(slots, early);
         CLS(0)
         product(std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
-        if (it > 0) poll_early<2>(slots, early);
+        if (!PACK && it > 0) poll_early<2>(slots, early);
 #ifdef CN_CL_STAMP
         if constexpr (SP) { CLS_FORCE(accs[0]) } else { CLS_FORCE(acc[0]) }
 #endif
@@ -780,6 +852,12 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
         __builtin_amdgcn_sched_barrier(0);     // (the first look at the samples, and the wait for them, stays behind the MFMAs above)
         if (it > 0) {      // the partners' deltas of the previous step (sampled at the top of the step, see EarlyPoll)
             unsigned vals[(CS - 1) * RPL * G];
+            if constexpr (PACK) {
+                unsigned plo[(CS - 1) * RPL], phi[(CS - 1) * RPL];
+                consume_all_packed<(CS - 1) * RPL, CN_POLL_DELAY_PACKED>(pslots, 1u + (unsigned)(it - 1) % 15u, p.fault, plo, phi, gaveup);
+#pragma unroll
+                for (int i = 0; i < (CS - 1) * RPL; ++i) { vals[2 * i] = plo[i]; vals[2 * i + 1] = phi[i]; }
+            } else
             poll_finish<(CS - 1) * RPL * G>(slots, p.xch_epoch + it, p.fault, vals, gaveup, early);
             CLS_FORCE(vals[0]) CLS(2)
 #pragma unroll
@@ -862,8 +940,17 @@ __global__ __launch_bounds__(UPC * 4) void lstm_bwd_cluster_kernel(LstmRec p)
             } else {
                 const bf16x4 dv = {(__bf16)dni, (__bf16)dig, (__bf16)dfg, (__bf16)dog};
                 const u64 bits = __builtin_bit_cast(u64, dv);
+                if constexpr (PACK) {
+                    unsigned mlo, mhi;
+                    packed_masks(1u + (unsigned)it % 15u, mlo, mhi);
+                    __hip_atomic_store(xpack + (long)(it & 1) * CS * (RPL * NT) + (long)member * (RPL * NT) + r * NT + tid,
+                                       bits | (u64)mlo | ((u64)mhi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (the helper workgroup reads the cluster's progress off member 0's ordinary granule)
+                    if (member == 0 && tid == 0 && r == 0) publish(mine, p.xch_epoch + it + 1, 0u);
+                } else {
                 publish(mine, p.xch_epoch + it + 1, (unsigned)bits);
                 publish(mine + NT, p.xch_epoch + it + 1, (unsigned)(bits >> 32));
+                }
                 if constexpr (SP) {                              // member-relative tile: own units first
                     *(unsigned *)(dnxt + tile_off(0, r)) = (unsigned)bits;
                     *(unsigned *)(dnxt + tile_off(0, r) + pitch) = (unsigned)(bits >> 32);
@@ -1475,7 +1562,16 @@ size_t lstm_cluster_xch_bytes(int prec, int Hp, int dirs, int PS, int rpl, int n
     const int NT = (Hp / CS) * 4;
     const size_t delta_scheme = (size_t)nclusters * 2 * CS * rpl * (prec == P_X3 ? 4 : 2) * NT * sizeof(u64);     // (the delta-exchange backward kernel's granules)
     const size_t psum_scheme = (size_t)nclusters * 2 * CS * CS * NT * sizeof(u64);                                  // lstm_bwd_cluster_psum_kernel
-    return delta_scheme > psum_scheme ? delta_scheme : psum_scheme;
+    // ... and behind them the packed granules of the 8-CU bf16 backward kernel (a region no 32-bit-tag scheme ever reads)
+    const size_t packed = (size_t)nclusters * 2 * CS * rpl * NT * sizeof(u64);
+    return (delta_scheme > psum_scheme ? delta_scheme : psum_scheme) + packed;
+}
+size_t lstm_cluster_xch_packed_offset(int prec, int Hp, int dirs, int PS, int rpl, int num_cus)
+{
+    const int CS = lstm_cluster_size(prec, Hp, dirs, PS, rpl, num_cus);
+    if (CS == 0) return 0;
+    const size_t packed = (size_t)(dirs * (PS / (4 * rpl))) * 2 * CS * rpl * ((Hp / CS) * 4) * sizeof(u64);
+    return lstm_cluster_xch_bytes(prec, Hp, dirs, PS, rpl, num_cus) - packed;
 }
 
 // Cluster launches of one device go through one gate: a cluster kernel needs ALL its workgroups resident, and two such
