@@ -443,6 +443,8 @@ def main():
             net.loss_accumulate()
             if prefetch and not from_host:
                 net.prefetch_sequences_resident(dfr[(i + 1) % nfrac])   # the next step's re-layout, beside this backward pass
+            elif prefetch:
+                net.prefetch_sequences(fracs[(i + 1) % nfrac])          # host buffers: packed and uploaded now, re-laid out beside this backward pass
             # every layer's momentum-SGD step behind its own gradient (cn_ctx_arm_update; with the library's communicator: behind
             # its all-reduce); the torch test double reduces outside the library, so it keeps the update behind the whole pass
             if armed and (not use_comm or (native_comm and not flat_exchange)):
@@ -510,8 +512,10 @@ def main():
             # one upload on a copy stream under the previous fraction's compute, then the re-layout kernel)
             for i in range(warmup):
                 step(i, from_host=True)
+            hits0 = net.prefetch_hits()
             hd = [timed(from_host=True) for _ in range(max(1, min(reps, 20)))]
             res["host_frames_per_s"] = frames / float(np.median(allmax([h[0] for h in hd])))
+            res["host_prefetch_hits"] = (net.prefetch_hits() - hits0, len(hd) * steps)
         if roofline_pass:
             # one more pass of the same steps with hipEvents around every kernel class, on the stream they are launched on
             net.timing_enable(True); net.timing_reset()
@@ -598,8 +602,10 @@ def main():
                                "one_rank_per_gpu": not shared_devices}
         if "host_frames_per_s" in res:
             out["load_path"] = {"value": res["host_frames_per_s"], "unit": "frames/s", "vs_resident": res["host_frames_per_s"] / value,
-                                "note": "same steps with every fraction handed over as HOST buffers through cn_fraction_load (pinned staging, upload of "
-                                        "fraction k+1 under the compute of fraction k, re-layout kernel); PCIe-inclusive, informational, never `value`"}
+                                "prefetched_loads": "%d of %d" % tuple(res.get("host_prefetch_hits", (0, 0))),
+                                "note": "same steps with every fraction handed over as HOST buffers: cn_fraction_prefetch of fraction k+1 behind the forward pass of "
+                                        "fraction k (packed into pinned staging and uploaded at once, re-laid out beside the backward pass), cn_fraction_load "
+                                        "then exchanges buffers; PCIe-inclusive, informational, never `value`"}
         if "timing" in res:
             out.update(roofline_records(res, wl, args.workload, args.parallel_sequences, args.precision, value))
             if native_comm:

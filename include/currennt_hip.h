@@ -198,6 +198,12 @@ int  cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_outp
  * when a prefetch that is already in flight has not been consumed.  The reference has no counterpart (its loader
  * thread prefetches HOST fractions, DataSet.cpp:546-552; Layer::loadSequences copies synchronously).   [async] */
 int  cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
+/* The same for HOST buffers: announces the fraction the NEXT cn_fraction_load will load.  The library packs it into pinned
+ * staging memory and starts its upload at once (copy stream), re-lays it out beside the coming backward pass, and that load
+ * only exchanges buffers -- what the reference's loader thread does for host fractions one fraction ahead (DataSet.cpp:202-
+ * 240,546-552,589), moved across PCIe as well.  The caller's buffers are copied before this returns.  Purely a hint, as above.
+ * CN_ERR_STATE when a prefetch that is already in flight has not been consumed.   [async] */
+int  cn_fraction_prefetch(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *fraction);
 
 /* Layer::computeForwardPass / computeBackwardPass (Layer.hpp:165-170).  Backward of a trainable
  * layer consumes its outputErrors, writes the preceding trainable layer's outputErrors

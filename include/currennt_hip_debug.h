@@ -21,6 +21,13 @@ int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
                    const float *bias, int act);
 /* C[M][N] = A[K][M]^T * B[K][N];  M % 32 == 0, N % 32 == 0 */
 int cn_dbg_gemm_tn(cn_ctx *ctx, const float *A, const float *B, float *C, int M, int N, int K);
+/* The row map of the fraction that is loaded (no counterpart in the reference, which multiplies every frame of a fraction:
+ * LstmLayer.cu:771-786): out[0] frames whose rows the N-wide products compute, out[1] dummy frames whose rows they fill with
+ * bias / 0 instead, out[2] T x (padded) parallel sequences.  [sync] */
+int cn_dbg_row_map_counts(cn_ctx *ctx, int out[3]);
+/* Loads of this context that found their fraction announced and re-laid out (cn_fraction_prefetch / _resident) and only exchanged
+ * buffers. */
+int cn_dbg_prefetch_hits(cn_ctx *ctx, int *hits);
 
 #ifdef __cplusplus
 }

@@ -30,14 +30,14 @@ BUF = {
 EXPORTS = [
     "cn_ctx_create", "cn_ctx_destroy", "cn_ctx_synchronize", "cn_ctx_set_option", "cn_ctx_get_option", "cn_ctx_join", "cn_layer_join", "cn_layer_join_stream", "cn_ctx_stream", "cn_last_error", "cn_device_arch", "cn_device_count", "cn_device_name",
     "cn_version", "cn_layer_create", "cn_layer_destroy", "cn_layer_size", "cn_layer_kind_of",
-    "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_fraction_prefetch_resident", "cn_layer_forward",
+    "cn_layer_weight_count", "cn_fraction_load", "cn_fraction_load_resident", "cn_fraction_prefetch_resident", "cn_fraction_prefetch", "cn_layer_forward",
     "cn_layer_backward", "cn_loss_eval", "cn_loss_accumulate", "cn_loss_read", "cn_layer_set_weights", "cn_layer_read", "cn_layer_write_output_errors", "cn_layer_upload",
     "cn_layer_device_ptr", "cn_ctx_param_arena", "cn_ctx_weights_touched", "cn_sgd_update",
     "cn_sgd_update_all", "cn_ctx_arm_update", "cn_ctx_accumulate_updates", "cn_ctx_take_accumulated", "cn_layer_set_learning_rate", "cn_ctx_timing_enable", "cn_ctx_timing_read", "cn_ctx_timing_reset",
     "cn_layer_recurrent_kernel",
     "cn_comm_unique_id", "cn_comm_init", "cn_comm_destroy", "cn_comm_info", "cn_comm_backend", "cn_allreduce_grads", "cn_loss_read_global",
     # include/currennt_hip_debug.h
-    "cn_dbg_gemm_nt", "cn_dbg_gemm_tn",
+    "cn_dbg_gemm_nt", "cn_dbg_gemm_tn", "cn_dbg_row_map_counts", "cn_dbg_prefetch_hits",
 ]
 
 
@@ -110,6 +110,7 @@ def load_library():
     L.cn_fraction_load.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_fraction_load_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_fraction_prefetch_resident.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
+    L.cn_fraction_prefetch.argtypes = [vp, vp, vp, C.POINTER(Fraction)]
     L.cn_loss_accumulate.argtypes = [vp]
     L.cn_loss_read.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_layer_forward.argtypes = [vp]
@@ -144,6 +145,8 @@ def load_library():
     L.cn_loss_read_global.argtypes = [vp, C.POINTER(cf), C.POINTER(C.c_int64), ci]
     L.cn_dbg_gemm_nt.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, ci]
     L.cn_dbg_gemm_tn.argtypes = [vp, vp, vp, vp, ci, ci, ci]
+    L.cn_dbg_row_map_counts.argtypes = [vp, vp]
+    L.cn_dbg_prefetch_hits.argtypes = [vp, C.POINTER(C.c_int)]
     _LIB = L
     return L
 

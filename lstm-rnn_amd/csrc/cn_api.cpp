@@ -91,6 +91,12 @@ struct cn_ctx {
     int PS = 0, PSp = 0, rpl = 1, maxT = 0, T = 0, Tmin = 0, N = 0, Next = 0, numSeqs = 0;
     bool loaded = false;
     char *d_pat = nullptr, *d_pat_raw = nullptr;      // [maxN] pattern types inside an allocation with guard steps
+    // ... and behind them the fraction's row map (GemmNT::rowmap; launch_rowmap): one allocation, so that the map travels with the
+    // pattern types when a prefetched fraction's buffers are swapped in
+    size_t pat_maxN = 0, pat_guard = 0;
+    static size_t pat_bytes(size_t maxN, size_t guard) { return ((maxN + 2 * guard + 15) & ~(size_t)15) + (4 + 2 * maxN) * sizeof(int); }
+    int *rowmap_of(char *pat_raw) const { return pat_raw ? (int *)(pat_raw + ((pat_maxN + 2 * pat_guard + 15) & ~(size_t)15)) : nullptr; }
+    int est_real = 0;                                 // estimate of the current fraction's real frames (dispatch only)
     int *d_tcls = nullptr;
     float *d_loss = nullptr;      // [2] per-call (error, #correct as int bits)
     float *d_loss_acc = nullptr;  // [2] running sums for cn_loss_accumulate
@@ -117,6 +123,8 @@ struct cn_ctx {
     struct Prefetch {
         bool valid = false, launched = false;
         cn_fraction f{}; cn_layer *input = nullptr, *post = nullptr;
+        int hits = 0;                                            // loads that found their fraction re-laid out (cn_dbg_prefetch_hits)
+        bool host = false; cn_fraction f_host{}; int slot = 0;     // cn_fraction_prefetch: f points into staging area `slot`, f_host is what the caller announced
         char *pat = nullptr, *pat_raw = nullptr; int *tcls = nullptr; void *in_op = nullptr; float *targets = nullptr;   // alternates
         bool allocated = false;
     } pf;
@@ -308,6 +316,16 @@ hipStream_t masked_stream(int device, int ncu, int total)
     return st;
 }
 
+// ---- row map -------------------------------------------------------------------------------
+// The N-wide products of a fraction may skip its dummy frames (GemmNT::rowmap): the map was built behind the re-layout of the
+// fraction that is current now (launch_fraction_load / launch_rowmap)
+static void use_rowmap(cn_ctx *c, GemmNT &g)
+{
+    if (opt().no_nt_rowmap || !c->d_pat_raw || !c->loaded) return;
+    int *rm = c->rowmap_of(c->d_pat_raw);
+    g.rowcnt = rm; g.rowmap = rm + 4; g.dummymap = rm + 4 + c->pat_maxN; g.m_est = c->est_real;
+}
+
 // ---- timing ---------------------------------------------------------------------------------
 hipEvent_t get_event(cn_ctx *c)
 {
@@ -431,12 +449,14 @@ void launch_prefetch(cn_ctx *c, hipStream_t st)
     cn_ctx::Prefetch &p = c->pf;
     const cn_fraction &f = p.f;
     const bool cls = p.post && (p.post->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || p.post->kind == CN_LAYER_BINARY_CLASSIFICATION);
+    if (p.host) HIP_CHECK(hipStreamWaitEvent(st, c->ev_up[p.slot], 0));      // cn_fraction_prefetch: f points into a staging area whose upload is on the copy stream
     launch_fraction_load(st, c->f32, f.max_seq_length, c->PS, c->PSp, (const char *)f.pat_types, p.pat,
                          cls ? (const int *)f.target_classes : nullptr, p.tcls,
                          (p.post && !cls) ? (const float *)f.targets : nullptr, p.post ? p.targets : nullptr,
-                         p.post ? p.post->size : 0, (const float *)f.inputs, p.input->size, p.in_op, p.input->Lp);
+                         p.post ? p.post->size : 0, (const float *)f.inputs, p.input->size, p.in_op, p.input->Lp, c->rowmap_of(p.pat_raw), (int)c->pat_maxN, f.min_seq_length);
     if (p.post && p.post->kind == CN_LAYER_BINARY_CLASSIFICATION)
         launch_classes_to_targets(st, p.tcls, p.targets, f.max_seq_length * c->PSp);
+    if (p.host) { HIP_CHECK(hipEventRecord(c->ev_free[p.slot], st)); c->stage_used[p.slot] = true; }
     p.launched = true;
 }
 // run `f(stream)` on the side stream after everything enqueued on the main stream so far
@@ -723,6 +743,7 @@ void lstm_forward(cn_layer *l)
         g.C = l->acts; g.ldc = R; g.C2 = nullptr; g.ldc2 = 0; g.bias = l->bias_p; g.act = ACT_IDENTITY;
         if (pre16) { g.C = nullptr; g.C2 = l->pre16; g.ldc2 = R; }
         g.M = c->N; g.N = R; g.K = l->Pp;
+        if (l->prev->lstm) use_rowmap(c, g);          // (y = 0 on dummy frames; what the caller's inputs hold there is the caller's business)
         launch_gemm_nt(c->stream, c->prec, g);
     }
     {   // K2+K3+K4: the whole time loop
@@ -764,6 +785,7 @@ void lstm_backward(cn_layer *l)
         g.A = l->delta_op; g.lda = R; g.B = l->WinT; g.ldb = R;
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = R;
+        use_rowmap(c, g);
         hipEvent_t fork = c->timing ? nullptr : fork_event(l);     // (timing mode records its own events around the kernel)
         launch_gemm_nt(c->stream, c->prec, g, fork);
         fork_attached = fork != nullptr;
@@ -833,6 +855,7 @@ void ff_forward(cn_layer *l)
         g.C2 = (!c->f32 && !softmax) ? l->out_op : nullptr; g.ldc2 = l->Lp;
         g.bias = l->bias_p; g.act = ff_act(l->kind);
         g.M = c->N; g.N = l->Lp; g.K = l->Pp;
+        if (l->prev->lstm) use_rowmap(c, g);          // (y = 0 on dummy frames, ComputeBlockOutputFn; a feed-forward layer's output is act(bias) there)
         launch_gemm_nt(c->stream, c->prec, g);
     }
     if (softmax) {
@@ -862,9 +885,11 @@ void ff_backward(cn_layer *l)
     repack(l);
     if (c->det) ensure_det(l);
     FoldItem colfold{}; colfold.nparts = 0;       // deterministic mode: the column sums' fold rides on the gradient product's
+    bool dummy_deltas_zero = false;               // (the row map's condition: every operand row of a dummy frame is zero)
     {
         Timed tm(c, KC_OTHER);
         if (l->kind == CN_LAYER_SOFTMAX && l->mcc_pending && l->Lp <= 8192) {
+            dummy_deltas_zero = true;             // softmax_mcc_bwd_kernel stores zeros for every pattern that is not real
             // bf16 mode: the fp32 outputErrors stay unwritten (read back from the bf16 operand copy if anyone asks)
             const bool with_loss = c->loss_deferred && c->rowstat_of == l && softmax_mcc_bwd_takes_loss(l->Lp);
             launch_softmax_mcc_bwd(c->stream, c->f32, l->out_f32, c->d_tcls, c->d_pat, N, l->size, l->Lp, c->f32 ? l->err : nullptr, l->delta_op, l->dbias,
@@ -891,6 +916,7 @@ void ff_backward(cn_layer *l)
         g.A = l->delta_op; g.lda = l->Lp; g.B = l->WinT; g.ldb = l->Lp;
         g.C = l->prev->err; g.ldc = l->prev->Lp; g.bias = nullptr; g.act = ACT_IDENTITY;
         g.M = N; g.N = l->Pp; g.K = l->Lp;
+        if (dummy_deltas_zero) use_rowmap(c, g);
         hipEvent_t fork = c->timing ? nullptr : fork_event(l);
         launch_gemm_nt(c->stream, c->prec, g, fork);
         fork_attached = fork != nullptr;
@@ -1317,8 +1343,9 @@ int cn_layer_create(cn_ctx *ctx, cn_layer_kind kind, cn_layer *preceding, int si
             ctx->PS = l->PS; ctx->maxT = l->maxT;
             {   // pattern types, with guard steps of PATTYPE_NONE on both sides (dalloc_guarded)
                 const size_t guard = (size_t)CN_GUARD_STEPS * ctx->PSp;
-                HIP_CHECK(hipMalloc((void **)&ctx->d_pat_raw, maxN + 2 * guard));
-                HIP_CHECK(hipMemsetAsync(ctx->d_pat_raw, 0, maxN + 2 * guard, ctx->stream));   // pad slots: PATTYPE_NONE forever
+                HIP_CHECK(hipMalloc((void **)&ctx->d_pat_raw, cn_ctx::pat_bytes(maxN, guard)));
+                HIP_CHECK(hipMemsetAsync(ctx->d_pat_raw, 0, cn_ctx::pat_bytes(maxN, guard), ctx->stream));   // pad slots: PATTYPE_NONE forever
+                ctx->pat_maxN = maxN; ctx->pat_guard = guard;
                 ctx->d_pat = ctx->d_pat_raw + guard;
             }
             HIP_CHECK(hipMalloc((void **)&ctx->d_tcls, maxN * sizeof(int)));
@@ -1475,6 +1502,50 @@ static void check_fraction(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, 
     if (f->min_seq_length < 0 || f->min_seq_length > T) throw cn_error(CN_ERR_SHAPE, "cn_fraction_load: bad min_seq_length");
     if (!f->pat_types || !f->inputs) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: pat_types / inputs missing");
 }
+// Host buffers of a fraction -> pinned staging area -> ONE contiguous upload on the copy stream ([patTypes | classes or targets |
+// inputs]; the two staging areas alternate).  Returns the area and where its parts lie; ev_up[slot] completes with the upload.
+struct Staged { int slot; char *dv; size_t b_pat, b_tgt_al, W; bool cls; };
+static Staged stage_upload(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    const int T = f->max_seq_length;
+    const size_t PS = ctx->PS;
+    const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
+    const size_t rows = (size_t)T * PS;
+    const size_t W = post_output ? (size_t)post_output->size : 0;
+    const size_t b_pat = (rows + 15) & ~(size_t)15;
+    const size_t b_tgt = !post_output ? 0 : (cls ? rows * sizeof(int) : rows * W * sizeof(float));
+    const size_t b_tgt_al = (b_tgt + 15) & ~(size_t)15;
+    const size_t b_in = rows * (size_t)input->size * sizeof(float);
+    const size_t need = b_pat + b_tgt_al + b_in;
+    if (need > ctx->stage_bytes || !ctx->h_stage[0]) {
+        HIP_CHECK(hipDeviceSynchronize());
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->h_stage[i]) HIP_CHECK(hipHostFree(ctx->h_stage[i]));
+            if (ctx->d_stage[i]) HIP_CHECK(hipFree(ctx->d_stage[i]));
+            ctx->stage_used[i] = false;
+        }
+        const size_t maxrows = (size_t)ctx->maxT * PS;
+        size_t cap = ((maxrows + 15) & ~(size_t)15) + ((maxrows * std::max(W * sizeof(float), sizeof(int)) + 15) & ~(size_t)15) + maxrows * (size_t)input->size * sizeof(float);
+        if (cap < need) cap = need;
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipHostMalloc((void **)&ctx->h_stage[i], cap, hipHostMallocDefault));
+            HIP_CHECK(hipMalloc((void **)&ctx->d_stage[i], cap));
+            if (!ctx->ev_up[i]) { HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
+        }
+        if (!ctx->copy) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
+        ctx->stage_bytes = cap;
+    }
+    const int slot = (int)(ctx->upload_idx++ & 1u);
+    if (ctx->stage_used[slot]) HIP_CHECK(hipEventSynchronize(ctx->ev_free[slot]));    // the re-layout kernel two fractions ago has read it
+    char *h = ctx->h_stage[slot], *dv = ctx->d_stage[slot];
+    memcpy(h, f->pat_types, rows);
+    if (post_output) memcpy(h + b_pat, cls ? (const void *)f->target_classes : (const void *)f->targets, b_tgt);
+    memcpy(h + b_pat + b_tgt_al, f->inputs, b_in);
+    HIP_CHECK(hipMemcpyAsync(dv, h, need, hipMemcpyHostToDevice, ctx->copy));
+    HIP_CHECK(hipEventRecord(ctx->ev_up[slot], ctx->copy));
+    return Staged{slot, dv, b_pat, b_tgt_al, W, cls};
+}
+
 static bool same_fraction(const cn_fraction &a, const cn_fraction &b)
 {
     return a.max_seq_length == b.max_seq_length && a.min_seq_length == b.min_seq_length && a.num_sequences == b.num_sequences &&
@@ -1500,9 +1571,10 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
             if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
             cn_ctx::Prefetch &pf = ctx->pf;
-            const bool hit = pf.valid && pf.launched && pf.input == input && pf.post == post_output && same_fraction(pf.f, *f);
+            const bool hit = pf.valid && pf.launched && !pf.host && pf.input == input && pf.post == post_output && same_fraction(pf.f, *f);
             pf.valid = false;          // a prefetch serves the very next load or nothing
             if (hit) {
+                ++pf.hits;
                 // the side stream has re-laid this fraction out already (join_side above ordered this stream behind it): the
                 // alternate buffers become the current ones
                 std::swap(ctx->d_pat, pf.pat); std::swap(ctx->d_pat_raw, pf.pat_raw); std::swap(ctx->d_tcls, pf.tcls);
@@ -1512,15 +1584,29 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             launch_fraction_load(ctx->stream, ctx->f32, T, (int)PS, (int)PSp, f->pat_types, ctx->d_pat,
                                  cls ? f->target_classes : nullptr, ctx->d_tcls,
                                  (post_output && !cls) ? f->targets : nullptr, post_output ? post_output->targets : nullptr,
-                                 post_output ? post_output->size : 0, f->inputs, input->size, input->out_op, input->Lp);
+                                 post_output ? post_output->size : 0, f->inputs, input->size, input->out_op, input->Lp, ctx->rowmap_of(ctx->d_pat_raw), (int)ctx->pat_maxN, f->min_seq_length);
             if (post_output && post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
                 launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
             }
-            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->est_real = f->num_sequences * ((f->min_seq_length + T + 1) / 2); ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
             ctx->loaded = true;
             return;
         }
-        ctx->pf.valid = false;
+        {   // cn_fraction_prefetch announced exactly this fraction and the side stream has re-laid it out (join_side above ordered
+            // this stream behind it): the alternate buffers become the current ones, nothing is copied or launched here
+            cn_ctx::Prefetch &pf = ctx->pf;
+            const bool hit = pf.valid && pf.launched && pf.host && pf.input == input && pf.post == post_output && same_fraction(pf.f_host, *f);
+            pf.valid = false;          // a prefetch serves the very next load or nothing
+            if (hit) {
+                ++pf.hits;
+                std::swap(ctx->d_pat, pf.pat); std::swap(ctx->d_pat_raw, pf.pat_raw); std::swap(ctx->d_tcls, pf.tcls);
+                std::swap(input->out_op, pf.in_op);
+                if (post_output && post_output->targets) std::swap(post_output->targets, pf.targets);
+                ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->est_real = f->num_sequences * ((f->min_seq_length + T + 1) / 2); ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+                ctx->loaded = true;
+                return;
+            }
+        }
         if (ctx->overlap) {
             // Host buffers: pack [patTypes | classes or targets | inputs] into pinned memory, ONE contiguous upload
             // on the copy stream (it runs while the previous fraction still computes: the staging areas alternate),
@@ -1529,54 +1615,24 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
             if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: target_classes missing");
             if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_load: targets missing");
-            const size_t rows = (size_t)T * PS;
-            const size_t W = post_output ? (size_t)post_output->size : 0;
-            const size_t b_pat = (rows + 15) & ~(size_t)15;
-            const size_t b_tgt = !post_output ? 0 : (cls ? rows * sizeof(int) : rows * W * sizeof(float));
-            const size_t b_tgt_al = (b_tgt + 15) & ~(size_t)15;
-            const size_t b_in = rows * (size_t)input->size * sizeof(float);
-            const size_t need = b_pat + b_tgt_al + b_in;
-            if (need > ctx->stage_bytes || !ctx->h_stage[0]) {
-                HIP_CHECK(hipDeviceSynchronize());
-                for (int i = 0; i < 2; ++i) {
-                    if (ctx->h_stage[i]) HIP_CHECK(hipHostFree(ctx->h_stage[i]));
-                    if (ctx->d_stage[i]) HIP_CHECK(hipFree(ctx->d_stage[i]));
-                    ctx->stage_used[i] = false;
-                }
-                const size_t maxrows = (size_t)ctx->maxT * PS;
-                size_t cap = ((maxrows + 15) & ~(size_t)15) + ((maxrows * std::max(W * sizeof(float), sizeof(int)) + 15) & ~(size_t)15) + maxrows * (size_t)input->size * sizeof(float);
-                if (cap < need) cap = need;
-                for (int i = 0; i < 2; ++i) {
-                    HIP_CHECK(hipHostMalloc((void **)&ctx->h_stage[i], cap, hipHostMallocDefault));
-                    HIP_CHECK(hipMalloc((void **)&ctx->d_stage[i], cap));
-                    if (!ctx->ev_up[i]) { HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming)); HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_free[i], hipEventDisableTiming)); }
-                }
-                if (!ctx->copy) HIP_CHECK(hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking));
-                ctx->stage_bytes = cap;
-            }
-            const int slot = (int)(ctx->upload_idx++ & 1u);
-            if (ctx->stage_used[slot]) HIP_CHECK(hipEventSynchronize(ctx->ev_free[slot]));    // the re-layout kernel two fractions ago has read it
-            char *h = ctx->h_stage[slot], *dv = ctx->d_stage[slot];
-            memcpy(h, f->pat_types, rows);
-            if (post_output) memcpy(h + b_pat, cls ? (const void *)f->target_classes : (const void *)f->targets, b_tgt);
-            memcpy(h + b_pat + b_tgt_al, f->inputs, b_in);
-            HIP_CHECK(hipMemcpyAsync(dv, h, need, hipMemcpyHostToDevice, ctx->copy));
-            HIP_CHECK(hipEventRecord(ctx->ev_up[slot], ctx->copy));
+            const Staged sg = stage_upload(ctx, input, post_output, f);
+            const int slot = sg.slot; char *dv = sg.dv; const size_t b_pat = sg.b_pat, b_tgt_al = sg.b_tgt_al, W = sg.W;
             HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_up[slot], 0));
             launch_fraction_load(ctx->stream, ctx->f32, T, (int)PS, (int)PSp, dv, ctx->d_pat,
                                  cls ? (const int *)(dv + b_pat) : nullptr, ctx->d_tcls,
                                  (post_output && !cls) ? (const float *)(dv + b_pat) : nullptr, post_output ? post_output->targets : nullptr,
-                                 (int)W, (const float *)(dv + b_pat + b_tgt_al), input->size, input->out_op, input->Lp);
+                                 (int)W, (const float *)(dv + b_pat + b_tgt_al), input->size, input->out_op, input->Lp, ctx->rowmap_of(ctx->d_pat_raw), (int)ctx->pat_maxN, f->min_seq_length);
             HIP_CHECK(hipEventRecord(ctx->ev_free[slot], ctx->stream));
             ctx->stage_used[slot] = true;
             if (post_output && post_output->kind == CN_LAYER_BINARY_CLASSIFICATION)
                 launch_classes_to_targets(ctx->stream, ctx->d_tcls, post_output->targets, (int)N);
-            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+            ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->est_real = f->num_sequences * ((f->min_seq_length + T + 1) / 2); ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
             ctx->loaded = true;
             return;
         }
         // CN_NO_OVERLAP: strided copies [T][PS] -> [T][PSp]: pad slots keep their permanent NONE / -1 / 0 contents
         HIP_CHECK(hipMemcpy2DAsync(ctx->d_pat, PSp, f->pat_types, PS, PS, T, kind, ctx->stream));
+        launch_rowmap(ctx->stream, ctx->d_pat, (int)N, ctx->rowmap_of(ctx->d_pat_raw), (int)ctx->pat_maxN, f->min_seq_length * (int)PSp);
         const size_t irow = (size_t)input->size * sizeof(float);
         HIP_CHECK(hipMemcpy2DAsync(input->stage_in, PSp * irow, f->inputs, PS * irow, PS * irow, T, kind, ctx->stream));
         if (post_output) {
@@ -1592,7 +1648,7 @@ static int fraction_load(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, co
             }
         }
         launch_pad_convert(ctx->stream, ctx->f32, input->stage_in, (int)N, input->size, input->out_op, input->Lp);
-        ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
+        ctx->T = T; ctx->Tmin = f->min_seq_length; ctx->N = (int)N; ctx->est_real = f->num_sequences * ((f->min_seq_length + T + 1) / 2); ctx->Next = T * (int)PS; ctx->numSeqs = f->num_sequences;
         ctx->loaded = true;
         if (!resident) HIP_CHECK(hipStreamSynchronize(ctx->stream));     // the caller may reuse its host buffers on return
     });
@@ -1606,12 +1662,22 @@ int cn_fraction_load_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_outpu
 {
     return fraction_load(ctx, input, post_output, f, true);
 }
+static int fraction_prefetch(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f, bool host);
 int cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    return fraction_prefetch(ctx, input, post_output, f, false);
+}
+int cn_fraction_prefetch(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f)
+{
+    return fraction_prefetch(ctx, input, post_output, f, true);
+}
+static int fraction_prefetch(cn_ctx *ctx, cn_layer *input, cn_layer *post_output, const cn_fraction *f, bool host)
 {
     if (!ctx || !input || !f) { g_last_error = "cn_fraction_prefetch_resident: NULL argument"; return CN_ERR_BAD_ARG; }
     return guarded([&] {
         enter(ctx);
         check_fraction(ctx, input, post_output, f);
+        if (host && !ctx->overlap) return;            // CN_NO_OVERLAP: no copy stream, no side streams: the load does it all
         const bool cls = post_output && (post_output->kind == CN_LAYER_MULTICLASS_CLASSIFICATION || post_output->kind == CN_LAYER_BINARY_CLASSIFICATION);
         if (post_output && cls && !f->target_classes) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_prefetch_resident: target_classes missing");
         if (post_output && !cls && !f->targets) throw cn_error(CN_ERR_BAD_ARG, "cn_fraction_prefetch_resident: targets missing");
@@ -1619,8 +1685,8 @@ int cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_o
         if (pf.valid && pf.launched) throw cn_error(CN_ERR_STATE, "cn_fraction_prefetch_resident: the previous prefetch has not been consumed by a cn_fraction_load_resident yet");
         if (!pf.allocated) {          // the alternates of the four buffers a fraction is re-laid out into (same initial contents)
             const size_t maxN = input->maxN(), guard = (size_t)CN_GUARD_STEPS * ctx->PSp;
-            HIP_CHECK(hipMalloc((void **)&pf.pat_raw, maxN + 2 * guard));
-            HIP_CHECK(hipMemsetAsync(pf.pat_raw, 0, maxN + 2 * guard, ctx->stream));
+            HIP_CHECK(hipMalloc((void **)&pf.pat_raw, cn_ctx::pat_bytes(maxN, guard)));
+            HIP_CHECK(hipMemsetAsync(pf.pat_raw, 0, cn_ctx::pat_bytes(maxN, guard), ctx->stream));
             pf.pat = pf.pat_raw + guard;
             HIP_CHECK(hipMalloc((void **)&pf.tcls, maxN * sizeof(int)));
             HIP_CHECK(hipMemsetAsync(pf.tcls, 0xFF, maxN * sizeof(int), ctx->stream));
@@ -1629,7 +1695,18 @@ int cn_fraction_prefetch_resident(cn_ctx *ctx, cn_layer *input, cn_layer *post_o
             pf.allocated = true;
         }
         if (post_output && post_output->targets && !pf.targets) pf.targets = (float *)dalloc(post_output, input->maxN() * post_output->size * sizeof(float));
-        pf.f = *f; pf.input = input; pf.post = post_output; pf.launched = false; pf.valid = true;
+        pf.f = *f; pf.input = input; pf.post = post_output; pf.launched = false; pf.host = host;
+        if (host) {
+            // pack and upload NOW (copy stream, beside whatever the device is doing); the re-layout follows on the side stream of the
+            // next gradient work, reading the staging area
+            const Staged sg = stage_upload(ctx, input, post_output, f);
+            pf.f_host = *f; pf.slot = sg.slot;
+            pf.f.pat_types = sg.dv;
+            pf.f.target_classes = (post_output && sg.cls) ? (const int *)(sg.dv + sg.b_pat) : nullptr;
+            pf.f.targets = (post_output && !sg.cls) ? (const float *)(sg.dv + sg.b_pat) : nullptr;
+            pf.f.inputs = (const float *)(sg.dv + sg.b_pat + sg.b_tgt_al);
+        }
+        pf.valid = true;
     });
 }
 
@@ -2194,6 +2271,26 @@ int cn_dbg_gemm_nt(cn_ctx *ctx, const float *A, const float *B, float *C, int M,
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
         }
         hipFree(dA); hipFree(dB); hipFree(dC); hipFree(oA); hipFree(oB); hipFree(dbias); hipFree(dC2);
+    });
+}
+
+int cn_dbg_prefetch_hits(cn_ctx *ctx, int *hits)
+{
+    if (!ctx || !hits) { g_last_error = "cn_dbg_prefetch_hits: NULL argument"; return CN_ERR_BAD_ARG; }
+    *hits = ctx->pf.hits;
+    return CN_OK;
+}
+
+int cn_dbg_row_map_counts(cn_ctx *ctx, int out[3])
+{
+    if (!ctx || !out) { g_last_error = "cn_dbg_row_map_counts: NULL argument"; return CN_ERR_BAD_ARG; }
+    return guarded([&] {
+        enter(ctx);
+        require_loaded(ctx);
+        join_side(ctx);
+        HIP_CHECK(hipMemcpyAsync(out, ctx->rowmap_of(ctx->d_pat_raw), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        out[2] = ctx->N;
     });
 }
 

@@ -343,13 +343,43 @@ __global__ void fraction_load_kernel(int T, int PS, int PSp, const char *pat, ch
         st_op<F32>(dst, idx, (sl < PS && c < P) ? in[(t * PS + sl) * P + c] : 0.f);
     }
 }
+// The row map of a fraction (GemmNT::rowmap): the rows of the real frames and of the dummy ones, each in ascending order, and their
+// counts.  Dummy = patType NONE at a time step >= the fraction's shortest sequence: only there do the recurrent kernels force
+// y = 0 / deltas = 0 (checkPatType, LstmLayer.cu:796,868) -- in front of it an empty slot is computed like any other, by the
+// reference too, and counts as real here.  One workgroup: every thread counts its chunk, a scan over the 1024 counts, every thread writes its
+// chunk's rows.  Runs behind the re-layout on the same stream (beside the backward pass for a prefetched fraction).
+__global__ __launch_bounds__(1024) void rowmap_kernel(const char *pat, int N, int *rm, int maxN, int unchecked)
+{
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, chunk = (N + 1023) / 1024, a = min(N, tid * chunk), b = min(N, a + chunk);
+    int n = 0;
+    for (int i = a; i < b; ++i) n += pat[i] != 0 || i < unchecked;
+    part[tid] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int r = part[tid] - n, d = a - r;          // real / dummy rows in front of this chunk
+    int *real = rm + 4, *dummy = rm + 4 + maxN;
+    for (int i = a; i < b; ++i) { if (pat[i] != 0 || i < unchecked) real[r++] = i; else dummy[d++] = i; }
+    if (tid == 1023) { rm[0] = part[1023]; rm[1] = N - part[1023]; }
+}
+void launch_rowmap(hipStream_t s, const char *dpat, int N, int *rm, int maxN, int unchecked)
+{
+    if (!rm || N <= 0) return;
+    hipLaunchKernelGGL(rowmap_kernel, dim3(1), dim3(1024), 0, s, dpat, N, rm, maxN, unchecked);
+}
 void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
-                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp)
+                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp, int *rm, int maxN, int Tmin)
 {
     long total = (long)T * PSp * Pp; if (total <= 0) return;
     int blocks = (int)((total + 255) / 256); if (blocks > 2048) blocks = 2048;
     if (f32) hipLaunchKernelGGL(fraction_load_kernel<true>, dim3(blocks), dim3(256), 0, s, T, PS, PSp, pat, dpat, tcls, dtcls, tgt, dtgt, W, in, P, dst, Pp);
     else     hipLaunchKernelGGL(fraction_load_kernel<false>, dim3(blocks), dim3(256), 0, s, T, PS, PSp, pat, dpat, tcls, dtcls, tgt, dtgt, W, in, P, dst, Pp);
+    launch_rowmap(s, dpat, T * PSp, rm, maxN, Tmin * PSp);
 }
 
 template <bool BF16>

@@ -93,7 +93,7 @@ template <int BM> struct NtGeom {
 };
 
 template <int PREC, int BM>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int nwg)
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int nwg, int ndw)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using G = NtGeom<BM>;
@@ -106,9 +106,40 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
+    // Row map of the fraction (GemmNT::rowmap): tile row m is row rowmap[m] of A and C for m < nreal; the rows of the dummy
+    // frames are not multiplied at all: they get act(0 + bias[n]) -- what the product gives for an all-zero operand row -- from
+    // the first `ndw` workgroups of the grid, which do nothing else (they start first and run beside the first round of tiles;
+    // in every tile's workgroup instead, the chain count -> row index -> store in front of its k loop cost the headline's input
+    // projection 5 us).  The grid still covers M rows: the host does not know nreal.
+    if ((int)blockIdx.x < ndw) {
+        __shared__ int drow[256];
+        const int ndummy = __builtin_amdgcn_readfirstlane(p.rowcnt[1]);
+        for (int base = blockIdx.x; base < ndummy; base += ndw * 256) {
+            __syncthreads();
+            const int d = base + ndw * tid;
+            drow[tid] = d < ndummy ? p.dummymap[d] : -1;       // this workgroup's next 256 dummy rows: one round of loads
+            __syncthreads();
+            for (int i = 0; i < 256 && drow[i] >= 0; ++i) {
+                const long m = drow[i];
+                for (int n = tid * 4; n < p.N; n += 1024) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias) v = *(const f32x4 *)(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, 0.f + v[e]);       // (0 + bias: what the epilogue computes for a zero sum)
+                    if (p.C) *(f32x4 *)(p.C + m * p.ldc + n) = v;
+                    if (p.C2) {
+                        if constexpr (PREC != P_BF16) *(f32x4 *)((float *)p.C2 + m * p.ldc2 + n) = v;
+                        else *(bf16x4 *)((__bf16 *)p.C2 + m * p.ldc2 + n) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    }
+                }
+            }
+        }
+        return;
+    }
+
     // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous
     // run of tiles so the N-tiles of one A panel hit the same L2 (bijective remap).
-    int bid = blockIdx.x;
+    int bid = blockIdx.x - ndw;
     {
         int q = nwg / 8, r = nwg % 8, x = bid % 8;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + bid / 8;
@@ -118,6 +149,20 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
 
     const char *Ab = (const char *)p.A, *Bb = (const char *)p.B;
     const int nk = (p.K + KB - 1) / KB;
+
+    // (count and row indices are loaded side by side -- one latency in front of the k loop; entries behind nreal are stale, valid
+    // rows -- and kept in LDS for the epilogue: looked up there row by row, each store waited for its own index)
+    __shared__ int crow[128];
+    long arow[G::NLD_A];                       // this thread's rows of A (elements), -1: behind the last row
+    int nreal = p.M;
+    {
+        if (tid < BM) crow[tid] = p.rowmap ? p.rowmap[min(m0 + tid, p.M - 1)] : m0 + tid;
+        if (p.rowcnt) nreal = __builtin_amdgcn_readfirstlane(p.rowcnt[0]);
+        if (m0 >= nreal) return;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::NLD_A; ++j) { const int r = (tid + 256 * j) >> 3; arow[j] = m0 + r < nreal ? (long)crow[r] * p.lda : -1; }
+    }
 
     u32x4 ra[G::NLD_A], rb[4];
     auto gload = [&](int kt) {
@@ -129,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
             if (j < G::NLD_A) ra[j < G::NLD_A ? j : 0] = z;
             rb[j] = z;
             if (k < p.K) {
-                if (j < G::NLD_A && m0 + row < p.M) ra[j < G::NLD_A ? j : 0] = *(const u32x4 *)(Ab + ((long)(m0 + row) * p.lda + k) * ELT);
+                if (j < G::NLD_A && arow[j < G::NLD_A ? j : 0] >= 0) ra[j < G::NLD_A ? j : 0] = *(const u32x4 *)(Ab + (arow[j < G::NLD_A ? j : 0] + k) * ELT);
                 if (n0 + row < p.N) rb[j] = *(const u32x4 *)(Bb + ((long)(n0 + row) * p.ldb + k) * ELT);
             }
         }
@@ -235,17 +280,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmNT p, int tiles_n, int
         if (n < p.N) {
 #pragma unroll
             for (int k = 0; k < ROWS / 8; ++k) {
-                const int row = (tid >> 5) + 8 * k, m = m0 + h * ROWS + row;
-                if (m >= p.M) break;
+                const int row = (tid >> 5) + 8 * k, mt = m0 + h * ROWS + row;
+                if (mt >= nreal) break;
+                const long m = crow[h * ROWS + row];
                 f32x4 v = *(const f32x4 *)(smem + row * EP + c4 * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = act_apply(p.act, v[e] + bv[e]);
-                if (p.C) *(f32x4 *)(p.C + (long)m * p.ldc + n) = v;
+                if (p.C) *(f32x4 *)(p.C + m * p.ldc + n) = v;
                 if (p.C2) {
-                    if constexpr (ELT == 4) *(f32x4 *)((float *)p.C2 + (long)m * p.ldc2 + n) = v;
+                    if constexpr (ELT == 4) *(f32x4 *)((float *)p.C2 + m * p.ldc2 + n) = v;
                     else {
                         const bf16x4 hh = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        *(bf16x4 *)((__bf16 *)p.C2 + (long)m * p.ldc2 + n) = hh;
+                        *(bf16x4 *)((__bf16 *)p.C2 + m * p.ldc2 + n) = hh;
                     }
                 }
             }
@@ -261,12 +307,22 @@ static void launch_nt(hipStream_t s, const GemmNT &g, hipEvent_t done)
     auto kern = gemm_nt_kernel<PREC, BM>;
     static DeviceOnce attr_once;
     if (attr_once.first()) (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    hipExtLaunchKernelGGL(kern, dim3(nwg), dim3(256), G::LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg);
+    // (with a row map: dummy-row workgroups in front, a fraction's dummy rows x N / 4 chunks over them)
+    const int ndw = g.rowcnt ? 96 : 0;
+    hipExtLaunchKernelGGL(kern, dim3(ndw + nwg), dim3(256), G::LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg, ndw);
 }
 
 void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
 {
     if (g.M <= 0 || g.N <= 0) return;
+    {
+        // CUs of the current device, once per device
+        static int cus_of[64] = {0};
+        int dev = 0; (void)hipGetDevice(&dev);
+        int &cus = cus_of[dev & 63];
+        if (!cus) { hipDeviceProp_t prop; cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
+        if (gemm_nt_panel_applies(prec, g, cus)) { launch_gemm_nt_panel(s, g, done); return; }
+    }
     if (gemm_nt_mid_applies(prec, g)) { launch_gemm_nt_mid(s, g, done); return; }
     if (gemm_nt_big_applies(prec, g)) { launch_gemm_nt_big(s, prec, g, done); return; }
     // 64-row tiles when the 128-row grid leaves the chip short of workgroups (< 400 tiles: the N = 256 / 192 products of the

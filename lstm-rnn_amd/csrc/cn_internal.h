@@ -38,7 +38,7 @@ enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
 #define CN_OPTION_LIST(FLAG, NUM)                                                                                                  \
     /* GEMM selection */                                                                                                          \
     FLAG(no_big_gemm) FLAG(no_big8) NUM(big8_min_k, 0) FLAG(no_nt_mid) FLAG(no_big_tn) NUM(nt_bm64_below, 400) NUM(tn_blocks, 0) \
-    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000) NUM(nt_mid_min_tiles, 384) NUM(nt_bm64_shortk_tiles, 1100)                                                                           \
+    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000) NUM(nt_mid_min_tiles, 384) NUM(nt_bm64_shortk_tiles, 1100) FLAG(no_nt_panel) NUM(nt_panel_max_panels, 0) FLAG(nt_panel_no_touch) NUM(nt_panel_min_ktiles, 8) NUM(nt_panel_max_ntiles, 2) FLAG(no_nt_rowmap)                                                                           \
     /* recurrent kernel selection */                                                                                              \
     FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
     FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \
@@ -82,6 +82,12 @@ struct GemmNT {            // C[m][n] = sum_k A[m][k] * B[n][k]   (+ bias[n]) ->
     const float *bias;            // [N] fp32 added before the activation (nullable)
     int act;                      // Act
     int M, N, K;                  // K multiple of 8 (bf16) / 4 (f32); N multiple of 32
+    // Row map of the fraction (launch_rowmap; nullable): rowcnt[0] real frames whose rows are rowmap[0 ..), rowcnt[1] dummy ones
+    // (patType NONE at a time step where the kernels check it: pad slots, frames behind the end of a sequence) in dummymap[0 ..).  A kernel that takes the map computes the
+    // real rows only and writes bias[n] (or 0) into the dummy rows -- what the full product gives there, because every operand row
+    // of a dummy frame is zero (zero-padded inputs, y = 0 by ComputeBlockOutputFn's dummy rule, deltas = 0 by ComputeBlockErrorsFn's).
+    // Kernels that do not take it compute all M rows.  m_est: the host's estimate of rowcnt[0] (0: M), for the dispatch only.
+    const int *rowmap, *dummymap, *rowcnt; int m_est;
 };
 struct GemmTN {            // C[m][n] += sum_k A[k][m] * B[k][n]   k in [0,K), fp32 atomics (split-K)
     const void *A; long lda;      // [K][M] op
@@ -110,6 +116,9 @@ bool gemm_nt_big_applies(int prec, const GemmNT &g);
 void launch_gemm_nt_big(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done = nullptr);
 // 128 x 256 tiles, two workgroups per CU, for the output-bound short-K products (cn_gemm_nt_mid.hip)
 bool gemm_nt_mid_applies(int prec, const GemmNT &g);
+// one 64-row panel per CU walked as one fill pipeline, for the N-wide products of short fractions (cn_gemm_nt_panel.hip)
+bool gemm_nt_panel_applies(int prec, const GemmNT &g, int cus);
+void launch_gemm_nt_panel(hipStream_t s, const GemmNT &g, hipEvent_t done = nullptr);
 void launch_gemm_nt_mid(hipStream_t s, const GemmNT &g, hipEvent_t done = nullptr);
 // cu_budget: CUs the launch may fill with its one-per-CU workgroups when it goes to the 256 x 256 kernel (0 = the chip)
 // `extra` (deterministic mode, nullable): one more fold that rides on the launch that adds this product's split partials (the
@@ -227,8 +236,11 @@ void launch_ff_pack(hipStream_t s, bool f32, const FfGeom &g, float bias, const 
 void launch_ff_unpack_grads(hipStream_t s, const FfGeom &g, float bias, float *dW, float *colsum, float *wu, hipEvent_t done = nullptr);
 
 // inputs [N][P] fp32 (reference layout) -> [N][Pp] op, zero padded
+// rm (nullable): the fraction's row map, built behind the re-layout: rm[0] real frames, rm[1] dummy ones, rm[4 ..) the real rows in
+// ascending order, rm[4 + maxN ..) the dummy rows
+void launch_rowmap(hipStream_t s, const char *dpat, int N, int *rm, int maxN, int unchecked);    // rows < unchecked count as real
 void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
-                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp);
+                          const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp, int *rm = nullptr, int maxN = 0, int Tmin = 0);
 void launch_pad_convert(hipStream_t s, bool f32, const float *src, int N, int P, void *dst, int Pp);
 // delta = act'(y) * err (in place on err, all N slots: FeedForwardLayer.cu:72-79), op copy for the GEMMs
 void launch_ff_delta(hipStream_t s, bool f32, int act, const float *y, float *err, void *delta_op, int N, int L, int Lp);

@@ -97,9 +97,8 @@ layers::InputLayer &NeuralNetwork::inputLayer() { return static_cast<layers::Inp
 layers::TrainableLayer &NeuralNetwork::outputLayer() { return static_cast<layers::TrainableLayer &>(*m_layers[m_layers.size() - 2]); }
 layers::PostOutputLayer &NeuralNetwork::postOutputLayer() { return static_cast<layers::PostOutputLayer &>(*m_layers.back()); }
 
-void NeuralNetwork::loadSequences(const data_sets::DataSetFraction &fraction)
+static cn_fraction describe(const data_sets::DataSetFraction &fraction)
 {
-    for (size_t i = 0; i < m_layers.size(); ++i) m_layers[i]->loadSequences(fraction);   // shape checks + host-side bookkeeping
     cn_fraction f;
     f.max_seq_length = fraction.maxSeqLength(); f.min_seq_length = fraction.minSeqLength();
     f.num_sequences = fraction.numSequences();
@@ -107,6 +106,19 @@ void NeuralNetwork::loadSequences(const data_sets::DataSetFraction &fraction)
     f.pat_types = fraction.patTypes().data(); f.inputs = fraction.inputs().data();
     f.target_classes = fraction.targetClasses().empty() ? 0 : fraction.targetClasses().data();
     f.targets = fraction.outputs().empty() ? 0 : fraction.outputs().data();
+    return f;
+}
+
+void NeuralNetwork::prefetchSequences(const data_sets::DataSetFraction &fraction)
+{
+    const cn_fraction f = describe(fraction);
+    hipCheck(cn_fraction_prefetch(m_ctx, m_layers.front()->handle(), m_layers.back()->handle(), &f), m_ctx);
+}
+
+void NeuralNetwork::loadSequences(const data_sets::DataSetFraction &fraction)
+{
+    for (size_t i = 0; i < m_layers.size(); ++i) m_layers[i]->loadSequences(fraction);   // shape checks + host-side bookkeeping
+    const cn_fraction f = describe(fraction);
     // (no synchronisation: cn_fraction_load has copied the host vectors into pinned staging memory when it returns, so
     // the caller may release them, and the upload runs under the previous fraction's compute)
     hipCheck(cn_fraction_load(m_ctx, m_layers.front()->handle(), m_layers.back()->handle(), &f), m_ctx);

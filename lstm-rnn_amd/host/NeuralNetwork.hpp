@@ -26,6 +26,7 @@ public:
     layers::PostOutputLayer &postOutputLayer();
 
     void loadSequences(const data_sets::DataSetFraction &fraction);    // NeuralNetwork.cpp:161-166
+    void prefetchSequences(const data_sets::DataSetFraction &fraction);   // cn_fraction_prefetch: what the next loadSequences will load
     void computeForwardPass();                                         // :168-173
     void computeBackwardPass();                                        // :175-184
     // Data-parallel training: bind this rank's RCCL communicator (collective; `id` = the CN_COMM_ID_BYTES rank 0 got from

@@ -52,12 +52,19 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
     // added up on the device, in the same order and in float like the reference's `error += ...`, and read back once
     // per pass over the data set: the host keeps enqueueing fractions while the device works.
     hipCheck(cn_loss_read(m_neuralNetwork.context(), nullptr, nullptr, 1), m_neuralNetwork.context());     // clear the sums
-    data_sets::DataSetFraction frac;
+    data_sets::DataSetFraction frac, next;
     bool firstFraction = true;
-    while (ds.getNextFraction(&frac)) {
+    bool have = ds.getNextFraction(&frac);
+    while (have) {
         m_neuralNetwork.loadSequences(frac);
         m_neuralNetwork.computeForwardPass();
         hipCheck(cn_loss_accumulate(m_neuralNetwork.postOutputLayer().handle()), m_neuralNetwork.context());
+        // The data set's worker has the next fraction ready one ahead (DataSet.cpp:202-240,632-668); in training it goes on
+        // across PCIe and through the re-layout beside this fraction's backward pass (cn_fraction_prefetch), and the load at
+        // the top of the next iteration only exchanges buffers.  (`next` keeps its vectors' storage when it becomes `frac`:
+        // the hint is matched by address.)
+        const bool haveNext = ds.getNextFraction(&next);
+        if (haveNext && calcWeightUpdates) m_neuralNetwork.prefetchSequences(next);
 
         if (calcWeightUpdates) {
             // weight noise: the forward pass above used the clean weights, the backward pass runs on noisy ones
@@ -93,6 +100,8 @@ real_t Optimizer::_processDataSet(data_sets::DataSet &ds, bool calcWeightUpdates
             }
         }
         firstFraction = false;
+        have = haveNext;
+        if (have) std::swap(frac, next);
     }
     if (calcWeightUpdates && !m_hybridOnlineBatch) _updateWeights();
     {

@@ -186,7 +186,7 @@ class NeuralNetwork:
                 return l
         raise KeyError(name)
 
-    def load_sequences(self, frac):                                                    # NeuralNetwork.cpp:161-166
+    def _host_descriptor(self, frac):
         x = np.ascontiguousarray(frac["inputs"], np.float32)
         pat = np.ascontiguousarray(frac["patTypes"], np.int8)
         f = B.Fraction()
@@ -207,10 +207,21 @@ class NeuralNetwork:
             keep.append(tg)
             f.targets = tg.ctypes.data_as(C.c_void_p)
             f.output_pattern_size = int(tg.shape[-1])
+        return f, keep
+
+    def load_sequences(self, frac):                                                    # NeuralNetwork.cpp:161-166
+        f, keep = self._host_descriptor(frac)
         # (the library copies the host arrays into pinned staging memory before it returns: nothing to wait for)
-        B.check(self.lib.cn_fraction_load(self.ctx, self.layers[0].handle, post.handle, C.byref(f)), self.ctx)
+        B.check(self.lib.cn_fraction_load(self.ctx, self.layers[0].handle, self.layers[-1].handle, C.byref(f)), self.ctx)
         self.T, self.Tmin = f.max_seq_length, f.min_seq_length
         self.N = self.T * self.PS
+
+    def prefetch_sequences(self, frac):
+        """cn_fraction_prefetch: `frac` (host arrays, as for load_sequences) is what the next load_sequences will load -- the
+        reference's loader thread one fraction ahead (DataSet.cpp:202-240), here across PCIe and through the re-layout as well.
+        The arrays must be the same objects (already contiguous float32 / int8 / int32) at that load: it matches by address."""
+        f, keep = self._host_descriptor(frac)
+        B.check(self.lib.cn_fraction_prefetch(self.ctx, self.layers[0].handle, self.layers[-1].handle, C.byref(f)), self.ctx)
 
     def _resident_descriptor(self, dfrac):
         f = B.Fraction()
@@ -339,6 +350,18 @@ class NeuralNetwork:
             if lay.type in ("lstm", "blstm"):
                 return self.lib.cn_layer_recurrent_kernel(lay.handle, 1 if backward else 0).decode()
         return ""
+
+    def prefetch_hits(self):
+        """Loads that found their fraction announced and re-laid out ahead (cn_dbg_prefetch_hits)."""
+        n = C.c_int(0)
+        B.check(self.lib.cn_dbg_prefetch_hits(self.ctx, C.byref(n)), self.ctx)
+        return n.value
+
+    def row_map_counts(self):
+        """(computed frames, dummy frames, T x padded parallel sequences) of the loaded fraction's row map (cn_dbg_row_map_counts)."""
+        out = (C.c_int * 3)()
+        B.check(self.lib.cn_dbg_row_map_counts(self.ctx, out), self.ctx)
+        return tuple(out)
 
     def bf16_preactivation_layers(self):
         """Names of the LSTM layers whose input projection hands its pre-activations to the recurrent kernel as bf16

@@ -71,6 +71,63 @@ def test_gemm_nt_mid_is_exact_on_small_integers(lib, shape):
     assert np.array_equal(out, ref), np.argwhere(out != ref)[:4]
 
 
+def _panel_everywhere(L, B, ctx):
+    """By default the panel kernel takes K >= 512 on at most two column tiles and one round of CUs; the tests want it on every shape."""
+    for name, value in ((b"nt_panel_min_ktiles", 1), (b"nt_panel_max_ntiles", 8), (b"nt_panel_max_panels", 384)):
+        B.check(L.cn_ctx_set_option(ctx, name, value), ctx)
+
+
+@pytest.mark.parametrize("flag", [0, 0x100, 0x200])
+@pytest.mark.parametrize("with_bias", [True, False])
+@pytest.mark.parametrize("shape", [(15000, 1024, 256), (14824, 256, 1024), (14824, 1024, 64), (15000, 192, 256), (15000, 256, 192),
+                                   (61, 32, 64), (130, 1792, 128), (16001, 992, 320), (3000, 288, 1024)])
+def test_gemm_nt_panel_is_exact_on_small_integers(lib, shape, with_bias, flag):
+    """The one-panel-per-CU kernel (cn_gemm_nt_panel.hip; bf16, identity, K in whole k-tiles of 64, N <= 1792): shapes of the N-wide
+    products of the headline step and edge cases (the last shape is what the default dispatch gives it).  Operands and bias are small integers, so every product and every fp32
+    partial sum is exact and the result must EQUAL numpy's -- a chunk taken from the wrong place (the fill's XOR placement, the
+    clamped edge rows and columns, a k-tile consumed before it landed: the counted vmcnt waits run across tile boundaries and
+    count the stores of the tile before) cannot hide inside a tolerance.  flag: fp32 result / both results / the bf16 copy alone."""
+    L, B = lib
+    M, N, K = shape
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randint(-3, 4, (M, K)).astype(np.float32); Bm = rng.randint(-3, 4, (N, K)).astype(np.float32)
+    bias = rng.randint(-5, 6, N).astype(np.float32)
+    if flag:            # (the copy is bf16: keep the sums exactly representable -- 8 bits)
+        A = (A > 1).astype(np.float32); Bm = np.sign(Bm) * (np.abs(Bm) > 2); bias = np.sign(bias)
+        Bm[:, 48:] = 0
+    out = np.full((M, N), 7.0, np.float32)
+    ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+    try:
+        _panel_everywhere(L, B, ctx)
+        for rep in range(3):
+            B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data if with_bias else None, 2 | flag), ctx)
+            ref = A.astype(np.int64) @ Bm.astype(np.int64).T + (bias.astype(np.int64) if with_bias else 0)
+            assert np.abs(ref).max() < (256 if flag else 1 << 24)
+            assert np.array_equal(out, ref.astype(np.float32)), (rep, np.argwhere(out != ref)[:4])
+    finally:
+        L.cn_ctx_destroy(ctx)
+
+
+def test_gemm_nt_panel_matches_the_tiled_kernel_bit_for_bit(lib):
+    """Same k order, same MFMA (operands swapped): the panel kernel and gemm_nt_kernel agree to the bit on random operands."""
+    L, B = lib
+    M, N, K = 14824, 1024, 256
+    rng = np.random.RandomState(5)
+    A = rng.randn(M, K).astype(np.float32); Bm = rng.randn(N, K).astype(np.float32); bias = rng.randn(N).astype(np.float32)
+    outs = []
+    for off in (0, 1):
+        out = np.zeros((M, N), np.float32)
+        ctx = C.c_void_p(); B.check(L.cn_ctx_create(0, 1, None, C.byref(ctx)))
+        try:
+            _panel_everywhere(L, B, ctx)
+            B.check(L.cn_ctx_set_option(ctx, b"no_nt_panel", off), ctx)
+            B.check(L.cn_dbg_gemm_nt(ctx, A.ctypes.data, Bm.ctypes.data, out.ctypes.data, M, N, K, bias.ctypes.data, 2), ctx)
+        finally:
+            L.cn_ctx_destroy(ctx)
+        outs.append(out)
+    assert np.array_equal(outs[0], outs[1]), np.abs(outs[0] - outs[1]).max()
+
+
 @pytest.mark.parametrize("with_bias", [True, False])
 @pytest.mark.parametrize("shape", [(4200, 6176, 256), (9000, 3104, 320), (7000, 4128, 832)])
 def test_gemm_nt_persistent_kernel_is_repeatable(lib, shape, with_bias, monkeypatch):

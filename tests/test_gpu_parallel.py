@@ -477,6 +477,61 @@ def test_prefetched_resident_fraction_equals_plain_load(pkg, post):
         assert np.abs(res[mode][1] - res["plain"][1]).max() < 1e-5, mode
 
 
+@pytest.mark.parametrize("post", ["multiclass_classification", "sse", "binary_classification"])
+def test_prefetched_host_fraction_equals_plain_load(pkg, post):
+    """cn_fraction_prefetch (host buffers; the reference's loader thread works one fraction ahead, DataSet.cpp:202-240): the next
+    fraction is packed and uploaded at once, re-laid out on the side stream beside the backward pass, and the load only exchanges
+    buffers.  Same protocol as the resident test: six training steps over three fractions of different lengths give the same
+    outputs and errors per step and the same weights as loads without the hint; a load of ANOTHER fraction than the announced
+    one discards the hint (and its staging area is reused later without harm); a second announcement while one is in flight is
+    CN_ERR_STATE; a resident load does not take a host hint."""
+    rng = np.random.RandomState(41)
+    P, PS = 5, 6
+    C = 1 if post == "binary_classification" else 4
+    layers = net_desc(P, [("blstm", 12), ("lstm", 8)], C, post=post)
+    if post == "binary_classification":
+        layers[-2]["type"] = "feedforward_logistic"
+    weights = random_weights(layers, rng, 0.4)
+    fracs = []
+    for lens in ([9, 7, 4, 6, 9], [5, 5, 3], [8, 8, 8, 8, 2, 1]):
+        if post == "sse":
+            xs, ts = random_sequences(rng, lens, P, L=C)
+            fr = pkg.make_fraction(xs, ts, PS, classification=False)
+        else:
+            xs, ts = random_sequences(rng, lens, P, C=max(C, 2))
+            fr = pkg.make_fraction(xs, ts, PS)
+        # (the hint is matched by address: the arrays handed over must be the ones the load will hand over)
+        fr["inputs"] = np.ascontiguousarray(fr["inputs"], np.float32); fr["patTypes"] = np.ascontiguousarray(fr["patTypes"], np.int8)
+        if fr.get("targetClasses") is not None: fr["targetClasses"] = np.ascontiguousarray(fr["targetClasses"], np.int32)
+        if fr.get("targets") is not None: fr["targets"] = np.ascontiguousarray(fr["targets"], np.float32)
+        fracs.append(fr)
+    order = [0, 1, 2, 0, 2, 1, 1, 0]
+    res = {}
+    for mode in ("plain", "prefetch", "wrong_hint"):
+        with pkg.NeuralNetwork(layers, weights, PS, 9, precision=pkg.PREC_F32) as net:
+            trace = []
+            for i, k in enumerate(order):
+                net.load_sequences(fracs[k])
+                net.compute_forward_pass()
+                e, c = net.error_and_correct()
+                trace.append((net.outputs().copy(), e, c))
+                if mode != "plain" and i + 1 < len(order):
+                    nxt = order[i + 1] if mode == "prefetch" else (order[i + 1] + 1) % 3
+                    net.prefetch_sequences(fracs[nxt])
+                net.compute_backward_pass()
+                if mode == "prefetch" and i == 0:
+                    with pytest.raises(pkg.CurrenntHipError, match="has not been consumed"):
+                        net.prefetch_sequences(fracs[0])
+                net.update_weights_fused(1e-2, 0.9)
+            # every announced fraction but none of the wrong ones was taken over by its load
+            assert net.prefetch_hits() == {"plain": 0, "prefetch": len(order) - 1, "wrong_hint": 0}[mode], (mode, net.prefetch_hits())
+            res[mode] = (trace, np.concatenate([l.weights() for l in net.trainable_layers()]))
+    for mode in ("prefetch", "wrong_hint"):
+        for (o, e, c), (o0, e0, c0) in zip(res[mode][0], res["plain"][0]):
+            assert np.abs(o - o0).max() < 1e-5 and abs(e - e0) <= 1e-4 * max(1.0, abs(e0)) and c == c0, mode
+        assert np.abs(res[mode][1] - res["plain"][1]).max() < 1e-5, mode
+
+
 def test_prefetch_hint_without_side_stream_work_is_dropped(pkg):
     """A network whose only trainable layer computes its gradient on the main stream (nothing runs beside the backward pass): the
     announced fraction is never re-laid out ahead, the load that follows takes the ordinary path, results equal the unhinted run."""

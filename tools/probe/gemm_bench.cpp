@@ -1,10 +1,14 @@
 // Times launch_gemm_nt / launch_gemm_tn on the shapes of the headline workload (bf16 operands, random data).
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -c tools/probe/gemm_bench.cpp -o /tmp/gb.o &&
-//        hipcc --offload-arch=gfx950 /tmp/gb.o lstm-rnn_amd/csrc/cn_gemm.o lstm-rnn_amd/csrc/cn_gemm_big.o lstm-rnn_amd/csrc/cn_gemm_tn_big.o lstm-rnn_amd/csrc/cn_gemm_nt_mid.o -o tools/probe/gemm_bench
+//        hipcc --offload-arch=gfx950 /tmp/gb.o -Llstm-rnn_amd -lcurrennt_hip -Wl,-rpath,'$ORIGIN/../../lstm-rnn_amd' -o tools/probe/gemm_bench
+// Options: the CN_<NAME> environment variables of cn_internal.h's option list (the library's process defaults: the probe has no context).
+// GEMM_BENCH_NO_TN=1 skips the weight-gradient shapes.  GEMM_BENCH_COLD=1: every nt launch behind a cache flush, timed alone.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <string>
+#include <cctype>
 
 #include "../../lstm-rnn_amd/csrc/cn_internal.h"
 
@@ -61,11 +65,27 @@ int main()
         float *C, *bias; CK(hipMalloc((void **)&C, (size_t)c.M * c.N * 4)); CK(hipMalloc((void **)&bias, c.N * 4)); CK(hipMemset(bias, 0, c.N * 4));
         GemmNT g{}; g.A = A; g.lda = c.K; g.B = B; g.ldb = c.K; g.C = C; g.ldc = c.N; g.bias = bias; g.act = ACT_IDENTITY; g.M = c.M; g.N = c.N; g.K = c.K;
         for (int i = 0; i < 3; ++i) launch_gemm_nt(s, false, g);
-        CK(hipEventRecord(e0, s));
         const int reps = 20;
+        float ms;
+        if (getenv("GEMM_BENCH_COLD")) {
+            // every launch behind a 600 MB fill (L2s and Infinity Cache hold nothing of the operands: the situation inside a
+            // training step, where 1.4 GB pass between two uses of anything), timed alone
+            static char *flush = nullptr;
+            if (!flush) CK(hipMalloc((void **)&flush, 600u << 20));
+            ms = 0.f;
+            for (int i = 0; i < reps; ++i) {
+                CK(hipMemsetAsync(flush, i, 600u << 20, s));
+                CK(hipEventRecord(e0, s));
+                launch_gemm_nt(s, false, g);
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float one; CK(hipEventElapsedTime(&one, e0, e1)); ms += one;
+            }
+        } else {
+        CK(hipEventRecord(e0, s));
         for (int i = 0; i < reps; ++i) launch_gemm_nt(s, false, g);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        }
         double us = ms * 1e3 / reps, bytes = (double)c.M * c.N * 4 + (double)c.M * c.K * 2 + (double)c.N * c.K * 2, fl = 2.0 * c.M * c.N * c.K;
         printf("gemm_nt M=%5d N=%4d K=%4d  %7.1f us  %6.0f GB/s (compulsory bytes)  %6.1f TFLOP/s   %s\n", c.M, c.N, c.K, us, bytes / us * 1e-3, fl / us * 1e-6, c.what);
 #ifdef B8_STAMP
@@ -76,6 +96,7 @@ int main()
     struct S tn[] = {{1024, 256, 15600, "dW_in layer 2/3"}, {1024, 64, 15600, "dW_in layer 1"}, {512, 128, 15548, "dW_rec per direction"}, {192, 256, 15600, "softmax dW"}, {8000, 1024, 25600, "LVCSR softmax dW"},
                    {2048, 512, 35200, "LVCSR dW_in of layers 2-4 (blstm512), T = 550"}, {1024, 256, 35136, "LVCSR dW_rec per direction"}, {8000, 512, 35200, "LVCSR softmax dW as run by bench.py"},
                    {2048, 512, 15600, "reading B dW_in (Hp = 256)"}, {1024, 256, 15548, "reading B dW_rec per direction"}, {4096, 1024, 32000, "long-utterance dW_in (Hp = 512)"}};
+    if (getenv("GEMM_BENCH_NO_TN")) return 0;
     const int tn_first = getenv("GEMM_BENCH_TN_FIRST") ? atoi(getenv("GEMM_BENCH_TN_FIRST")) : 0;      // skip the first n tn shapes
     int itn = 0;
     for (auto &c : tn) {
