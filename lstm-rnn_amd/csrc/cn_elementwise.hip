@@ -346,31 +346,45 @@ __global__ void fraction_load_kernel(int T, int PS, int PSp, const char *pat, ch
 // The row map of a fraction (GemmNT::rowmap): the rows of the real frames and of the dummy ones, each in ascending order, and their
 // counts.  Dummy = patType NONE at a time step >= the fraction's shortest sequence: only there do the recurrent kernels force
 // y = 0 / deltas = 0 (checkPatType, LstmLayer.cu:796,868) -- in front of it an empty slot is computed like any other, by the
-// reference too, and counts as real here.  One workgroup: every thread counts its chunk, a scan over the 1024 counts, every thread writes its
-// chunk's rows.  Runs behind the re-layout on the same stream (beside the backward pass for a prefetched fraction).
-__global__ __launch_bounds__(1024) void rowmap_kernel(const char *pat, int N, int *rm, int maxN, int unchecked)
+// reference too, and counts as real here.  One workgroup: every thread counts its chunk, a scan over the 1024 counts (shuffles inside a wave, 16 wave
+// sums through LDS), every thread writes its chunk's rows.  Runs behind the re-layout on the same stream (beside the backward pass for a prefetched fraction).
+__global__ __launch_bounds__(1024) void rowmap_kernel(const char *pat, int N, int *rm, int maxN, int unchecked, int staged)
 {
-    __shared__ int part[1024];
-    const int tid = threadIdx.x, chunk = (N + 1023) / 1024, a = min(N, tid * chunk), b = min(N, a + chunk);
-    int n = 0;
-    for (int i = a; i < b; ++i) n += pat[i] != 0 || i < unchecked;
-    part[tid] = n;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = tid >= off ? part[tid - off] : 0;
+    extern __shared__ __attribute__((aligned(16))) char spat[];
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (N + 1023) / 1024, a = min(N, tid * chunk), b = min(N, a + chunk);
+    // (a thread's chunk is a run of single bytes: read from memory one by one it is a chain of ~2 x 18 dependent loads, 15 us for
+    // the headline's 18 000 frames; staged through LDS in 16-byte pieces first when the fraction fits)
+    const char *src = pat;
+    if (staged) {
+        for (int i = tid * 16; i < N; i += 1024 * 16) {
+            if (i + 16 <= N && ((size_t)(pat + i) & 15) == 0) *(uint4 *)(spat + i) = *(const uint4 *)(pat + i);
+            else for (int j = i; j < min(N, i + 16); ++j) spat[j] = pat[j];
+        }
         __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+        src = spat;
     }
-    int r = part[tid] - n, d = a - r;          // real / dummy rows in front of this chunk
+    int n = 0;
+    for (int i = a; i < b; ++i) n += src[i] != 0 || i < unchecked;
+    int x = n;                                 // inclusive scan over the wave's 64 counts, then over the 16 waves
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int v = wsum[w]; total += v; if (w < wave) base += v; }
+    int r = base + x - n, d = a - r;           // real / dummy rows in front of this chunk
     int *real = rm + 4, *dummy = rm + 4 + maxN;
-    for (int i = a; i < b; ++i) { if (pat[i] != 0 || i < unchecked) real[r++] = i; else dummy[d++] = i; }
-    if (tid == 1023) { rm[0] = part[1023]; rm[1] = N - part[1023]; }
+    for (int i = a; i < b; ++i) { if (src[i] != 0 || i < unchecked) real[r++] = i; else dummy[d++] = i; }
+    if (tid == 0) { rm[0] = total; rm[1] = N - total; }
 }
 void launch_rowmap(hipStream_t s, const char *dpat, int N, int *rm, int maxN, int unchecked)
 {
     if (!rm || N <= 0) return;
-    hipLaunchKernelGGL(rowmap_kernel, dim3(1), dim3(1024), 0, s, dpat, N, rm, maxN, unchecked);
+    const int staged = N <= 60 * 1024;
+    hipLaunchKernelGGL(rowmap_kernel, dim3(1), dim3(1024), staged ? (N + 15) & ~15 : 0, s, dpat, N, rm, maxN, unchecked, staged);
 }
 void launch_fraction_load(hipStream_t s, bool f32, int T, int PS, int PSp, const char *pat, char *dpat, const int *tcls, int *dtcls,
                           const float *tgt, float *dtgt, int W, const float *in, int P, void *dst, int Pp, int *rm, int maxN, int Tmin)

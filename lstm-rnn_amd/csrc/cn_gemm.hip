@@ -312,9 +312,10 @@ static void launch_nt(hipStream_t s, const GemmNT &g, hipEvent_t done)
     hipExtLaunchKernelGGL(kern, dim3(ndw + nwg), dim3(256), G::LDS_BYTES, s, nullptr, done, 0, g, tiles_n, nwg, ndw);
 }
 
-void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
+void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g_in, hipEvent_t done)
 {
-    if (g.M <= 0 || g.N <= 0) return;
+    if (g_in.M <= 0 || g_in.N <= 0) return;
+    GemmNT g = g_in;
     {
         // CUs of the current device, once per device
         static int cus_of[64] = {0};
@@ -323,6 +324,10 @@ void launch_gemm_nt(hipStream_t s, int prec, const GemmNT &g, hipEvent_t done)
         if (!cus) { hipDeviceProp_t prop; cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256; }
         if (gemm_nt_panel_applies(prec, g, cus)) { launch_gemm_nt_panel(s, g, done); return; }
     }
+    // The tiled kernels below multiply every row unless asked otherwise: gemm_nt_kernel takes the row map too (option
+    // nt_rowmap_tiled; tests/test_gpu_rowmap.py runs it), but 15 % fewer rows buy it nothing inside the headline step (input
+    // projections 27 -> 27 us: store-bound, and the dummy rows are written all the same; softmax products 10.3 -> 11-13)
+    if (!opt().nt_rowmap_tiled) { g.rowmap = g.dummymap = g.rowcnt = nullptr; g.m_est = 0; }
     if (gemm_nt_mid_applies(prec, g)) { launch_gemm_nt_mid(s, g, done); return; }
     if (gemm_nt_big_applies(prec, g)) { launch_gemm_nt_big(s, prec, g, done); return; }
     // 64-row tiles when the 128-row grid leaves the chip short of workgroups (< 400 tiles: the N = 256 / 192 products of the

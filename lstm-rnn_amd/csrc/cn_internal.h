@@ -38,7 +38,7 @@ enum Prec { P_BF16 = 0, P_F32 = 1, P_X3 = 2 };
 #define CN_OPTION_LIST(FLAG, NUM)                                                                                                  \
     /* GEMM selection */                                                                                                          \
     FLAG(no_big_gemm) FLAG(no_big8) NUM(big8_min_k, 0) FLAG(no_nt_mid) FLAG(no_big_tn) NUM(nt_bm64_below, 400) NUM(tn_blocks, 0) \
-    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000) NUM(nt_mid_min_tiles, 384) NUM(nt_bm64_shortk_tiles, 1100) FLAG(no_nt_panel) NUM(nt_panel_max_panels, 0) FLAG(nt_panel_no_touch) NUM(nt_panel_min_ktiles, 8) NUM(nt_panel_max_ntiles, 2) FLAG(no_nt_rowmap)                                                                           \
+    NUM(tnbig_blocks, 0) NUM(tnbig_group_mink, 28000) NUM(nt_mid_min_tiles, 384) NUM(nt_bm64_shortk_tiles, 1100) FLAG(no_nt_panel) NUM(nt_panel_max_panels, 0) FLAG(nt_panel_no_touch) NUM(nt_panel_min_ktiles, 8) NUM(nt_panel_max_ntiles, 2) FLAG(no_nt_rowmap) FLAG(nt_rowmap_tiled)                                                                           \
     /* recurrent kernel selection */                                                                                              \
     FLAG(no_lds_claim) FLAG(bwd_ug2) FLAG(fwd_ug2) FLAG(bwd_psum) FLAG(no_bwd_psum) FLAG(cluster_helpers) FLAG(no_cluster_helpers) \
     FLAG(cluster4) FLAG(no_cluster) FLAG(cluster_gate_off) FLAG(no_s2c) FLAG(s2c) FLAG(no_s2_asm) FLAG(no_s2_asm_bwd) FLAG(s2_x3) \

@@ -27,6 +27,7 @@ def _run(pkg, layers, weights, fracs, PS, T, off, mode):
     prec = {"bf16": pkg.PREC_BF16, "bf16x3": pkg.PREC_BF16X3}[mode]
     with pkg.NeuralNetwork(layers, weights, PS, T, precision=prec, deterministic=True) as net:
         net.set_option("no_nt_rowmap", off)
+        net.set_option("nt_rowmap_tiled", 1)      # (by default only the panel kernel takes the map; the tiled kernel's path is tested here too)
         out = {"err": [], "post": [], "oerr": []}
         for k, f in enumerate(fracs * 2):
             net.load_sequences(f); net.compute_forward_pass(); out["err"].append(net.calculate_error())
