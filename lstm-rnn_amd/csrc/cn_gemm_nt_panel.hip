@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(GemmNT p, int tiles_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave8 >= 4;
-    const int wave = wave8 & 3;                                 // multiplying wave: its 64 columns of a tile; loader: 0 .. 2 bring B, 3 brings A
+    const int wave = wave8 & 3;                                 // multiplying wave: its 64 columns of a tile; loader: its quarter of the pieces
     const int fr = lane & 31, fh = lane >> 5;
     const int m0 = blockIdx.x * NP_BM;
     // row map (GemmNT::rowmap): panel row m is row rowmap[m] of A and C, m < nreal; the dummy rows get bias / 0 at the end
@@ -289,6 +289,9 @@ __global__ __launch_bounds__(512) void gemm_nt_panel_kernel(GemmNT p, int tiles_
             kt = 0; ++nt;
         }
     }
+    // (a touch lands in LDS: none may be in flight when the workgroup's LDS goes back to the CU -- with a dozen k-tiles behind the
+    // last one they have landed long ago, with one or two they may not have)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
