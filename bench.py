@@ -182,6 +182,15 @@ def gemm_roofline(wl, precision, tm, frames, steps):
                     "products": len(prods), "products_hbm_bound": int(hbm_bound), "launches": tm[cls][1]}
     out["note"] = ("roof = sum over the class's products of max(flop / %.0f TFLOP/s, algorithmic bytes / %.0f GB/s); frac = roof / achieved device "
                    "time (hipEvents on the launching stream); gemm_grad runs on side streams beside the recurrent kernels" % (peak_fl / 1e12, PEAK_HBM_GBS))
+    # why a class sits below 0.6 of its roof, in one line each (measured: NOTEBOOK A.7)
+    out["below_roof_because"] = {
+        "gemm_wide": "every product runs with cold operands behind a recurrent kernel (the same kernels back to back: 0.7 x the time); the "
+                     "input projections write 61 MB of fp32 pre-activations each (their stores alone take 14 of 27 us, bf16 results cost the "
+                     "bf16 mode's pin a factor of two: option pre16); a fraction's rows are T_max x PS, 15-30 % of them dummy frames that the roof "
+                     "does not count -- only the panel kernel (long-K, narrow-N products) skips them",
+        "gemm_grad": "split-K over the frames in 64 x 64 tiles on the 80 CUs of a masked stream beside the recurrent kernels (hidden there: "
+                     "only the first layer's group, ~30 us on the whole chip, is on the critical path); deeper prefetch measured slower",
+    }
     return out
 
 
