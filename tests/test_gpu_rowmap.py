@@ -1,4 +1,5 @@
-"""-m gpu: the fraction's row map (GemmNT::rowmap, cn_internal.h; option "no_nt_rowmap" switches it off).
+"""-m gpu: the fraction's row map (GemmNT::rowmap, cn_internal.h; option "no_nt_rowmap" switches it off; by default the panel
+kernel takes it -- the error products of the headline step --, with "nt_rowmap_tiled" gemm_nt_kernel does too: both run here).
 
 The reference multiplies ALL T x PS frames of a fraction in its N-wide products (LstmLayer.cu:771-786,990-1009,
 FeedForwardLayer.cu:143-160,188-198), dummy ones included; every operand row of a dummy frame is zero there (y = 0 and
@@ -65,10 +66,10 @@ def test_row_map_changes_no_visible_bit(pkg, mode):
             assert np.array_equal(a, b), (name, i, np.abs(a - b).max())
 
 
-def test_row_map_is_used_by_the_headline_products(pkg):
-    """... and it is not a dead switch: with the map the N-wide products behind LSTM layers run the panel kernel on the
-    headline's fraction (the estimated real rows fit one round of CUs), which the timing classes cannot show -- so count rows:
-    the map of a fraction lists exactly the frames whose patType is not NONE from the shortest sequence's end on."""
+def test_row_map_lists_the_frames_nobody_checks_as_real(pkg):
+    """The map itself (cn_dbg_row_map_counts): real = every frame in front of the shortest sequence's end (nobody checks patTypes
+    there: empty and pad slots are computed like any other, by the reference too) + the frames whose patType is not NONE behind
+    it; dummy = the rest; together all T x padded-PS rows."""
     rng = np.random.RandomState(3)
     P, C, PS, T = 39, 183, 50, 120
     layers = net_desc(P, [("blstm", 250)] * 2, C)
